@@ -1,0 +1,139 @@
+"""Deterministic synthetic clouds for the BASELINE.json configs.
+
+model  = points on a closed, asymmetric star-shaped surface inside a 0.2 m box
+         (superellipsoid radial function + 3 Gaussian bumps), area-weighted
+         rejection sampling, fp32.
+scene  = the same surface re-sampled independently (different sample points, so
+         NN distances are non-zero) + 10 % uniform clutter in a 0.4 m box, moved
+         by the ground-truth pose Rz(12°)·Ry(−7°)·Rx(5°), t=(0.015,−0.010,0.020) m,
+         plus N(0,(0.5 mm)²) noise, then shuffled (sensor order is not spatial).
+
+numpy's PCG64 stream is platform-independent, so both boxes generate identical
+clouds from the seeds alone; nothing is read from disk.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_AXES = np.array([0.100, 0.075, 0.050])          # superellipsoid semi-axes (m)
+_POW = 2.5
+_BUMP_DIR = np.array([[0.80, 0.35, 0.48], [-0.30, 0.90, -0.31], [0.10, -0.55, 0.83]])
+_BUMP_DIR = _BUMP_DIR / np.linalg.norm(_BUMP_DIR, axis=1, keepdims=True)
+_BUMP_AMP = np.array([0.22, -0.15, 0.30])
+_BUMP_SIG = np.array([0.35, 0.50, 0.25])          # radians
+
+
+def _radius(u: np.ndarray) -> np.ndarray:
+    """Radial function r(u) of the star-shaped model surface; u unit vectors (n,3)."""
+    se = (np.abs(u / _AXES) ** _POW).sum(axis=1) ** (-1.0 / _POW)
+    ang = np.arccos(np.clip(u @ _BUMP_DIR.T, -1.0, 1.0))           # (n,3)
+    bump = (_BUMP_AMP * np.exp(-(ang / _BUMP_SIG) ** 2)).sum(axis=1)
+    return se * (1.0 + bump)
+
+
+def _sample_dirs(rng: np.random.Generator, m: int) -> np.ndarray:
+    v = rng.standard_normal((m, 3))
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def model_surface(n: int, seed: int = 1, return_normals: bool = False):
+    """n points on the model surface, approximately area-uniform. float32 (n,3)."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, 3), np.float64)
+    nrm = np.empty((n, 3), np.float64) if return_normals else None
+    got = 0
+    h = 1e-4
+    w_max = None
+    while got < n:
+        m = max(4096, int((n - got) * 2.2))
+        u = _sample_dirs(rng, m)
+        # tangent frame
+        a = np.where(np.abs(u[:, :1]) < 0.9, np.array([[1.0, 0, 0]]), np.array([[0, 1.0, 0]]))
+        e1 = np.cross(u, a); e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
+        e2 = np.cross(u, e1)
+        r = _radius(u)
+
+        def rr(d):
+            q = u + h * d
+            return _radius(q / np.linalg.norm(q, axis=1, keepdims=True))
+
+        g1 = (rr(e1) - rr(-e1)) / (2 * h)
+        g2 = (rr(e2) - rr(-e2)) / (2 * h)
+        w = r * np.sqrt(r * r + g1 * g1 + g2 * g2)          # dA/dΩ
+        if w_max is None:
+            w_max = 1.25 * w.max()
+        keep = rng.random(m) * w_max < w
+        p = (u * r[:, None])[keep]
+        k = min(len(p), n - got)
+        out[got:got + k] = p[:k]
+        if return_normals:
+            # surface normal of p(u)=r(u)u :  n ∝ r u − ∇_S r
+            nn = (r[:, None] * u - g1[:, None] * e1 - g2[:, None] * e2)[keep][:k]
+            nrm[got:got + k] = nn / np.linalg.norm(nn, axis=1, keepdims=True)
+        got += k
+    if return_normals:
+        return out.astype(np.float32), nrm.astype(np.float32)
+    return out.astype(np.float32)
+
+
+def rot_xyz(rx_deg: float, ry_deg: float, rz_deg: float) -> np.ndarray:
+    """Rz·Ry·Rx (degrees) as float64 (3,3)."""
+    rx, ry, rz = np.deg2rad([rx_deg, ry_deg, rz_deg])
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+GT_R = rot_xyz(5.0, -7.0, 12.0)
+GT_T = np.array([0.015, -0.010, 0.020])
+
+
+def ground_truth_pose() -> np.ndarray:
+    """4x4 (math layout) that maps model coordinates to scene coordinates."""
+    T = np.eye(4)
+    T[:3, :3] = GT_R
+    T[:3, 3] = GT_T
+    return T
+
+
+def scene_cloud(n: int, seed_surface: int = 2, seed_clutter: int = 3, seed_noise: int = 4,
+                clutter_frac: float = 0.10, noise_sigma: float = 0.0005, shuffle: bool = True,
+                R: np.ndarray | None = None, t: np.ndarray | None = None) -> np.ndarray:
+    """n scene points: re-sampled surface ∪ clutter, posed, noised. float32 (n,3)."""
+    R = GT_R if R is None else R
+    t = GT_T if t is None else t
+    n_surf = int(round(n / (1.0 + clutter_frac)))
+    n_clut = n - n_surf
+    surf = model_surface(n_surf, seed_surface).astype(np.float64)
+    rc = np.random.default_rng(seed_clutter)
+    clut = rc.uniform(-0.2, 0.2, size=(n_clut, 3))
+    pts = np.concatenate([surf, clut], axis=0)
+    pts = pts @ R.T + t
+    rn = np.random.default_rng(seed_noise)
+    pts += rn.standard_normal(pts.shape) * noise_sigma
+    if shuffle:
+        pts = pts[rn.permutation(len(pts))]
+    return pts.astype(np.float32)
+
+
+def config_clouds(name: str):
+    """(scene=source, model=target) for a BASELINE.json config: 'C2' or 'C3'."""
+    if name == "C2":
+        return scene_cloud(100_000), model_surface(20_000, 1)
+    if name == "C3":
+        return scene_cloud(1_000_000), model_surface(100_000, 1)
+    raise ValueError(name)
+
+
+def bumpy_torus(n: int, seed: int = 11) -> np.ndarray:
+    """KAT-1 cloud: points on a bumpy torus (unique ICP optimum). float32 (n,3)."""
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(0, 2 * np.pi, n)
+    b = rng.uniform(0, 2 * np.pi, n)
+    R0, r0 = 0.08, 0.03 * (1 + 0.3 * np.sin(3 * a) * np.cos(2 * b) + 0.2 * np.cos(a))
+    x = (R0 + r0 * np.cos(b)) * np.cos(a)
+    y = (R0 + r0 * np.cos(b)) * np.sin(a) * 0.8
+    z = r0 * np.sin(b) + 0.01 * np.sin(2 * a)
+    return np.stack([x, y, z], axis=1).astype(np.float32)

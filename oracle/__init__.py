@@ -1,0 +1,347 @@
+"""ctypes binding of the CPU ORACLE (oracle/libope_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+PARITY UNPINNED — see oracle/ope_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libope_oracle.so")
+_SRCS = ["kdtree.c", "icp.c", "features.c", "ope_oracle.h", "Makefile"]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds)."""
+    stale = force or not os.path.exists(_LIB_PATH)
+    if not stale:
+        t = os.path.getmtime(_LIB_PATH)
+        stale = any(os.path.getmtime(os.path.join(_HERE, s)) > t for s in _SRCS)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "libope_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+class IcpParams(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int),
+        ("transformation_epsilon", C.c_double),
+        ("euclidean_fitness_epsilon", C.c_double),
+        ("max_corr_dist", C.c_double),
+        ("use_reciprocal", C.c_int),
+        ("min_correspondences", C.c_int),
+        ("corr_mode", C.c_int),
+        ("k_normal_shooting", C.c_int),
+        ("use_surface_normal_rej", C.c_int),
+        ("surface_normal_thr", C.c_double),
+        ("use_self_occluded_rej", C.c_int),
+        ("self_occluded_thr", C.c_double),
+        ("mse_threshold_absolute", C.c_double),
+        ("failure_after_max_iter", C.c_int),
+        ("acc_mode", C.c_int),
+        ("transform_mode", C.c_int),
+    ]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int),
+        ("converged", C.c_int),
+        ("state", C.c_int),
+        ("last_mse", C.c_double),
+        ("n_corr", C.c_int),
+        ("fitness", C.c_double),
+        ("align_strength", C.c_double),
+    ]
+
+
+class Convergence(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int),
+        ("failure_after_max_iter", C.c_int),
+        ("rotation_threshold", C.c_double),
+        ("translation_threshold", C.c_double),
+        ("mse_threshold_relative", C.c_double),
+        ("mse_threshold_absolute", C.c_double),
+        ("max_iterations_similar_transforms", C.c_int),
+        ("iterations_similar_transforms", C.c_int),
+        ("prev_mse", C.c_double),
+        ("cur_mse", C.c_double),
+        ("state", C.c_int),
+    ]
+
+
+CONV_NAMES = ["NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE", "NO_CORRESPONDENCES"]
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_dp = C.POINTER(C.c_double)
+_lp = C.POINTER(C.c_int64)
+
+
+def _declare(L):
+    L.orc_kdtree_build.restype = C.c_void_p
+    L.orc_kdtree_build.argtypes = [_fp, C.c_int, C.c_int]
+    L.orc_kdtree_free.argtypes = [C.c_void_p]
+    L.orc_kdtree_knn.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, _ip, _fp, _ip]
+    L.orc_kdtree_radius.restype = C.c_int64
+    L.orc_kdtree_radius.argtypes = [C.c_void_p, _fp, C.c_int, C.c_float, C.c_int, _lp, _ip, _fp, C.c_int64]
+    L.orc_bruteforce_nn.argtypes = [_fp, C.c_int, _fp, C.c_int, _ip, _fp]
+    L.orc_umeyama.restype = C.c_int
+    L.orc_umeyama.argtypes = [_fp, _fp, C.c_int, C.c_int, _fp]
+    L.orc_umeyama_from_sums.restype = C.c_int
+    L.orc_umeyama_from_sums.argtypes = [_dp, _dp, _fp]
+    L.orc_svd3.argtypes = [_dp, _dp, _dp, _dp]
+    L.orc_convergence_init.argtypes = [C.POINTER(Convergence)]
+    L.orc_convergence_step.restype = C.c_int
+    L.orc_convergence_step.argtypes = [C.POINTER(Convergence), C.c_int, _fp, C.c_double]
+    L.orc_icp_default_params.argtypes = [C.POINTER(IcpParams)]
+    L.orc_icp.restype = C.c_int
+    L.orc_icp.argtypes = [_fp, _fp, C.c_int, _fp, _fp, C.c_int, _fp, C.POINTER(IcpParams), _fp,
+                          C.POINTER(IcpResult), _fp, _ip, _ip, _fp]
+    L.orc_fitness.restype = C.c_double
+    L.orc_fitness.argtypes = [_fp, C.c_int, _fp, C.c_int, _fp, C.c_double, C.POINTER(C.c_int)]
+    L.orc_icp_partial_sums.argtypes = [_fp, C.c_int, C.c_void_p, _fp, _fp, C.c_double, _dp, _dp]
+    L.orc_transform_points.argtypes = [_fp, C.c_int, _fp, _fp]
+    L.orc_transform_normals.argtypes = [_fp, C.c_int, _fp, _fp]
+    L.orc_normals_knn.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, _fp]
+    L.orc_pair_features.restype = C.c_int
+    L.orc_pair_features.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]
+    L.orc_fpfh.argtypes = [_fp, _fp, C.c_int, C.c_float, _fp, _fp, _dp]
+    L.orc_uniform_sampling.restype = C.c_int
+    L.orc_uniform_sampling.argtypes = [_fp, C.c_int, C.c_float, _ip]
+    L.orc_sacia_error.restype = C.c_double
+    L.orc_sacia_error.argtypes = [_fp, C.c_int, C.c_void_p, _fp, C.c_double]
+    L.orc_sacia.restype = C.c_int
+    L.orc_sacia.argtypes = [_fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                            C.c_float, C.c_uint64, _ip, _fp, _dp, _ip]
+    L.orc_feature_knn.argtypes = [_fp, C.c_int, _fp, C.c_int, C.c_int, _ip, _fp]
+
+
+def _f32(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if cols is not None:
+        assert a.ndim == 2 and a.shape[1] == cols, a.shape
+    return a
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class KdTree:
+    """Exact k-NN / radius search (stand-in for pcl::search::KdTree)."""
+
+    def __init__(self, xyz, leaf_max: int = 15):
+        self.xyz = _f32(xyz, 3)
+        self.h = lib().orc_kdtree_build(_p(self.xyz, _fp), len(self.xyz), leaf_max)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_kdtree_free(self.h)
+            self.h = None
+
+    def knn(self, q, k: int = 1):
+        q = _f32(q, 3)
+        idx = np.empty((len(q), k), np.int32)
+        d2 = np.empty((len(q), k), np.float32)
+        found = np.empty(len(q), np.int32)
+        lib().orc_kdtree_knn(self.h, _p(q, _fp), len(q), k, _p(idx, _ip), _p(d2, _fp), _p(found, _ip))
+        return idx, d2, found
+
+    def radius(self, q, r: float, sorted_: bool = True):
+        q = _f32(q, 3)
+        offs = np.empty(len(q) + 1, np.int64)
+        total = lib().orc_kdtree_radius(self.h, _p(q, _fp), len(q), r, int(sorted_), _p(offs, _lp), None, None, 0)
+        idx = np.empty(max(total, 1), np.int32)
+        d2 = np.empty(max(total, 1), np.float32)
+        lib().orc_kdtree_radius(self.h, _p(q, _fp), len(q), r, int(sorted_), _p(offs, _lp), _p(idx, _ip),
+                                _p(d2, _fp), total)
+        return offs, idx[:total], d2[:total]
+
+
+def bruteforce_nn(tgt, q):
+    tgt, q = _f32(tgt, 3), _f32(q, 3)
+    idx = np.empty(len(q), np.int32)
+    d2 = np.empty(len(q), np.float32)
+    lib().orc_bruteforce_nn(_p(tgt, _fp), len(tgt), _p(q, _fp), len(q), _p(idx, _ip), _p(d2, _fp))
+    return idx, d2
+
+
+def umeyama(src, tgt, acc_mode: int = 0) -> np.ndarray:
+    """Returns the 4x4 as a numpy (4,4) array in MATH layout (T[r,c])."""
+    src, tgt = _f32(src, 3), _f32(tgt, 3)
+    T = np.empty(16, np.float32)
+    rc = lib().orc_umeyama(_p(src, _fp), _p(tgt, _fp), len(src), acc_mode, _p(T, _fp))
+    assert rc == 0
+    return T.reshape(4, 4).T.copy()
+
+
+def umeyama_from_sums(S, pivot) -> np.ndarray:
+    S = np.ascontiguousarray(S, np.float64)
+    pivot = np.ascontiguousarray(pivot, np.float64)
+    T = np.empty(16, np.float32)
+    rc = lib().orc_umeyama_from_sums(_p(S, _dp), _p(pivot, _dp), _p(T, _fp))
+    assert rc == 0
+    return T.reshape(4, 4).T.copy()
+
+
+def svd3(A):
+    A = np.ascontiguousarray(A, np.float64)
+    U = np.empty((3, 3)); s = np.empty(3); V = np.empty((3, 3))
+    lib().orc_svd3(_p(A, _dp), _p(U, _dp), _p(s, _dp), _p(V, _dp))
+    return U, s, V
+
+
+def colmajor(T) -> np.ndarray:
+    """(4,4) math-layout matrix -> column-major float[16]."""
+    return np.ascontiguousarray(np.asarray(T, np.float32).T).reshape(16)
+
+
+def default_icp_params() -> IcpParams:
+    p = IcpParams()
+    lib().orc_icp_default_params(C.byref(p))
+    return p
+
+
+@dataclass
+class IcpOut:
+    T: np.ndarray
+    iterations: int
+    converged: bool
+    state: int
+    last_mse: float
+    n_corr: int
+    fitness: float
+    align_strength: float
+    T_hist: np.ndarray
+    corr_q: np.ndarray
+    corr_m: np.ndarray
+    corr_d2: np.ndarray
+
+
+def icp(src, tgt, params: IcpParams | None = None, guess=None, src_nrm=None, tgt_nrm=None) -> IcpOut:
+    src, tgt = _f32(src, 3), _f32(tgt, 3)
+    p = params or default_icp_params()
+    sn = _f32(src_nrm, 3) if src_nrm is not None else None
+    tn = _f32(tgt_nrm, 3) if tgt_nrm is not None else None
+    g = colmajor(guess) if guess is not None else None
+    T = np.empty(16, np.float32)
+    res = IcpResult()
+    hist = np.zeros((max(p.max_iterations, 1), 16), np.float32)
+    cq = np.empty(len(src), np.int32); cm = np.empty(len(src), np.int32); cd = np.empty(len(src), np.float32)
+    rc = lib().orc_icp(_p(src, _fp), _p(sn, _fp), len(src), _p(tgt, _fp), _p(tn, _fp), len(tgt), _p(g, _fp),
+                       C.byref(p), _p(T, _fp), C.byref(res), _p(hist, _fp), _p(cq, _ip), _p(cm, _ip), _p(cd, _fp))
+    if rc != 0:
+        raise ValueError(f"orc_icp rc={rc}")
+    n = res.n_corr
+    return IcpOut(T.reshape(4, 4).T.copy(), res.iterations, bool(res.converged), res.state, res.last_mse, n,
+                  res.fitness, res.align_strength,
+                  hist[: res.iterations].reshape(-1, 4, 4).transpose(0, 2, 1).copy(), cq[:n], cm[:n], cd[:n])
+
+
+def fitness(src, tgt, T, max_range: float = np.finfo(np.float64).max):
+    src, tgt = _f32(src, 3), _f32(tgt, 3)
+    n = C.c_int(0)
+    t = colmajor(T)
+    v = lib().orc_fitness(_p(src, _fp), len(src), _p(tgt, _fp), len(tgt), _p(t, _fp), max_range, C.byref(n))
+    return v, n.value
+
+
+def icp_partial_sums(src, tree: KdTree, T, max_corr_dist, pivot) -> np.ndarray:
+    src = _f32(src, 3)
+    t = colmajor(T)
+    pv = np.ascontiguousarray(pivot, np.float64)
+    S = np.empty(17, np.float64)
+    lib().orc_icp_partial_sums(_p(src, _fp), len(src), tree.h, _p(tree.xyz, _fp), _p(t, _fp), max_corr_dist,
+                               _p(pv, _dp), _p(S, _dp))
+    return S
+
+
+def transform_points(xyz, T):
+    xyz = _f32(xyz, 3)
+    out = np.empty_like(xyz)
+    t = colmajor(T)
+    lib().orc_transform_points(_p(xyz, _fp), len(xyz), _p(t, _fp), _p(out, _fp))
+    return out
+
+
+def normals_knn(xyz, k: int = 30, vp=(0.0, 0.0, 0.0)):
+    xyz = _f32(xyz, 3)
+    v = np.asarray(vp, np.float32)
+    nrm = np.empty_like(xyz)
+    curv = np.empty(len(xyz), np.float32)
+    lib().orc_normals_knn(_p(xyz, _fp), len(xyz), k, _p(v, _fp), _p(nrm, _fp), _p(curv, _fp))
+    return nrm, curv
+
+
+def pair_features(p1, n1, p2, n2):
+    a = [np.asarray(x, np.float32) for x in (p1, n1, p2, n2)]
+    f = [C.c_float() for _ in range(4)]
+    ok = lib().orc_pair_features(*[_p(x, _fp) for x in a], *[C.byref(x) for x in f])
+    return bool(ok), tuple(x.value for x in f)
+
+
+def fpfh(xyz, nrm, radius: float):
+    xyz, nrm = _f32(xyz, 3), _f32(nrm, 3)
+    out = np.empty((len(xyz), 33), np.float32)
+    spfh = np.empty((len(xyz), 33), np.float32)
+    mean_nb = C.c_double(0)
+    lib().orc_fpfh(_p(xyz, _fp), _p(nrm, _fp), len(xyz), radius, _p(out, _fp), _p(spfh, _fp), C.byref(mean_nb))
+    return out, spfh, mean_nb.value
+
+
+def uniform_sampling(xyz, leaf: float) -> np.ndarray:
+    xyz = _f32(xyz, 3)
+    out = np.empty(len(xyz), np.int32)
+    n = lib().orc_uniform_sampling(_p(xyz, _fp), len(xyz), leaf, _p(out, _ip))
+    return out[:n].copy()
+
+
+def feature_knn(feat, q, k: int):
+    feat, q = _f32(feat, 33), _f32(q, 33)
+    idx = np.empty((len(q), k), np.int32)
+    d2 = np.empty((len(q), k), np.float32)
+    lib().orc_feature_knn(_p(feat, _fp), len(feat), _p(q, _fp), len(q), k, _p(idx, _ip), _p(d2, _fp))
+    return idx, d2
+
+
+def sacia_error(src, tree: KdTree, T, thr: float) -> float:
+    src = _f32(src, 3)
+    t = colmajor(T)
+    return lib().orc_sacia_error(_p(src, _fp), len(src), tree.h, _p(t, _fp), thr)
+
+
+def sacia(src, src_feat, tgt, tgt_feat, n_iter=400, nr_samples=5, k_corr=5, max_corr_dist=0.05,
+          min_sample_dist=0.01, seed=1, forced_samples=None):
+    src, tgt = _f32(src, 3), _f32(tgt, 3)
+    sf, tf = _f32(src_feat, 33), _f32(tgt_feat, 33)
+    fs = np.ascontiguousarray(forced_samples, np.int32) if forced_samples is not None else None
+    T = np.empty(16, np.float32)
+    err = C.c_double(0)
+    bi = C.c_int32(-1)
+    rc = lib().orc_sacia(_p(src, _fp), _p(sf, _fp), len(src), _p(tgt, _fp), _p(tf, _fp), len(tgt), n_iter,
+                         nr_samples, k_corr, max_corr_dist, min_sample_dist, seed, _p(fs, _ip), _p(T, _fp),
+                         C.byref(err), C.byref(bi))
+    if rc != 0:
+        raise ValueError(f"orc_sacia rc={rc}")
+    return T.reshape(4, 4).T.copy(), err.value, bi.value

@@ -1,0 +1,538 @@
+/*
+ * icp.c — CPU ORACLE (test infrastructure, not product code; parity unpinned,
+ * see ope_oracle.h).
+ *
+ * Restates, step for step:
+ *   IterativeClosestPoint::computeTransformation   impl/icp_mod.hpp:119-272
+ *   IterativeClosestPoint::transformCloud          impl/icp_mod.hpp:48-115
+ *   Registration::align / getFitnessScore          impl/registration_mod.hpp:131-219
+ *   CorrespondenceEstimation::determine*           impl/correspondence_estimation_mod.hpp:127-303
+ *   normal shooting                                impl/correspondence_estimation_normal_shooting_weighted.hpp:107-145
+ *   rejector scores                                correspondence_rejection_mod.h:368-391
+ *   self-occluded rejector                         impl/correspondence_rejection_self_occluded_normal.cpp:43-64
+ *   DefaultConvergenceCriteria                     default_convergence_criteria_mod.h:94-121,226-234
+ *   getAlignStrength                               icp_mod.h:249-260
+ * and, from the un-vendored PCL 1.7.x / Eigen 3 (published algorithms):
+ *   DefaultConvergenceCriteria::hasConverged, TransformationEstimationSVD
+ *   (use_umeyama_) -> Eigen::umeyama(src, dst, with_scaling=false).
+ */
+#include "ope_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ */
+/* 3x3 SVD by cyclic Jacobi on A^T A, then U = A V / s with            */
+/* Gram-Schmidt completion for (near-)zero singular values.            */
+/* ------------------------------------------------------------------ */
+static void jacobi_eig3(double S[9], double V[9]) {
+  /* S symmetric (row-major), on exit diagonal holds eigenvalues, V columns eigenvectors */
+  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = fabs(S[1]) + fabs(S[2]) + fabs(S[5]);
+    double diag = fabs(S[0]) + fabs(S[4]) + fabs(S[8]);
+    if (off <= 1e-300 || off <= 1e-17 * diag) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double apq = S[3 * p + q];
+        if (apq == 0.0) continue;
+        double app = S[3 * p + p], aqq = S[3 * q + q];
+        double theta = (aqq - app) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) { /* columns p,q of S */
+          double skp = S[3 * k + p], skq = S[3 * k + q];
+          S[3 * k + p] = c * skp - s * skq;
+          S[3 * k + q] = s * skp + c * skq;
+        }
+        for (int k = 0; k < 3; ++k) { /* rows p,q of S */
+          double spk = S[3 * p + k], sqk = S[3 * q + k];
+          S[3 * p + k] = c * spk - s * sqk;
+          S[3 * q + k] = s * spk + c * sqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          double vkp = V[3 * k + p], vkq = V[3 * k + q];
+          V[3 * k + p] = c * vkp - s * vkq;
+          V[3 * k + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+}
+
+static double det3(const double M[9]) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+void orc_svd3(const double A[9], double U[9], double s[3], double V[9]) {
+  double AtA[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += A[3 * k + i] * A[3 * k + j];
+      AtA[3 * i + j] = a;
+    }
+  double Vt[9];
+  jacobi_eig3(AtA, Vt);
+  double ev[3] = {AtA[0], AtA[4], AtA[8]};
+  int ord[3] = {0, 1, 2};
+  for (int i = 0; i < 2; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (ev[ord[j]] > ev[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+  for (int c = 0; c < 3; ++c) {
+    for (int r = 0; r < 3; ++r) V[3 * r + c] = Vt[3 * r + ord[c]];
+  }
+  /* singular values = |A v_c| (more accurate than sqrt(eig) for small ones) */
+  double Ucol[3][3];
+  for (int c = 0; c < 3; ++c) {
+    for (int r = 0; r < 3; ++r) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += A[3 * r + k] * V[3 * k + c];
+      Ucol[c][r] = a;
+    }
+    s[c] = sqrt(Ucol[c][0] * Ucol[c][0] + Ucol[c][1] * Ucol[c][1] + Ucol[c][2] * Ucol[c][2]);
+  }
+  /* orthonormalise U columns (modified Gram-Schmidt with completion) */
+  double tiny = 1e-14 * (s[0] > 0 ? s[0] : 1.0);
+  for (int c = 0; c < 3; ++c) {
+    double *u = Ucol[c];
+    for (int p = 0; p < c; ++p) {
+      double d = u[0] * Ucol[p][0] + u[1] * Ucol[p][1] + u[2] * Ucol[p][2];
+      for (int r = 0; r < 3; ++r) u[r] -= d * Ucol[p][r];
+    }
+    double nrm = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    if (s[c] <= tiny || nrm <= 1e-8 * (s[c] > 0 ? s[c] : 1.0) + 1e-300) {
+      /* pick any unit vector orthogonal to previous columns */
+      if (c == 0) { u[0] = 1; u[1] = 0; u[2] = 0; }
+      else if (c == 1) {
+        const double *a = Ucol[0];
+        int m = fabs(a[0]) < fabs(a[1]) ? (fabs(a[0]) < fabs(a[2]) ? 0 : 2) : (fabs(a[1]) < fabs(a[2]) ? 1 : 2);
+        double e[3] = {0, 0, 0};
+        e[m] = 1;
+        double d = a[m];
+        for (int r = 0; r < 3; ++r) u[r] = e[r] - d * a[r];
+      } else {
+        const double *a = Ucol[0], *b = Ucol[1];
+        u[0] = a[1] * b[2] - a[2] * b[1];
+        u[1] = a[2] * b[0] - a[0] * b[2];
+        u[2] = a[0] * b[1] - a[1] * b[0];
+      }
+      nrm = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    }
+    for (int r = 0; r < 3; ++r) u[r] /= nrm;
+  }
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) U[3 * r + c] = Ucol[c][r];
+}
+
+/* Eigen::umeyama tail: sigma (row-major, = 1/n * dst_demean * src_demean^T),
+ * means -> 4x4 column-major float. */
+static void umeyama_finish(const double sigma[9], const double src_mean[3], const double dst_mean[3], float T[16]) {
+  double U[9], s[3], V[9];
+  orc_svd3(sigma, U, s, V);
+  double S[3] = {1, 1, 1};
+  if (det3(sigma) < 0) S[2] = -1;
+  int rank = 0;
+  for (int i = 0; i < 3; ++i)
+    if (!(fabs(s[i]) <= fabs(s[0]) * 1e-5)) ++rank; /* Eigen isMuchSmallerThan(d_i, d_0), float dummy_precision 1e-5 */
+  double R[9];
+  if (rank == 2) {
+    if (det3(U) * det3(V) > 0) { S[0] = S[1] = S[2] = 1; }
+    else { S[0] = S[1] = 1; S[2] = -1; }
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += U[3 * i + k] * S[k] * V[3 * j + k];
+      R[3 * i + j] = a;
+    }
+  double t[3];
+  for (int i = 0; i < 3; ++i)
+    t[i] = dst_mean[i] - (R[3 * i] * src_mean[0] + R[3 * i + 1] * src_mean[1] + R[3 * i + 2] * src_mean[2]);
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) T[4 * c + r] = (float)R[3 * r + c];
+  T[3] = T[7] = T[11] = 0.f;
+  T[12] = (float)t[0]; T[13] = (float)t[1]; T[14] = (float)t[2]; T[15] = 1.f;
+}
+
+int orc_umeyama(const float *src, const float *tgt, int n, int acc_mode, float T[16]) {
+  if (n < 1) return -1;
+  double sm[3], dm[3], sigma[9];
+  if (acc_mode == 0) {
+    /* Scalar=float throughout, as pcl::umeyama instantiated by
+     * TransformationEstimationSVD<..., float> */
+    float smf[3] = {0, 0, 0}, dmf[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i)
+      for (int d = 0; d < 3; ++d) { smf[d] += src[3 * i + d]; dmf[d] += tgt[3 * i + d]; }
+    float inv = 1.0f / (float)n;
+    for (int d = 0; d < 3; ++d) { smf[d] *= inv; dmf[d] *= inv; }
+    float sg[9] = {0};
+    for (int i = 0; i < n; ++i) {
+      float a[3], b[3];
+      for (int d = 0; d < 3; ++d) { a[d] = src[3 * i + d] - smf[d]; b[d] = tgt[3 * i + d] - dmf[d]; }
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) sg[3 * r + c] += b[r] * a[c];
+    }
+    for (int k = 0; k < 9; ++k) sigma[k] = (double)(sg[k] * inv);
+    for (int d = 0; d < 3; ++d) { sm[d] = smf[d]; dm[d] = dmf[d]; }
+  } else {
+    double s0[3] = {0, 0, 0}, d0[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i)
+      for (int d = 0; d < 3; ++d) { s0[d] += src[3 * i + d]; d0[d] += tgt[3 * i + d]; }
+    for (int d = 0; d < 3; ++d) { sm[d] = s0[d] / n; dm[d] = d0[d] / n; }
+    for (int k = 0; k < 9; ++k) sigma[k] = 0;
+    for (int i = 0; i < n; ++i) {
+      double a[3], b[3];
+      for (int d = 0; d < 3; ++d) { a[d] = src[3 * i + d] - sm[d]; b[d] = tgt[3 * i + d] - dm[d]; }
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) sigma[3 * r + c] += b[r] * a[c];
+    }
+    for (int k = 0; k < 9; ++k) sigma[k] /= n;
+  }
+  umeyama_finish(sigma, sm, dm, T);
+  return 0;
+}
+
+int orc_umeyama_from_sums(const double S[17], const double pivot[3], float T[16]) {
+  double n = S[0];
+  if (n < 1) return -1;
+  double sm[3], dm[3], sigma[9];
+  for (int d = 0; d < 3; ++d) { sm[d] = S[1 + d] / n; dm[d] = S[4 + d] / n; }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) sigma[3 * r + c] = S[7 + 3 * r + c] / n - dm[r] * sm[c];
+  for (int d = 0; d < 3; ++d) { sm[d] += pivot[d]; dm[d] += pivot[d]; }
+  umeyama_finish(sigma, sm, dm, T);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+void orc_convergence_init(orc_convergence *c) {
+  c->max_iterations = 100;
+  c->failure_after_max_iter = 0;
+  c->rotation_threshold = 0.99999;
+  c->translation_threshold = 3e-4 * 3e-4;
+  c->mse_threshold_relative = 0.00001;
+  c->mse_threshold_absolute = 1e-12;
+  c->max_iterations_similar_transforms = 0;
+  c->iterations_similar_transforms = 0;
+  c->prev_mse = DBL_MAX;
+  c->cur_mse = DBL_MAX;
+  c->state = ORC_CONV_NOT_CONVERGED;
+}
+
+int orc_convergence_step(orc_convergence *c, int iterations, const float T[16], double mse) {
+  c->state = ORC_CONV_NOT_CONVERGED;
+  /* 1. iteration cap */
+  if (iterations >= c->max_iterations) {
+    if (c->failure_after_max_iter) return 0;
+    c->state = ORC_CONV_ITERATIONS;
+    return 1;
+  }
+  /* 2. incremental-transform epsilon */
+  double cos_angle = 0.5 * ((double)T[0] + (double)T[5] + (double)T[10] - 1.0);
+  double tr2 = (double)T[12] * T[12] + (double)T[13] * T[13] + (double)T[14] * T[14];
+  if (cos_angle >= c->rotation_threshold && tr2 <= c->translation_threshold) {
+    if (c->iterations_similar_transforms < c->max_iterations_similar_transforms) {
+      ++c->iterations_similar_transforms;
+      return 0;
+    }
+    c->iterations_similar_transforms = 0;
+    c->state = ORC_CONV_TRANSFORM;
+    return 1;
+  }
+  /* 3. MSE, absolute then relative */
+  c->cur_mse = mse;
+  if (fabs(c->cur_mse - c->prev_mse) < c->mse_threshold_absolute) {
+    if (c->iterations_similar_transforms < c->max_iterations_similar_transforms) {
+      ++c->iterations_similar_transforms;
+      return 0;
+    }
+    c->iterations_similar_transforms = 0;
+    c->state = ORC_CONV_ABS_MSE;
+    return 1;
+  }
+  if (fabs(c->cur_mse - c->prev_mse) / c->prev_mse < c->mse_threshold_relative) {
+    if (c->iterations_similar_transforms < c->max_iterations_similar_transforms) {
+      ++c->iterations_similar_transforms;
+      return 0;
+    }
+    c->iterations_similar_transforms = 0;
+    c->state = ORC_CONV_REL_MSE;
+    return 1;
+  }
+  c->prev_mse = c->cur_mse;
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+static inline int finite3(const float *p) { return isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]); }
+
+void orc_transform_points(const float *in, int n, const float T[16], float *out) {
+  for (int i = 0; i < n; ++i) {
+    const float *p = in + 3 * i;
+    float *o = out + 3 * i;
+    if (!finite3(p)) { if (o != p) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; } continue; }
+    float x = p[0], y = p[1], z = p[2];
+    /* Eigen 4x4 * (x,y,z,1): column-major accumulation */
+    o[0] = T[0] * x + T[4] * y + T[8] * z + T[12];
+    o[1] = T[1] * x + T[5] * y + T[9] * z + T[13];
+    o[2] = T[2] * x + T[6] * y + T[10] * z + T[14];
+  }
+}
+
+void orc_transform_normals(const float *in, int n, const float T[16], float *out) {
+  for (int i = 0; i < n; ++i) {
+    const float *p = in + 3 * i;
+    float *o = out + 3 * i;
+    if (!finite3(p)) { if (o != p) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; } continue; }
+    float x = p[0], y = p[1], z = p[2];
+    o[0] = T[0] * x + T[4] * y + T[8] * z;
+    o[1] = T[1] * x + T[5] * y + T[9] * z;
+    o[2] = T[2] * x + T[6] * y + T[10] * z;
+  }
+}
+
+static void mat4_mul_f(const float A[16], const float B[16], float C[16]) {
+  float R[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      float a = 0;
+      for (int k = 0; k < 4; ++k) a += A[4 * k + r] * B[4 * c + k];
+      R[4 * c + r] = a;
+    }
+  memcpy(C, R, sizeof R);
+}
+
+static void mat4_mul_d(const double A[16], const double B[16], double C[16]) {
+  double R[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      double a = 0;
+      for (int k = 0; k < 4; ++k) a += A[4 * k + r] * B[4 * c + k];
+      R[4 * c + r] = a;
+    }
+  memcpy(C, R, sizeof R);
+}
+
+static int is_identity(const float T[16]) {
+  for (int i = 0; i < 16; ++i)
+    if (T[i] != ((i % 5 == 0) ? 1.f : 0.f)) return 0;
+  return 1;
+}
+
+void orc_icp_default_params(orc_icp_params *p) {
+  memset(p, 0, sizeof *p);
+  p->max_iterations = 10;
+  p->transformation_epsilon = 0.0;
+  p->euclidean_fitness_epsilon = -DBL_MAX;
+  p->max_corr_dist = sqrt(DBL_MAX);
+  p->use_reciprocal = 0;
+  p->min_correspondences = 3;
+  p->corr_mode = 0;
+  p->k_normal_shooting = 20;
+  p->surface_normal_thr = 0.7;
+  p->self_occluded_thr = 0.6;
+  p->mse_threshold_absolute = 1e-12;
+  p->acc_mode = 0;
+  p->transform_mode = 0;
+}
+
+double orc_fitness(const float *src_xyz, int ns, const float *tgt_xyz, int nt, const float T[16],
+                   double max_range, int *n_used) {
+  orc_kdtree *tree = orc_kdtree_build(tgt_xyz, nt, 15);
+  double score = 0;
+  int nr = 0;
+  for (int i = 0; i < ns; ++i) {
+    float p[3];
+    orc_transform_points(src_xyz + 3 * i, 1, T, p);
+    int32_t id; float d; int32_t f;
+    orc_kdtree_knn(tree, p, 1, 1, &id, &d, &f);
+    if (f && (double)d <= max_range) { score += d; nr++; }
+  }
+  orc_kdtree_free(tree);
+  if (n_used) *n_used = nr;
+  return nr > 0 ? score / nr : DBL_MAX;
+}
+
+void orc_icp_partial_sums(const float *src_xyz, int ns, const orc_kdtree *tgt_tree, const float *tgt_xyz,
+                          const float T[16], double max_corr_dist, const double pivot[3], double S[17]) {
+  for (int k = 0; k < 17; ++k) S[k] = 0;
+  double md2 = max_corr_dist * max_corr_dist;
+  for (int i = 0; i < ns; ++i) {
+    if (!finite3(src_xyz + 3 * i)) continue;
+    float p[3];
+    orc_transform_points(src_xyz + 3 * i, 1, T, p);
+    int32_t id; float d; int32_t f;
+    orc_kdtree_knn(tgt_tree, p, 1, 1, &id, &d, &f);
+    if (!f || (double)d > md2) continue;
+    double s[3], t[3];
+    for (int k = 0; k < 3; ++k) { s[k] = (double)p[k] - pivot[k]; t[k] = (double)tgt_xyz[3 * id + k] - pivot[k]; }
+    S[0] += 1;
+    for (int k = 0; k < 3; ++k) { S[1 + k] += s[k]; S[4 + k] += t[k]; }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) S[7 + 3 * r + c] += t[r] * s[c];
+    S[16] += d;
+  }
+}
+
+int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt_xyz, const float *tgt_nrm, int nt,
+            const float guess[16], const orc_icp_params *p, float out_T[16], orc_icp_result *res, float *T_hist,
+            int32_t *corr_q_out, int32_t *corr_m_out, float *corr_d2_out) {
+  static const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  memset(res, 0, sizeof *res);
+  memcpy(out_T, I4, sizeof I4);
+  /* Registration::initCompute: no target -> error, silent return (registration_mod.hpp:73-77);
+   * setInputTarget rejects empty clouds (:60-64). */
+  if (nt <= 0 || !tgt_xyz) return -1;
+  if (ns <= 0 || !src_xyz) return -2;
+  if (!guess) guess = I4;
+  int need_src_nrm = (p->corr_mode == 1) || p->use_surface_normal_rej || p->use_self_occluded_rej;
+  int need_tgt_nrm = p->use_surface_normal_rej;
+  if ((need_src_nrm && !src_nrm) || (need_tgt_nrm && !tgt_nrm)) return -3;
+
+  orc_kdtree *tree = orc_kdtree_build(tgt_xyz, nt, 15);
+  orc_kdtree *rtree = NULL;
+
+  float *work = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
+  float *wnrm = src_nrm ? (float *)malloc(sizeof(float) * 3 * (size_t)ns) : NULL;
+  int32_t *cq = (int32_t *)malloc(sizeof(int32_t) * (size_t)ns);
+  int32_t *cm = (int32_t *)malloc(sizeof(int32_t) * (size_t)ns);
+  float *cd = (float *)malloc(sizeof(float) * (size_t)ns);
+  float *ps = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
+  float *pt = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
+  int kk = p->k_normal_shooting > 0 ? p->k_normal_shooting : 1;
+  int32_t *nn_i = (int32_t *)malloc(sizeof(int32_t) * (size_t)kk);
+  float *nn_d = (float *)malloc(sizeof(float) * (size_t)kk);
+
+  float final_T[16], Tk[16];
+  double final_Td[16];
+  memcpy(final_T, guess, sizeof final_T);
+  for (int i = 0; i < 16; ++i) final_Td[i] = guess[i];
+  if (!is_identity(guess)) {
+    orc_transform_points(src_xyz, ns, guess, work);
+    if (wnrm) orc_transform_normals(src_nrm, ns, guess, wnrm);
+  } else {
+    memcpy(work, src_xyz, sizeof(float) * 3 * (size_t)ns);
+    if (wnrm) memcpy(wnrm, src_nrm, sizeof(float) * 3 * (size_t)ns);
+  }
+  memcpy(Tk, I4, sizeof Tk);
+
+  orc_convergence cc;
+  orc_convergence_init(&cc);
+  cc.max_iterations = p->max_iterations;
+  cc.mse_threshold_relative = p->euclidean_fitness_epsilon;
+  cc.translation_threshold = p->transformation_epsilon;
+  cc.rotation_threshold = 1.0 - p->transformation_epsilon;
+  cc.mse_threshold_absolute = p->mse_threshold_absolute;
+  cc.failure_after_max_iter = p->failure_after_max_iter;
+
+  int iterations = 0, converged = 0, ncorr = 0;
+  double max_d2 = p->max_corr_dist * p->max_corr_dist;
+  do {
+    ncorr = 0;
+    if (p->use_reciprocal && !rtree) { /* source tree rebuilt every iteration: the dirty flag is set by setInputSource */ }
+    if (p->use_reciprocal) {
+      if (rtree) orc_kdtree_free(rtree);
+      rtree = orc_kdtree_build(work, ns, 15);
+    }
+    for (int i = 0; i < ns; ++i) {
+      const float *q = work + 3 * i;
+      if (!finite3(q)) continue;
+      if (p->corr_mode == 0) {
+        int32_t id; float d; int32_t f;
+        orc_kdtree_knn(tree, q, 1, 1, &id, &d, &f);
+        if (!f || (double)d > max_d2) continue;
+        if (p->use_reciprocal) {
+          int32_t rid; float rd; int32_t rf;
+          orc_kdtree_knn(rtree, tgt_xyz + 3 * id, 1, 1, &rid, &rd, &rf);
+          if (!rf || (double)rd > max_d2 || rid != i) continue;
+        }
+        cq[ncorr] = i; cm[ncorr] = id; cd[ncorr] = d; ++ncorr;
+      } else {
+        int32_t f;
+        orc_kdtree_knn(tree, q, 1, kk, nn_i, nn_d, &f);
+        if (f <= 0) continue;
+        double min_dist = DBL_MAX;
+        int min_index = 0;
+        const float *nq = wnrm + 3 * i;
+        for (int j = 0; j < f; ++j) {
+          /* pt = target - source in float, then double cross product */
+          float vx = tgt_xyz[3 * nn_i[j]] - q[0], vy = tgt_xyz[3 * nn_i[j] + 1] - q[1], vz = tgt_xyz[3 * nn_i[j] + 2] - q[2];
+          double N[3] = {nq[0], nq[1], nq[2]}, V[3] = {vx, vy, vz};
+          double C[3] = {N[1] * V[2] - N[2] * V[1], N[2] * V[0] - N[0] * V[2], N[0] * V[1] - N[1] * V[0]};
+          double dist = C[0] * C[0] + C[1] * C[1] + C[2] * C[2];
+          if (dist < min_dist) { min_dist = dist; min_index = j; }
+        }
+        /* quirk Q2: squared line distance compared against the UNSQUARED max distance */
+        if (min_dist > p->max_corr_dist) continue;
+        cq[ncorr] = i; cm[ncorr] = nn_i[min_index]; cd[ncorr] = nn_d[min_index]; ++ncorr;
+      }
+    }
+    /* rejectors, in the order they were added (poseestimator.cpp:334-337) */
+    if (p->use_surface_normal_rej) {
+      int m = 0;
+      for (int c = 0; c < ncorr; ++c) {
+        const float *a = wnrm + 3 * cq[c], *b = tgt_nrm + 3 * cm[c];
+        double score = (double)((a[0] * b[0]) + (a[1] * b[1]) + (a[2] * b[2]));
+        if (score > p->surface_normal_thr) { cq[m] = cq[c]; cm[m] = cm[c]; cd[m] = cd[c]; ++m; }
+      }
+      ncorr = m;
+    }
+    if (p->use_self_occluded_rej) {
+      int m = 0;
+      for (int c = 0; c < ncorr; ++c) {
+        const float *a = wnrm + 3 * cq[c], *pp = work + 3 * cq[c];
+        double s = sqrt((double)(pp[0] * pp[0] + pp[1] * pp[1] + pp[2] * pp[2]));
+        double score = (double)((a[0] * (-pp[0] / s)) + (a[1] * (-pp[1] / s)) + (a[2] * (-pp[2] / s)));
+        if (score > p->self_occluded_thr) { cq[m] = cq[c]; cm[m] = cm[c]; cd[m] = cd[c]; ++m; }
+      }
+      ncorr = m;
+    }
+    if (ncorr < p->min_correspondences) {
+      cc.state = ORC_CONV_NO_CORRESPONDENCES;
+      converged = 0;
+      break;
+    }
+    for (int c = 0; c < ncorr; ++c) {
+      memcpy(ps + 3 * c, work + 3 * cq[c], 3 * sizeof(float));
+      memcpy(pt + 3 * c, tgt_xyz + 3 * cm[c], 3 * sizeof(float));
+    }
+    orc_umeyama(ps, pt, ncorr, p->acc_mode, Tk);
+    if (p->transform_mode == 0) {
+      orc_transform_points(work, ns, Tk, work);
+      if (wnrm) orc_transform_normals(wnrm, ns, Tk, wnrm);
+      mat4_mul_f(Tk, final_T, final_T);
+    } else {
+      double Tkd[16];
+      for (int i = 0; i < 16; ++i) Tkd[i] = Tk[i];
+      mat4_mul_d(Tkd, final_Td, final_Td);
+      for (int i = 0; i < 16; ++i) final_T[i] = (float)final_Td[i];
+      orc_transform_points(src_xyz, ns, final_T, work);
+      if (wnrm) orc_transform_normals(src_nrm, ns, final_T, wnrm);
+    }
+    if (T_hist) memcpy(T_hist + 16 * (size_t)iterations, final_T, sizeof final_T);
+    ++iterations;
+    double mse = 0;
+    for (int c = 0; c < ncorr; ++c) mse += cd[c];
+    mse /= (double)ncorr;
+    converged = orc_convergence_step(&cc, iterations, Tk, mse);
+  } while (!converged);
+
+  memcpy(out_T, final_T, sizeof final_T);
+  res->iterations = iterations;
+  res->converged = converged;
+  res->state = cc.state;
+  res->last_mse = cc.cur_mse;
+  res->n_corr = ncorr;
+  res->align_strength = (double)ncorr / (double)(ns + nt);
+  res->fitness = orc_fitness(src_xyz, ns, tgt_xyz, nt, final_T, DBL_MAX, NULL);
+  if (corr_q_out) memcpy(corr_q_out, cq, sizeof(int32_t) * (size_t)ncorr);
+  if (corr_m_out) memcpy(corr_m_out, cm, sizeof(int32_t) * (size_t)ncorr);
+  if (corr_d2_out) memcpy(corr_d2_out, cd, sizeof(float) * (size_t)ncorr);
+
+  free(work); free(wnrm); free(cq); free(cm); free(cd); free(ps); free(pt); free(nn_i); free(nn_d);
+  orc_kdtree_free(tree);
+  if (rtree) orc_kdtree_free(rtree);
+  return 0;
+}

@@ -1,0 +1,219 @@
+/*
+ * ope_oracle.h — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the registration hot path of
+ * gopi-erabati/Object-Pose-Estimation (DetectAndLocalize): the vendored,
+ * modified PCL ICP loop plus the un-vendored PCL 1.7.x primitives it calls.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or sample
+ * scenes, and PCL/Eigen/FLANN are not installed here, so the reference itself
+ * cannot be run.  This oracle is pinned only by analytic known-answer tests
+ * and independent numpy/scipy cross-checks (tests/test_oracle_*.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call anything in this directory.  The product library
+ * (object-pose-estimation_amd/libope_hip.so) never does.
+ *
+ * All 4x4 transforms are COLUMN-MAJOR float[16] (Eigen::Matrix4f layout;
+ * T[12..14] is the translation), as in the reference
+ * (DetectAndLocalize/src/rosinterface.cpp:435-437).
+ * Point arrays are packed float xyz triples; normals likewise.
+ */
+#ifndef OPE_ORACLE_H
+#define OPE_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* kd-tree: exact k-NN / radius search.  Stands in for                 */
+/* pcl::search::KdTree -> pcl::KdTreeFLANN -> flann::KDTreeSingleIndex */
+/* (leaf_max_size 15, L2_Simple, eps 0), instantiated at               */
+/* registration_mod.h:104-105, correspondence_estimation_mod.h:97-98,  */
+/* poseestimator.cpp:151.  Distances returned are SQUARED L2, sorted   */
+/* ascending for k-NN (PCL convention).                                */
+/* ------------------------------------------------------------------ */
+typedef struct orc_kdtree orc_kdtree;
+
+orc_kdtree *orc_kdtree_build(const float *xyz, int n, int leaf_max);
+void orc_kdtree_free(orc_kdtree *t);
+/* For each of nq queries write k (idx,d2) pairs, ascending d2; slots past
+ * the number found (n<k or non-finite query) get idx=-1, d2=INFINITY.
+ * found[nq] (optional) receives the per-query count. */
+void orc_kdtree_knn(const orc_kdtree *t, const float *q, int nq, int k,
+                    int32_t *idx, float *d2, int32_t *found);
+/* Radius search (d2 <= r*r, PCL/FLANN convention).  offsets[nq+1] is always
+ * written.  If idx/d2 are non-NULL they receive up to cap entries in
+ * per-query blocks, each block sorted ascending by d2 when `sorted` != 0
+ * (FPFH uses an unsorted tree; order then follows tree traversal).
+ * Returns the total number of neighbours. */
+int64_t orc_kdtree_radius(const orc_kdtree *t, const float *q, int nq, float radius,
+                          int sorted, int64_t *offsets, int32_t *idx, float *d2, int64_t cap);
+
+/* Brute-force 1-NN, used to validate the tree in tests. */
+void orc_bruteforce_nn(const float *tgt, int nt, const float *q, int nq, int32_t *idx, float *d2);
+
+/* ------------------------------------------------------------------ */
+/* Rigid transform estimation                                          */
+/* pcl::registration::TransformationEstimationSVD (use_umeyama_=true)  */
+/* -> pcl::umeyama / Eigen::umeyama(src,dst,false)  [uPCL, restated]   */
+/* called at impl/icp_mod.hpp:243 and poseestimator.cpp:435.           */
+/* acc_mode 0: float accumulation (Scalar=float, as PCL);              */
+/* acc_mode 1: double accumulation, float result.                      */
+/* Returns 0, or -1 if n < 1.                                          */
+/* ------------------------------------------------------------------ */
+int orc_umeyama(const float *src, const float *tgt, int n, int acc_mode, float T[16]);
+/* Same from the 17 raw sums the GPU reduces:
+ * S = { n, sum s (3), sum t (3), sum t_i s_j (9, row-major i,j), sum d2 }.
+ * Sums are taken about `pivot` (subtracted from both s and t). */
+int orc_umeyama_from_sums(const double S[17], const double pivot[3], float T[16]);
+
+/* 3x3 SVD (two-sided Jacobi via A^T A eigen-decomposition refinement),
+ * A = U diag(s) V^T, s descending, row-major 3x3 arrays. */
+void orc_svd3(const double A[9], double U[9], double s[3], double V[9]);
+
+/* ------------------------------------------------------------------ */
+/* Convergence criteria: DefaultConvergenceCriteria                    */
+/* (default_convergence_criteria_mod.h:94-121,226-234 + uPCL           */
+/* impl/default_convergence_criteria.hpp::hasConverged, restated).     */
+/* ------------------------------------------------------------------ */
+enum {
+  ORC_CONV_NOT_CONVERGED = 0,
+  ORC_CONV_ITERATIONS = 1,
+  ORC_CONV_TRANSFORM = 2,
+  ORC_CONV_ABS_MSE = 3,
+  ORC_CONV_REL_MSE = 4,
+  ORC_CONV_NO_CORRESPONDENCES = 5
+};
+
+typedef struct {
+  int max_iterations;               /* 100  */
+  int failure_after_max_iter;       /* 0    */
+  double rotation_threshold;        /* 0.99999 */
+  double translation_threshold;     /* 9e-8 */
+  double mse_threshold_relative;    /* 1e-5 */
+  double mse_threshold_absolute;    /* 1e-12 */
+  int max_iterations_similar_transforms; /* 0 */
+  /* state */
+  int iterations_similar_transforms;
+  double prev_mse, cur_mse;
+  int state;
+} orc_convergence;
+
+void orc_convergence_init(orc_convergence *c);
+/* One hasConverged() evaluation.  T = last incremental transform (col-major
+ * float), mse = mean of correspondence distances of this iteration. */
+int orc_convergence_step(orc_convergence *c, int iterations, const float T[16], double mse);
+
+/* ------------------------------------------------------------------ */
+/* ICP: IterativeClosestPoint::computeTransformation                   */
+/* (impl/icp_mod.hpp:119-272), Registration::align                     */
+/* (impl/registration_mod.hpp:176-219), getFitnessScore (:131-165),    */
+/* getAlignStrength (icp_mod.h:249-260).                               */
+/* ------------------------------------------------------------------ */
+typedef struct {
+  int max_iterations;              /* Registration default 10 (registration_mod.h:106) */
+  double transformation_epsilon;   /* 0 */
+  double euclidean_fitness_epsilon;/* -DBL_MAX */
+  double max_corr_dist;            /* sqrt(DBL_MAX) */
+  int use_reciprocal;              /* 0 */
+  int min_correspondences;         /* 3 */
+  int corr_mode;                   /* 0: 1-NN (correspondence_estimation_mod.hpp:127-213)
+                                      1: normal shooting (…normal_shooting_weighted.hpp:107-145) */
+  int k_normal_shooting;           /* 20 (poseestimator.cpp:246) */
+  int use_surface_normal_rej;      /* CorrespondenceRejectorSurfaceNormal */
+  double surface_normal_thr;       /* 0.7 (poseestimator.cpp:272) */
+  int use_self_occluded_rej;       /* CorrespondenceRejectorSelfOccludedNormal */
+  double self_occluded_thr;        /* 0.6 (poseestimator.cpp:291) */
+  double mse_threshold_absolute;   /* 1e-12; <0 disables (throughput runs) */
+  int failure_after_max_iter;      /* 0 */
+  int acc_mode;                    /* umeyama accumulation, see orc_umeyama */
+  int transform_mode;              /* 0: incremental float transform of the working cloud
+                                         each iteration (reference, icp_mod.hpp:246);
+                                      1: final_T (composed in double) applied to the
+                                         original source each iteration (device design) */
+} orc_icp_params;
+
+typedef struct {
+  int iterations;
+  int converged;
+  int state;
+  double last_mse;
+  int n_corr;            /* post-rejection correspondences of the last iteration */
+  double fitness;        /* getFitnessScore(DBL_MAX) after align */
+  double align_strength; /* n_corr / (ns + nt) */
+} orc_icp_result;
+
+void orc_icp_default_params(orc_icp_params *p);
+
+/* Returns 0 on success (including "not converged"), <0 on bad input.
+ * T_hist (optional, max_iterations*16) receives final_T after each iteration.
+ * corr_* (optional, capacity ns) receive the last iteration's correspondences. */
+int orc_icp(const float *src_xyz, const float *src_nrm, int ns,
+            const float *tgt_xyz, const float *tgt_nrm, int nt,
+            const float guess[16], const orc_icp_params *p,
+            float out_T[16], orc_icp_result *res,
+            float *T_hist, int32_t *corr_q, int32_t *corr_m, float *corr_d2);
+
+/* Registration::getFitnessScore(max_range) for an arbitrary transform. */
+double orc_fitness(const float *src_xyz, int ns, const float *tgt_xyz, int nt,
+                   const float T[16], double max_range, int *n_used);
+
+/* One correspondence pass + the 17 sums (for the sharded / multi-rank tests):
+ * src is transformed by T (float math), 1-NN'd into tgt, thresholded by
+ * max_corr_dist, and S (see orc_umeyama_from_sums) accumulated about pivot. */
+void orc_icp_partial_sums(const float *src_xyz, int ns, const orc_kdtree *tgt_tree,
+                          const float *tgt_xyz, const float T[16], double max_corr_dist,
+                          const double pivot[3], double S[17]);
+
+/* pcl::transformPointCloud (float math): out = R*p + t; non-finite points
+ * are copied through unchanged (icp_mod.hpp:71-72,104-105). */
+void orc_transform_points(const float *in, int n, const float T[16], float *out);
+void orc_transform_normals(const float *in, int n, const float T[16], float *out);
+
+/* ------------------------------------------------------------------ */
+/* Features (uPCL, restated): NormalEstimation, FPFHEstimation,         */
+/* UniformSampling, SampleConsensusInitialAlignment.                    */
+/* ------------------------------------------------------------------ */
+/* NormalEstimation::compute with k-NN (poseestimator.cpp:151-156).
+ * out_nrm n*3, out_curv n.  Viewpoint vp (0,0,0 in the reference). */
+void orc_normals_knn(const float *xyz, int n, int k, const float vp[3], float *out_nrm, float *out_curv);
+
+/* pcl::computePairFeatures; returns 0 if rejected (f4==0 or |v|==0). */
+int orc_pair_features(const float p1[3], const float n1[3], const float p2[3], const float n2[3],
+                      float *f1, float *f2, float *f3, float *f4);
+
+/* FPFHEstimation::compute, radius search, 11+11+11 bins (poseestimator.cpp:121-125).
+ * out n*33.  Also optionally returns SPFH (n*33) and mean neighbour count. */
+void orc_fpfh(const float *xyz, const float *nrm, int n, float radius, float *out33,
+              float *spfh33_opt, double *mean_neighbours_opt);
+
+/* UniformSampling::compute (PCL 1.7 keypoints API, poseestimator.cpp:141-145)
+ * with DETERMINISTIC output order (ascending voxel key) instead of
+ * boost::unordered_map order.  Returns count; out_idx capacity n. */
+int orc_uniform_sampling(const float *xyz, int n, float leaf, int32_t *out_idx);
+
+/* SAC-IA error metric for one hypothesis: sum of TruncatedError(1-NN d2). */
+double orc_sacia_error(const float *src_xyz, int ns, const orc_kdtree *tgt_tree,
+                       const float T[16], double corr_dist_threshold);
+
+/* SampleConsensusInitialAlignment::computeTransformation (poseestimator.cpp:50-64).
+ * RNG is an injectable 64-bit LCG stream (PCL uses unseeded rand()).
+ * If forced_samples != NULL it holds n_iter*nr_samples source indices followed
+ * by n_iter*nr_samples target indices and no RNG is used. */
+int orc_sacia(const float *src_xyz, const float *src_feat33, int ns,
+              const float *tgt_xyz, const float *tgt_feat33, int nt,
+              int n_iter, int nr_samples, int k_corr, double max_corr_dist, float min_sample_dist,
+              uint64_t seed, const int32_t *forced_samples,
+              float out_T[16], double *best_err, int32_t *best_iter);
+
+/* 33-D feature k-NN (brute force), used by SAC-IA findSimilarFeatures. */
+void orc_feature_knn(const float *feat33, int n, const float *q33, int nq, int k, int32_t *idx, float *d2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPE_ORACLE_H */
