@@ -1,0 +1,223 @@
+/*
+ * ope.h — C ABI of libope_hip.so, the MI355X-native (gfx950) replacement for the
+ * registration hot path of gopi-erabati/Object-Pose-Estimation (DetectAndLocalize).
+ *
+ * The reference has no FFI of its own: its operator API is the PCL class-template
+ * protocol.  Each entry point below names the reference call it replaces
+ * (paths relative to the reference root; vPCL = the vendored include/pcl/registration/ headers).
+ * The C++ façade include/ope/pcl_compat.hpp re-creates those PCL call shapes on
+ * top of this ABI; INTEGRATION.md shows the re-pointing of poseestimator.cpp.
+ *
+ * Conventions
+ *  - every function returns OPE_OK (0) or a negative OPE_E* code; no exceptions
+ *    cross the ABI; ope_last_error(ctx) gives the message of the last failure.
+ *  - 4x4 transforms are COLUMN-MAJOR float[16] (Eigen::Matrix4f memory layout,
+ *    translation in [12..14]; reference: rosinterface.cpp:435-437).
+ *  - host buffers are only read/written during the call; device copies are owned
+ *    by the ope_cloud / ope_index handles.  Handles are not thread-safe; calls on
+ *    one ope_ctx must be externally serialised (reference: one PoseEstimator per
+ *    process, rosinterface.h:54).
+ *  - this library is GPU-only.  There is no CPU fallback: ope_ctx_create fails
+ *    with OPE_ENODEV when no HIP device is present.
+ */
+#ifndef OPE_H
+#define OPE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPE_ABI_VERSION 1
+
+enum {
+  OPE_OK = 0,
+  OPE_EINVAL = -1,  /* bad argument (NULL handle, n == 0 where forbidden, …) */
+  OPE_ENODEV = -2,  /* no HIP device / bad ordinal */
+  OPE_EHIP = -3,    /* a HIP runtime call failed */
+  OPE_ENOMEM = -4,
+  OPE_ESTATE = -5,  /* call out of sequence (e.g. ope_icp_step without begin) */
+  OPE_ECOMM = -6,   /* RCCL failure */
+  OPE_EEMPTY = -7   /* empty target cloud (registration_mod.hpp:60-64) */
+};
+
+typedef struct ope_ctx ope_ctx;
+typedef struct ope_cloud ope_cloud;
+typedef struct ope_index ope_index;
+
+/* ---------------- context ---------------- */
+int ope_abi_version(void);
+int ope_device_count(void);
+/* One context per GPU (one process per GPU in multi-GPU runs). */
+int ope_ctx_create(ope_ctx **out, int device_ordinal);
+void ope_ctx_destroy(ope_ctx *ctx);
+/* Run on an externally owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the context's own stream. */
+int ope_ctx_set_stream(ope_ctx *ctx, void *hip_stream);
+int ope_ctx_sync(ope_ctx *ctx);
+const char *ope_last_error(const ope_ctx *ctx);
+
+/* ---------------- clouds ---------------- */
+/* Upload n points from an array of structs: xyz floats at base + i*stride + xyz_off,
+ * optional normal floats at normal_off (pass -1 for none).  Works directly on
+ * pcl::PointXYZ (stride 16, xyz_off 0), pcl::PointXYZRGBNormal (stride 48,
+ * normal_off 16) or packed float[3] (stride 12).  Replaces setInputSource /
+ * setInputCloud (registration_mod.h:197-201; poseestimator.cpp:121,155,312).
+ * Points are re-ordered on the device along a Morton curve (the permutation is
+ * kept; all outputs are reported in ORIGINAL indices).  Non-finite points are
+ * kept in the index space but never produce correspondences (icp_mod.hpp:71-72). */
+int ope_cloud_upload(ope_ctx *ctx, const void *base, size_t n, size_t stride_bytes, size_t xyz_off,
+                     ptrdiff_t normal_off, ope_cloud **out);
+/* Attach / replace normals (n*3 packed floats, original order). */
+int ope_cloud_set_normals(ope_ctx *ctx, ope_cloud *cloud, const float *normals_xyz);
+size_t ope_cloud_size(const ope_cloud *cloud);
+void ope_cloud_free(ope_cloud *cloud);
+
+/* ---------------- search index over a target cloud ---------------- */
+typedef struct {
+  int leaf_size; /* max points per leaf bucket (default 16) */
+} ope_index_params;
+void ope_index_default_params(ope_index_params *p);
+/* Replaces the kd-tree build of Registration::initCompute (registration_mod.hpp:80-84)
+ * / pcl::search::KdTree::setInputCloud (poseestimator.cpp:151-152).
+ * Returns OPE_EEMPTY for an empty (or all-non-finite) target. */
+int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_params *params, ope_index **out);
+void ope_index_free(ope_index *index);
+
+/* Exact searches, results in ORIGINAL target indices, squared L2 distances
+ * (pcl::search::KdTree::nearestKSearch / radiusSearch semantics).  `T` (optional)
+ * is applied to the queries first (float math).  Host output buffers.
+ *   nn:     out_idx[nq], out_d2[nq]; idx = -1, d2 = +inf for non-finite queries.
+ *   knn:    out_idx[nq*k], out_d2[nq*k], ascending d2, -1/+inf padded.
+ *   radius: counts[nq] always; if out_idx/out_d2 non-NULL, up to max_nn per query
+ *           at stride max_nn (ascending d2). */
+int ope_nn_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *index, const float *T,
+                  int32_t *out_idx, float *out_d2);
+int ope_knn_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *index, const float *T, int k,
+                   int32_t *out_idx, float *out_d2);
+int ope_radius_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *index, float radius, int max_nn,
+                      int32_t *counts, int32_t *out_idx, float *out_d2);
+
+/* ---------------- ICP ---------------- */
+enum { /* DefaultConvergenceCriteria::ConvergenceState, default_convergence_criteria_mod.h:73-81 */
+  OPE_CONV_NOT_CONVERGED = 0,
+  OPE_CONV_ITERATIONS = 1,
+  OPE_CONV_TRANSFORM = 2,
+  OPE_CONV_ABS_MSE = 3,
+  OPE_CONV_REL_MSE = 4,
+  OPE_CONV_NO_CORRESPONDENCES = 5
+};
+
+enum { OPE_CORR_NEAREST = 0, OPE_CORR_NORMAL_SHOOTING = 1 };
+
+typedef struct {
+  /* Registration defaults, registration_mod.h:106-118 */
+  int max_iterations;               /* 10 */
+  double transformation_epsilon;    /* 0 */
+  double euclidean_fitness_epsilon; /* -DBL_MAX */
+  double max_corr_dist;             /* sqrt(DBL_MAX) */
+  int min_correspondences;          /* 3 */
+  int use_reciprocal;               /* 0 */
+  /* correspondence estimation: 1-NN (correspondence_estimation_mod.hpp:127-213) or
+   * normal shooting over the k nearest (…normal_shooting_weighted.hpp:107-145) */
+  int corr_mode;
+  int k_normal_shooting; /* 20 (poseestimator.cpp:246) */
+  /* rejectors, applied in this order (poseestimator.cpp:334-337) */
+  int use_surface_normal_rej;  /* CorrespondenceRejectorSurfaceNormal, score correspondence_rejection_mod.h:368-376 */
+  double surface_normal_thr;   /* 0.7 (poseestimator.cpp:272) */
+  int use_self_occluded_rej;   /* correspondence_rejection_mod.h:382-391; opt-in, see SURVEY Q3 */
+  double self_occluded_thr;    /* 0.6 (poseestimator.cpp:291) */
+  /* DefaultConvergenceCriteria knobs reachable through getConvergeCriteria() */
+  double mse_threshold_absolute; /* 1e-12; negative disables (fixed-length throughput runs) */
+  int failure_after_max_iter;    /* 0 */
+  /* host polling period for the on-device convergence flag (iterations); 0 = only at the end */
+  int check_every;
+} ope_icp_params;
+
+typedef struct {
+  int iterations;        /* nr_iterations_ */
+  int converged;         /* hasConverged() */
+  int state;             /* OPE_CONV_* */
+  double last_mse;       /* correspondences_cur_mse_ */
+  int64_t n_corr;        /* post-rejection correspondences of the last iteration */
+  double align_strength; /* getAlignStrength(): n_corr / (N_src + N_tgt), icp_mod.h:249-260
+                            (N_src = the full source size set with ope_icp_set_global_sizes in sharded runs) */
+} ope_icp_result;
+
+void ope_icp_default_params(ope_icp_params *p);
+
+/* Registration::align(output, guess) -> IterativeClosestPoint::computeTransformation
+ * (registration_mod.hpp:176-219, icp_mod.hpp:119-272).  guess may be NULL (identity).
+ * out_T receives getFinalTransformation(). */
+int ope_icp_run(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float *guess,
+                const ope_icp_params *params, float out_T[16], ope_icp_result *result);
+
+/* Step-wise form of the same loop, for one-process-per-GPU drivers that put a
+ * collective between the local reduction and the transform update:
+ *   begin -> { accumulate -> [all-reduce 17 doubles at ope_icp_sums_device()] -> update } * -> end
+ * All launches go to the context stream; nothing synchronises the host except
+ * ope_icp_poll / ope_icp_end. */
+int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float *guess,
+                  const ope_icp_params *params);
+int ope_icp_accumulate(ope_ctx *ctx);
+/* Device pointer to the 17 fp64 sums {n, Σs[3], Σt[3], Σ t sᵀ[9], Σd²} (about the index pivot). */
+void *ope_icp_sums_device(ope_ctx *ctx);
+int ope_icp_update(ope_ctx *ctx);
+int ope_icp_poll(ope_ctx *ctx, ope_icp_result *result); /* syncs the stream */
+int ope_icp_end(ope_ctx *ctx, float out_T[16], ope_icp_result *result);
+/* In sharded runs: the sizes getAlignStrength divides by (defaults: local sizes). */
+int ope_icp_set_global_sizes(ope_ctx *ctx, int64_t n_src_total, int64_t n_tgt_total);
+
+/* Last iteration's post-rejection correspondences, compacted in query order
+ * (pcl::Correspondences: index_query, index_match, distance = squared L2). */
+int ope_icp_correspondences(ope_ctx *ctx, int32_t *index_query, int32_t *index_match, float *distance, size_t cap,
+                            size_t *n);
+
+/* Registration::getFitnessScore(max_range), registration_mod.hpp:131-165.
+ * sum_out/n_out (optional) expose the partial sums for sharded runs. */
+int ope_fitness(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float T[16], double max_range,
+                double *score, double *sum_out, int64_t *n_out);
+
+/* pcl::transformPointCloud on the host copy of a result (float math): out = T * in. */
+int ope_transform_cloud(ope_ctx *ctx, const ope_cloud *cloud, const float T[16], float *out_xyz);
+
+/* ---------------- native RCCL path (optional; torch.distributed drivers use the step-wise API) ---------------- */
+#define OPE_COMM_ID_BYTES 128
+int ope_comm_get_unique_id(char id[OPE_COMM_ID_BYTES]);
+int ope_comm_init_rank(ope_ctx *ctx, const char id[OPE_COMM_ID_BYTES], int nranks, int rank);
+int ope_comm_destroy(ope_ctx *ctx);
+
+/* ---------------- features (coarse stage) ---------------- */
+/* pcl::NormalEstimation::compute with setKSearch(k) and viewpoint vp (poseestimator.cpp:151-156).
+ * out_normals n*3, out_curvature n (optional), ORIGINAL order; NaN where fewer than 3 neighbours.
+ * The normals are also attached to `cloud` on the device. */
+int ope_normals(ope_ctx *ctx, ope_cloud *cloud, int k, const float vp[3], float *out_normals, float *out_curvature);
+/* pcl::FPFHEstimation::compute with setRadiusSearch(radius) on a cloud that carries
+ * normals (poseestimator.cpp:121-125).  out33 n*33 floats. */
+int ope_fpfh(ope_ctx *ctx, const ope_cloud *cloud, float radius, float *out33);
+/* pcl::UniformSampling::compute(PointCloud<int>&) with setRadiusSearch(leaf)
+ * (poseestimator.cpp:141-145); survivors in ascending voxel-key order. */
+int ope_uniform_sampling(ope_ctx *ctx, const ope_cloud *cloud, float leaf, int32_t *out_idx, size_t *n_out);
+
+typedef struct {
+  int max_iterations;      /* 400  (poseestimator.cpp:55) */
+  int nr_samples;          /* 5    (:56) */
+  int k_correspondences;   /* 5    (:57) */
+  double max_corr_dist;    /* 0.05 (:58) */
+  float min_sample_dist;   /* 0.01 (:59) */
+  uint64_t seed;           /* PCL uses unseeded rand(); here an explicit LCG stream */
+} ope_sacia_params;
+void ope_sacia_default_params(ope_sacia_params *p);
+/* pcl::SampleConsensusInitialAlignment::align (poseestimator.cpp:50-64).
+ * src_feat/tgt_feat: n*33 floats in ORIGINAL order.  forced_samples (optional):
+ * max_iterations*nr_samples source indices then as many target indices. */
+int ope_sacia(ope_ctx *ctx, const ope_cloud *src, const float *src_feat33, const ope_cloud *tgt,
+              const ope_index *tgt_index, const float *tgt_feat33, const ope_sacia_params *params,
+              const int32_t *forced_samples, float out_T[16], double *best_error, int32_t *best_iteration);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPE_H */

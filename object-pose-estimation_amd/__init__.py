@@ -1,0 +1,438 @@
+"""object-pose-estimation_amd — MI355X-native registration hot path (ICP + FPFH/SAC-IA).
+
+Thin ctypes binding of the C ABI in include/ope.h (libope_hip.so, hand-written HIP for gfx950).
+This package is plumbing for tests, bench.py and the torch.distributed driver; the product is
+the shared library and the C++ façade in include/ope/.  There is NO CPU fallback: every entry
+point raises if the library or a GPU is missing.
+
+The directory name has a hyphen, so import it with
+    importlib.import_module("object-pose-estimation_amd")
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libope_hip.so")
+
+OPE_OK, OPE_EINVAL, OPE_ENODEV, OPE_EHIP, OPE_ENOMEM, OPE_ESTATE, OPE_ECOMM, OPE_EEMPTY = 0, -1, -2, -3, -4, -5, -6, -7
+CONV_NAMES = ["NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE", "NO_CORRESPONDENCES"]
+CORR_NEAREST, CORR_NORMAL_SHOOTING = 0, 1
+COMM_ID_BYTES = 128
+
+
+class OpeError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"ope error {code}: {msg}")
+        self.code = code
+
+
+def build_library(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of libope_hip.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs += [os.path.join(_HERE, "..", "include", "ope.h"), os.path.join(_HERE, "Makefile")]
+    stale = force or not os.path.exists(LIB_PATH)
+    if not stale:
+        t = os.path.getmtime(LIB_PATH)
+        stale = any(os.path.getmtime(s) > t for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-j8", "libope_hip.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+class IcpParams(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int),
+        ("transformation_epsilon", C.c_double),
+        ("euclidean_fitness_epsilon", C.c_double),
+        ("max_corr_dist", C.c_double),
+        ("min_correspondences", C.c_int),
+        ("use_reciprocal", C.c_int),
+        ("corr_mode", C.c_int),
+        ("k_normal_shooting", C.c_int),
+        ("use_surface_normal_rej", C.c_int),
+        ("surface_normal_thr", C.c_double),
+        ("use_self_occluded_rej", C.c_int),
+        ("self_occluded_thr", C.c_double),
+        ("mse_threshold_absolute", C.c_double),
+        ("failure_after_max_iter", C.c_int),
+        ("check_every", C.c_int),
+    ]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int),
+        ("converged", C.c_int),
+        ("state", C.c_int),
+        ("last_mse", C.c_double),
+        ("n_corr", C.c_int64),
+        ("align_strength", C.c_double),
+    ]
+
+
+class IndexParams(C.Structure):
+    _fields_ = [("leaf_size", C.c_int)]
+
+
+class SaciaParams(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int),
+        ("nr_samples", C.c_int),
+        ("k_correspondences", C.c_int),
+        ("max_corr_dist", C.c_double),
+        ("min_sample_dist", C.c_float),
+        ("seed", C.c_uint64),
+    ]
+
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# every symbol include/ope.h declares: (name, restype, argtypes)
+ABI = [
+    ("ope_abi_version", C.c_int, []),
+    ("ope_device_count", C.c_int, []),
+    ("ope_ctx_create", C.c_int, [C.POINTER(_vp), C.c_int]),
+    ("ope_ctx_destroy", None, [_vp]),
+    ("ope_ctx_set_stream", C.c_int, [_vp, _vp]),
+    ("ope_ctx_sync", C.c_int, [_vp]),
+    ("ope_last_error", C.c_char_p, [_vp]),
+    ("ope_cloud_upload", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_ssize_t, C.POINTER(_vp)]),
+    ("ope_cloud_set_normals", C.c_int, [_vp, _vp, _fp]),
+    ("ope_cloud_size", C.c_size_t, [_vp]),
+    ("ope_cloud_free", None, [_vp]),
+    ("ope_index_default_params", None, [C.POINTER(IndexParams)]),
+    ("ope_index_build", C.c_int, [_vp, _vp, C.POINTER(IndexParams), C.POINTER(_vp)]),
+    ("ope_index_free", None, [_vp]),
+    ("ope_nn_search", C.c_int, [_vp, _vp, _vp, _fp, _ip, _fp]),
+    ("ope_knn_search", C.c_int, [_vp, _vp, _vp, _fp, C.c_int, _ip, _fp]),
+    ("ope_radius_search", C.c_int, [_vp, _vp, _vp, C.c_float, C.c_int, _ip, _ip, _fp]),
+    ("ope_icp_default_params", None, [C.POINTER(IcpParams)]),
+    ("ope_icp_run", C.c_int, [_vp, _vp, _vp, _fp, C.POINTER(IcpParams), _fp, C.POINTER(IcpResult)]),
+    ("ope_icp_begin", C.c_int, [_vp, _vp, _vp, _fp, C.POINTER(IcpParams)]),
+    ("ope_icp_accumulate", C.c_int, [_vp]),
+    ("ope_icp_sums_device", _vp, [_vp]),
+    ("ope_icp_update", C.c_int, [_vp]),
+    ("ope_icp_poll", C.c_int, [_vp, C.POINTER(IcpResult)]),
+    ("ope_icp_end", C.c_int, [_vp, _fp, C.POINTER(IcpResult)]),
+    ("ope_icp_set_global_sizes", C.c_int, [_vp, C.c_int64, C.c_int64]),
+    ("ope_icp_correspondences", C.c_int, [_vp, _ip, _ip, _fp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("ope_fitness", C.c_int, [_vp, _vp, _vp, _fp, C.c_double, _dp, _dp, C.POINTER(C.c_int64)]),
+    ("ope_transform_cloud", C.c_int, [_vp, _vp, _fp, _fp]),
+    ("ope_comm_get_unique_id", C.c_int, [C.c_char_p]),
+    ("ope_comm_init_rank", C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
+    ("ope_comm_destroy", C.c_int, [_vp]),
+    ("ope_normals", C.c_int, [_vp, _vp, C.c_int, _fp, _fp, _fp]),
+    ("ope_fpfh", C.c_int, [_vp, _vp, C.c_float, _fp]),
+    ("ope_uniform_sampling", C.c_int, [_vp, _vp, C.c_float, _ip, C.POINTER(C.c_size_t)]),
+    ("ope_sacia_default_params", None, [C.POINTER(SaciaParams)]),
+    ("ope_sacia", C.c_int, [_vp, _vp, _fp, _vp, _vp, _fp, C.POINTER(SaciaParams), _ip, _fp, _dp, _ip]),
+]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libope_hip.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OpeError(OPE_ENODEV, f"{LIB_PATH} is missing: run __graft_entry__.build() / make -C {_HERE}")
+        # torch ships its own libamdhip64.so.7 / librccl.so.1; importing it first makes this library
+        # bind to the same HIP runtime (same SONAME), so streams and device pointers are shareable.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for pure C-ABI use
+            pass
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in ABI:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _f32(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if cols is not None and not (a.ndim == 2 and a.shape[1] == cols):
+        raise ValueError(f"expected (n,{cols}) float array, got {a.shape}")
+    return a
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def colmajor(T) -> np.ndarray:
+    """(4,4) math-layout matrix -> column-major float[16] (Eigen::Matrix4f memory order)."""
+    return np.ascontiguousarray(np.asarray(T, np.float32).T).reshape(16)
+
+
+def from_colmajor(t16) -> np.ndarray:
+    return np.asarray(t16, np.float32).reshape(4, 4).T.copy()
+
+
+def default_icp_params(**kw) -> IcpParams:
+    p = IcpParams()
+    lib().ope_icp_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+@dataclass
+class IcpOut:
+    T: np.ndarray          # (4,4) math layout, float32 — getFinalTransformation()
+    iterations: int
+    converged: bool
+    state: int
+    last_mse: float
+    n_corr: int
+    align_strength: float
+
+
+class Context:
+    """One ope_ctx (one GPU)."""
+
+    def __init__(self, device: int = 0):
+        h = _vp()
+        rc = lib().ope_ctx_create(C.byref(h), device)
+        if rc != OPE_OK:
+            raise OpeError(rc, (lib().ope_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ope_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int):
+        if rc != OPE_OK:
+            raise OpeError(rc, (lib().ope_last_error(self.h) or b"").decode())
+
+    def set_stream(self, stream_ptr: int | None):
+        self._chk(lib().ope_ctx_set_stream(self.h, _vp(stream_ptr) if stream_ptr else None))
+
+    def sync(self):
+        self._chk(lib().ope_ctx_sync(self.h))
+
+    # ---- clouds / index
+    def upload(self, xyz, normals=None) -> "Cloud":
+        xyz = _f32(xyz, 3)
+        h = _vp()
+        self._chk(lib().ope_cloud_upload(self.h, xyz.ctypes.data_as(_vp), len(xyz), 12, 0, -1, C.byref(h)))
+        c = Cloud(self, h, len(xyz))
+        if normals is not None:
+            c.set_normals(normals)
+        return c
+
+    def upload_struct(self, buf: np.ndarray, stride: int, xyz_off: int, normal_off: int = -1) -> "Cloud":
+        """Upload from an array-of-structs byte buffer (e.g. pcl::PointXYZRGBNormal, stride 48)."""
+        buf = np.ascontiguousarray(buf)
+        n = buf.nbytes // stride
+        h = _vp()
+        self._chk(lib().ope_cloud_upload(self.h, buf.ctypes.data_as(_vp), n, stride, xyz_off, normal_off, C.byref(h)))
+        return Cloud(self, h, n)
+
+    def build_index(self, cloud: "Cloud", leaf_size: int | None = None) -> "Index":
+        p = IndexParams()
+        lib().ope_index_default_params(C.byref(p))
+        if leaf_size:
+            p.leaf_size = leaf_size
+        h = _vp()
+        self._chk(lib().ope_index_build(self.h, cloud.h, C.byref(p), C.byref(h)))
+        return Index(self, h, cloud)
+
+    # ---- searches
+    def nn(self, queries: "Cloud", index: "Index", T=None):
+        n = queries.n
+        idx = np.empty(n, np.int32)
+        d2 = np.empty(n, np.float32)
+        t = colmajor(T) if T is not None else None
+        self._chk(lib().ope_nn_search(self.h, queries.h, index.h, _p(t, _fp), _p(idx, _ip), _p(d2, _fp)))
+        return idx, d2
+
+    def knn(self, queries: "Cloud", index: "Index", k: int, T=None):
+        n = queries.n
+        idx = np.empty((n, k), np.int32)
+        d2 = np.empty((n, k), np.float32)
+        t = colmajor(T) if T is not None else None
+        self._chk(lib().ope_knn_search(self.h, queries.h, index.h, _p(t, _fp), k, _p(idx, _ip), _p(d2, _fp)))
+        return idx, d2
+
+    def radius(self, queries: "Cloud", index: "Index", radius: float, max_nn: int = 0):
+        n = queries.n
+        counts = np.empty(n, np.int32)
+        idx = np.empty((n, max_nn), np.int32) if max_nn else None
+        d2 = np.empty((n, max_nn), np.float32) if max_nn else None
+        self._chk(lib().ope_radius_search(self.h, queries.h, index.h, radius, max_nn, _p(counts, _ip), _p(idx, _ip),
+                                          _p(d2, _fp)))
+        return counts, idx, d2
+
+    # ---- ICP
+    def icp(self, src: "Cloud", tgt: "Index", params: IcpParams | None = None, guess=None) -> IcpOut:
+        p = params or default_icp_params()
+        g = colmajor(guess) if guess is not None else None
+        T = np.empty(16, np.float32)
+        r = IcpResult()
+        self._chk(lib().ope_icp_run(self.h, src.h, tgt.h if tgt is not None else None, _p(g, _fp), C.byref(p),
+                                    _p(T, _fp), C.byref(r)))
+        return IcpOut(from_colmajor(T), r.iterations, bool(r.converged), r.state, r.last_mse, r.n_corr, r.align_strength)
+
+    def icp_begin(self, src: "Cloud", tgt: "Index", params: IcpParams | None = None, guess=None):
+        p = params or default_icp_params()
+        g = colmajor(guess) if guess is not None else None
+        self._chk(lib().ope_icp_begin(self.h, src.h, tgt.h, _p(g, _fp), C.byref(p)))
+
+    def icp_accumulate(self):
+        self._chk(lib().ope_icp_accumulate(self.h))
+
+    def icp_sums_ptr(self) -> int:
+        return int(lib().ope_icp_sums_device(self.h) or 0)
+
+    def icp_update(self):
+        self._chk(lib().ope_icp_update(self.h))
+
+    def icp_poll(self) -> IcpResult:
+        r = IcpResult()
+        self._chk(lib().ope_icp_poll(self.h, C.byref(r)))
+        return r
+
+    def icp_end(self) -> IcpOut:
+        T = np.empty(16, np.float32)
+        r = IcpResult()
+        self._chk(lib().ope_icp_end(self.h, _p(T, _fp), C.byref(r)))
+        return IcpOut(from_colmajor(T), r.iterations, bool(r.converged), r.state, r.last_mse, r.n_corr, r.align_strength)
+
+    def icp_set_global_sizes(self, n_src_total: int, n_tgt_total: int):
+        self._chk(lib().ope_icp_set_global_sizes(self.h, n_src_total, n_tgt_total))
+
+    def icp_correspondences(self, cap: int):
+        q = np.empty(cap, np.int32); m = np.empty(cap, np.int32); d = np.empty(cap, np.float32)
+        n = C.c_size_t(0)
+        self._chk(lib().ope_icp_correspondences(self.h, _p(q, _ip), _p(m, _ip), _p(d, _fp), cap, C.byref(n)))
+        k = min(n.value, cap)
+        return q[:k], m[:k], d[:k]
+
+    def fitness(self, src: "Cloud", tgt: "Index", T, max_range: float = float(np.finfo(np.float64).max)):
+        t = colmajor(T)
+        score = C.c_double(0); s = C.c_double(0); n = C.c_int64(0)
+        self._chk(lib().ope_fitness(self.h, src.h, tgt.h, _p(t, _fp), max_range, C.byref(score), C.byref(s), C.byref(n)))
+        return score.value, s.value, n.value
+
+    def transform_cloud(self, cloud: "Cloud", T) -> np.ndarray:
+        out = np.empty((cloud.n, 3), np.float32)
+        t = colmajor(T)
+        self._chk(lib().ope_transform_cloud(self.h, cloud.h, _p(t, _fp), _p(out, _fp)))
+        return out
+
+    # ---- RCCL
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int):
+        self._chk(lib().ope_comm_init_rank(self.h, unique_id, nranks, rank))
+
+    def comm_destroy(self):
+        self._chk(lib().ope_comm_destroy(self.h))
+
+    # ---- features
+    def normals(self, cloud: "Cloud", k: int = 30, vp=(0.0, 0.0, 0.0)):
+        v = np.asarray(vp, np.float32)
+        nrm = np.empty((cloud.n, 3), np.float32)
+        curv = np.empty(cloud.n, np.float32)
+        self._chk(lib().ope_normals(self.h, cloud.h, k, _p(v, _fp), _p(nrm, _fp), _p(curv, _fp)))
+        return nrm, curv
+
+    def fpfh(self, cloud: "Cloud", radius: float) -> np.ndarray:
+        out = np.empty((cloud.n, 33), np.float32)
+        self._chk(lib().ope_fpfh(self.h, cloud.h, radius, _p(out, _fp)))
+        return out
+
+    def uniform_sampling(self, cloud: "Cloud", leaf: float) -> np.ndarray:
+        out = np.empty(cloud.n, np.int32)
+        n = C.c_size_t(0)
+        self._chk(lib().ope_uniform_sampling(self.h, cloud.h, leaf, _p(out, _ip), C.byref(n)))
+        return out[: n.value].copy()
+
+    def sacia(self, src: "Cloud", src_feat, tgt: "Cloud", tgt_index: "Index", tgt_feat, params: SaciaParams | None = None,
+              forced_samples=None):
+        p = params or default_sacia_params()
+        sf, tf = _f32(src_feat, 33), _f32(tgt_feat, 33)
+        fs = np.ascontiguousarray(forced_samples, np.int32) if forced_samples is not None else None
+        T = np.empty(16, np.float32)
+        err = C.c_double(0); bi = C.c_int32(-1)
+        self._chk(lib().ope_sacia(self.h, src.h, _p(sf, _fp), tgt.h, tgt_index.h, _p(tf, _fp), C.byref(p), _p(fs, _ip),
+                                  _p(T, _fp), C.byref(err), C.byref(bi)))
+        return from_colmajor(T), err.value, bi.value
+
+
+def default_sacia_params(**kw) -> SaciaParams:
+    p = SaciaParams()
+    lib().ope_sacia_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().ope_comm_get_unique_id(buf)
+    if rc != OPE_OK:
+        raise OpeError(rc, (lib().ope_last_error(None) or b"").decode())
+    return buf.raw
+
+
+class Cloud:
+    def __init__(self, ctx: Context, h, n: int):
+        self.ctx, self.h, self.n = ctx, h, n
+
+    def set_normals(self, normals):
+        nrm = _f32(normals, 3)
+        if len(nrm) != self.n:
+            raise ValueError("normals length mismatch")
+        self.ctx._chk(lib().ope_cloud_set_normals(self.ctx.h, self.h, _p(nrm, _fp)))
+
+    def free(self):
+        if self.h:
+            lib().ope_cloud_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.free()
+        except Exception:
+            pass
+
+
+class Index:
+    def __init__(self, ctx: Context, h, cloud: Cloud):
+        self.ctx, self.h, self.cloud = ctx, h, cloud
+
+    def free(self):
+        if self.h:
+            lib().ope_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.free()
+        except Exception:
+            pass

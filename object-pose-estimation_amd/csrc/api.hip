@@ -1,0 +1,617 @@
+// api.hip — the C ABI of libope_hip.so (see include/ope.h for what each entry point replaces).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+#include "ope_internal.hpp"
+
+namespace ope {
+
+// launchers defined in icp_kernels.hip
+void launch_icp_accumulate(hipStream_t, int, int, bool, const CloudView &, const BvhView &, const IcpState *, double *,
+                           int32_t *, float *);
+void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, int, bool);
+void launch_icp_update(hipStream_t, IcpState *);
+void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
+void launch_knn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int, int32_t *, float *);
+void launch_fitness(hipStream_t, int, const CloudView &, const BvhView &, const float *, double, double *);
+// comm.cpp
+int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count);
+
+static thread_local std::string g_global_err;
+
+int set_err(ope_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  else g_global_err = msg;
+  return code;
+}
+
+static inline bool finite3(const float *p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
+
+static inline uint32_t expand_bits10(uint32_t v) {
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+// column-major 4x4 -> 12 floats, rows of [R|t]
+static void colmajor_to_rows(const float *T, float rows[12]) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) rows[4 * r + c] = T[4 * c + r];
+}
+
+static int ensure_scratch(ope_ctx *ctx, size_t bytes) {
+  if (ctx->scratch_bytes >= bytes) return OPE_OK;
+  if (ctx->d_scratch) OPE_HIP(ctx, hipFree(ctx->d_scratch));
+  ctx->d_scratch = nullptr;
+  ctx->scratch_bytes = 0;
+  OPE_HIP(ctx, hipMalloc(&ctx->d_scratch, bytes));
+  ctx->scratch_bytes = bytes;
+  return OPE_OK;
+}
+
+}  // namespace ope
+
+using namespace ope;
+
+extern "C" {
+
+int ope_abi_version(void) { return OPE_ABI_VERSION; }
+
+int ope_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ope_ctx_create(ope_ctx **out, int device_ordinal) {
+  if (!out) return OPE_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return set_err(nullptr, OPE_ENODEV, "no HIP device: libope_hip.so is GPU-only and has no CPU fallback");
+  if (device_ordinal < 0 || device_ordinal >= n) return set_err(nullptr, OPE_ENODEV, "bad device ordinal");
+  ope_ctx *ctx = new ope_ctx();
+  ctx->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
+    delete ctx;
+    return set_err(nullptr, OPE_EHIP, "hipSetDevice/hipStreamCreate failed");
+  }
+  ctx->stream = ctx->own_stream;
+  if (hipMalloc(&ctx->d_state, sizeof(IcpState)) != hipSuccess ||
+      hipMalloc(&ctx->d_partials, sizeof(double) * kNumSums * kAccMaxBlocks) != hipSuccess ||
+      hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState)) != hipSuccess) {
+    ope_ctx_destroy(ctx);
+    return set_err(nullptr, OPE_ENOMEM, "context allocation failed");
+  }
+  *out = ctx;
+  return OPE_OK;
+}
+
+void ope_ctx_destroy(ope_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  ope_comm_destroy(ctx);
+  if (ctx->d_state) (void)hipFree(ctx->d_state);
+  if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+  if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
+  if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
+  if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int ope_ctx_set_stream(ope_ctx *ctx, void *hip_stream) {
+  if (!ctx) return OPE_EINVAL;
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return OPE_OK;
+}
+
+int ope_ctx_sync(ope_ctx *ctx) {
+  if (!ctx) return OPE_EINVAL;
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return OPE_OK;
+}
+
+const char *ope_last_error(const ope_ctx *ctx) { return ctx ? ctx->err.c_str() : g_global_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------ clouds
+int ope_cloud_upload(ope_ctx *ctx, const void *base, size_t n, size_t stride_bytes, size_t xyz_off,
+                     ptrdiff_t normal_off, ope_cloud **out) {
+  if (!ctx || !out || (n && !base) || stride_bytes < 12) return set_err(ctx, OPE_EINVAL, "ope_cloud_upload: bad argument");
+  if (n > (size_t)0x7fffffff) return set_err(ctx, OPE_EINVAL, "ope_cloud_upload: more than 2^31-1 points");
+  *out = nullptr;
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  ope_cloud *c = new ope_cloud();
+  c->ctx = ctx;
+  c->n = n;
+  c->h_xyz.resize(n * 3);
+  const unsigned char *b = static_cast<const unsigned char *>(base);
+  for (size_t i = 0; i < n; ++i) std::memcpy(&c->h_xyz[3 * i], b + i * stride_bytes + xyz_off, 12);
+  // bounding box of the finite points
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  size_t nv = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float *p = &c->h_xyz[3 * i];
+    if (!finite3(p)) continue;
+    ++nv;
+    for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], p[d]); hi[d] = std::max(hi[d], p[d]); }
+  }
+  c->n_valid = nv;
+  if (nv == 0) { for (int d = 0; d < 3; ++d) lo[d] = hi[d] = 0.f; }
+  std::memcpy(c->bb_lo, lo, sizeof lo);
+  std::memcpy(c->bb_hi, hi, sizeof hi);
+  // Morton order (10 bits per axis over the cloud's own bbox); non-finite points go last
+  std::vector<uint64_t> keys(n);
+  float inv[3];
+  for (int d = 0; d < 3; ++d) inv[d] = (hi[d] > lo[d]) ? 1023.999f / (hi[d] - lo[d]) : 0.f;
+  for (size_t i = 0; i < n; ++i) {
+    const float *p = &c->h_xyz[3 * i];
+    uint64_t code;
+    if (!finite3(p)) code = (uint64_t)1 << 30;  // above every 30-bit Morton code
+    else {
+      uint32_t q[3];
+      for (int d = 0; d < 3; ++d) q[d] = std::min<uint32_t>(1023u, (uint32_t)std::max(0.f, (p[d] - lo[d]) * inv[d]));
+      code = expand_bits10(q[0]) | (expand_bits10(q[1]) << 1) | (expand_bits10(q[2]) << 2);
+    }
+    keys[i] = (code << 32) | (uint64_t)i;  // index in the low bits keeps the sort stable and unique
+  }
+  std::sort(keys.begin(), keys.end());
+  c->perm.resize(n);
+  std::vector<float> packed(n * 4);
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t o = (int32_t)(keys[i] & 0xffffffffu);
+    c->perm[i] = o;
+    packed[4 * i + 0] = c->h_xyz[3 * (size_t)o + 0];
+    packed[4 * i + 1] = c->h_xyz[3 * (size_t)o + 1];
+    packed[4 * i + 2] = c->h_xyz[3 * (size_t)o + 2];
+    std::memcpy(&packed[4 * i + 3], &o, 4);
+  }
+  hipError_t e = hipMalloc((void **)&c->d_xyzw, sizeof(float4) * std::max<size_t>(n, 1));
+  if (e == hipSuccess && n) e = hipMemcpy(c->d_xyzw, packed.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    ope_cloud_free(c);
+    return set_err(ctx, OPE_EHIP, std::string("ope_cloud_upload: ") + hipGetErrorString(e));
+  }
+  *out = c;
+  if (normal_off >= 0) {
+    std::vector<float> nrm(n * 3);
+    for (size_t i = 0; i < n; ++i) std::memcpy(&nrm[3 * i], b + i * stride_bytes + (size_t)normal_off, 12);
+    int rc = ope_cloud_set_normals(ctx, c, nrm.data());
+    if (rc != OPE_OK) { ope_cloud_free(c); *out = nullptr; return rc; }
+  }
+  return OPE_OK;
+}
+
+int ope_cloud_set_normals(ope_ctx *ctx, ope_cloud *cloud, const float *normals_xyz) {
+  if (!ctx || !cloud || !normals_xyz) return set_err(ctx, OPE_EINVAL, "ope_cloud_set_normals: bad argument");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = cloud->n;
+  std::vector<float> packed(n * 4);
+  for (size_t i = 0; i < n; ++i) {
+    const size_t o = (size_t)cloud->perm[i];
+    packed[4 * i + 0] = normals_xyz[3 * o + 0];
+    packed[4 * i + 1] = normals_xyz[3 * o + 1];
+    packed[4 * i + 2] = normals_xyz[3 * o + 2];
+    packed[4 * i + 3] = 0.f;
+  }
+  if (!cloud->d_nrm) OPE_HIP(ctx, hipMalloc((void **)&cloud->d_nrm, sizeof(float4) * std::max<size_t>(n, 1)));
+  if (n) OPE_HIP(ctx, hipMemcpy(cloud->d_nrm, packed.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+  return OPE_OK;
+}
+
+size_t ope_cloud_size(const ope_cloud *cloud) { return cloud ? cloud->n : 0; }
+
+void ope_cloud_free(ope_cloud *cloud) {
+  if (!cloud) return;
+  if (cloud->ctx) (void)hipSetDevice(cloud->ctx->device);
+  if (cloud->d_xyzw) (void)hipFree(cloud->d_xyzw);
+  if (cloud->d_nrm) (void)hipFree(cloud->d_nrm);
+  delete cloud;
+}
+
+// ------------------------------------------------------------------------------------------ index
+void ope_index_default_params(ope_index_params *p) {
+  if (p) p->leaf_size = 16;
+}
+
+int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_params *params, ope_index **out) {
+  if (!ctx || !target || !out) return set_err(ctx, OPE_EINVAL, "ope_index_build: bad argument");
+  *out = nullptr;
+  // Registration::setInputTarget: "Invalid or empty point cloud dataset given!" (registration_mod.hpp:60-64)
+  if (target->n_valid == 0) return set_err(ctx, OPE_EEMPTY, "ope_index_build: invalid or empty target cloud");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  ope_index_params dp;
+  ope_index_default_params(&dp);
+  if (params) dp = *params;
+  const size_t n = target->n_valid;
+  std::vector<float> xyz(n * 3), nrm;
+  std::vector<int32_t> ids(n);
+  size_t m = 0;
+  for (size_t i = 0; i < target->n; ++i) {
+    const float *p = &target->h_xyz[3 * i];
+    if (!finite3(p)) continue;
+    xyz[3 * m] = p[0]; xyz[3 * m + 1] = p[1]; xyz[3 * m + 2] = p[2];
+    ids[m++] = (int32_t)i;
+  }
+  if (target->d_nrm) {
+    // fetch normals back in original order
+    std::vector<float> packed(target->n * 4);
+    OPE_HIP(ctx, hipMemcpy(packed.data(), target->d_nrm, sizeof(float4) * target->n, hipMemcpyDeviceToHost));
+    std::vector<float> orig(target->n * 3);
+    for (size_t i = 0; i < target->n; ++i)
+      for (int d = 0; d < 3; ++d) orig[3 * (size_t)target->perm[i] + d] = packed[4 * i + d];
+    nrm.resize(n * 3);
+    for (size_t k = 0; k < n; ++k)
+      for (int d = 0; d < 3; ++d) nrm[3 * k + d] = orig[3 * (size_t)ids[k] + d];
+  }
+  HostBvh hb;
+  build_bvh_host(xyz.data(), ids.data(), nrm.empty() ? nullptr : nrm.data(), n, dp.leaf_size, hb);
+  ope_index *ix = new ope_index();
+  ix->ctx = ctx;
+  ix->n = n;
+  ix->n_total = target->n;
+  ix->depth = hb.depth;
+  std::memcpy(ix->bb_lo, target->bb_lo, sizeof ix->bb_lo);
+  std::memcpy(ix->bb_hi, target->bb_hi, sizeof ix->bb_hi);
+  for (int d = 0; d < 3; ++d) ix->pivot[d] = 0.5 * ((double)target->bb_lo[d] + (double)target->bb_hi[d]);
+  hipError_t e = hipMalloc((void **)&ix->d_boxes, sizeof(float) * hb.boxes.size());
+  if (e == hipSuccess) e = hipMemcpy(ix->d_boxes, hb.boxes.data(), sizeof(float) * hb.boxes.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void **)&ix->d_pts, sizeof(float4) * n);
+  if (e == hipSuccess) e = hipMemcpy(ix->d_pts, hb.pts4.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess && !hb.nrm4.empty()) {
+    e = hipMalloc((void **)&ix->d_nrm, sizeof(float4) * n);
+    if (e == hipSuccess) e = hipMemcpy(ix->d_nrm, hb.nrm4.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    ope_index_free(ix);
+    return set_err(ctx, OPE_EHIP, std::string("ope_index_build: ") + hipGetErrorString(e));
+  }
+  *out = ix;
+  return OPE_OK;
+}
+
+void ope_index_free(ope_index *index) {
+  if (!index) return;
+  if (index->ctx) (void)hipSetDevice(index->ctx->device);
+  if (index->d_boxes) (void)hipFree(index->d_boxes);
+  if (index->d_pts) (void)hipFree(index->d_pts);
+  if (index->d_nrm) (void)hipFree(index->d_nrm);
+  delete index;
+}
+
+// ------------------------------------------------------------------------------------------ searches
+static int upload_T(ope_ctx *ctx, const float *T, float **d_T) {
+  *d_T = nullptr;
+  if (!T) return OPE_OK;
+  float rows[12];
+  colmajor_to_rows(T, rows);
+  int rc = ensure_scratch(ctx, 1 << 16);
+  if (rc != OPE_OK) return rc;
+  OPE_HIP(ctx, hipMemcpyAsync(ctx->d_scratch, rows, sizeof rows, hipMemcpyHostToDevice, ctx->stream));
+  *d_T = static_cast<float *>(ctx->d_scratch);
+  return OPE_OK;
+}
+
+int ope_nn_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *index, const float *T, int32_t *out_idx,
+                  float *out_d2) {
+  if (!ctx || !queries || !index || !out_idx || !out_d2) return set_err(ctx, OPE_EINVAL, "ope_nn_search: bad argument");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = queries->n;
+  if (n == 0) return OPE_OK;
+  float *d_T;
+  int rc = upload_T(ctx, T, &d_T);
+  if (rc != OPE_OK) return rc;
+  int32_t *d_idx;
+  float *d_d2;
+  OPE_HIP(ctx, hipMalloc((void **)&d_idx, sizeof(int32_t) * n));
+  OPE_HIP(ctx, hipMalloc((void **)&d_d2, sizeof(float) * n));
+  launch_nn_search(ctx->stream, queries->view(), index->view(), d_T, d_idx, d_d2);
+  std::vector<int32_t> hi(n);
+  std::vector<float> hd(n);
+  hipError_t e = hipMemcpyAsync(hi.data(), d_idx, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(hd.data(), d_d2, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_idx);
+  (void)hipFree(d_d2);
+  if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_nn_search: ") + hipGetErrorString(e));
+  for (size_t i = 0; i < n; ++i) {
+    out_idx[queries->perm[i]] = hi[i];
+    out_d2[queries->perm[i]] = hd[i];
+  }
+  return OPE_OK;
+}
+
+int ope_knn_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *index, const float *T, int k,
+                   int32_t *out_idx, float *out_d2) {
+  if (!ctx || !queries || !index || !out_idx || !out_d2 || k < 1 || k > 32)
+    return set_err(ctx, OPE_EINVAL, "ope_knn_search: bad argument (1 <= k <= 32)");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = queries->n;
+  if (n == 0) return OPE_OK;
+  float *d_T;
+  int rc = upload_T(ctx, T, &d_T);
+  if (rc != OPE_OK) return rc;
+  int32_t *d_idx;
+  float *d_d2;
+  OPE_HIP(ctx, hipMalloc((void **)&d_idx, sizeof(int32_t) * n * k));
+  OPE_HIP(ctx, hipMalloc((void **)&d_d2, sizeof(float) * n * k));
+  launch_knn_search(ctx->stream, queries->view(), index->view(), d_T, k, d_idx, d_d2);
+  std::vector<int32_t> hi(n * k);
+  std::vector<float> hd(n * k);
+  hipError_t e = hipMemcpyAsync(hi.data(), d_idx, sizeof(int32_t) * n * k, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(hd.data(), d_d2, sizeof(float) * n * k, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_idx);
+  (void)hipFree(d_d2);
+  if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_knn_search: ") + hipGetErrorString(e));
+  for (size_t i = 0; i < n; ++i) {
+    std::memcpy(out_idx + (size_t)queries->perm[i] * k, hi.data() + i * k, sizeof(int32_t) * k);
+    std::memcpy(out_d2 + (size_t)queries->perm[i] * k, hd.data() + i * k, sizeof(float) * k);
+  }
+  return OPE_OK;
+}
+
+// ------------------------------------------------------------------------------------------ ICP
+void ope_icp_default_params(ope_icp_params *p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof *p);
+  p->max_iterations = 10;
+  p->transformation_epsilon = 0.0;
+  p->euclidean_fitness_epsilon = -std::numeric_limits<double>::max();
+  p->max_corr_dist = std::sqrt(std::numeric_limits<double>::max());
+  p->min_correspondences = 3;
+  p->use_reciprocal = 0;
+  p->corr_mode = OPE_CORR_NEAREST;
+  p->k_normal_shooting = 20;
+  p->use_surface_normal_rej = 0;
+  p->surface_normal_thr = 0.7;
+  p->use_self_occluded_rej = 0;
+  p->self_occluded_thr = 0.6;
+  p->mse_threshold_absolute = 1e-12;
+  p->failure_after_max_iter = 0;
+  p->check_every = 10;
+}
+
+int ope_icp_set_global_sizes(ope_ctx *ctx, int64_t n_src_total, int64_t n_tgt_total) {
+  if (!ctx) return OPE_EINVAL;
+  ctx->n_src_total = n_src_total;
+  ctx->n_tgt_total = n_tgt_total;
+  return OPE_OK;
+}
+
+int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float *guess,
+                  const ope_icp_params *params) {
+  if (!ctx || !src) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: bad argument");
+  // Registration::initCompute: "No input target dataset was given!" (registration_mod.hpp:73-77)
+  if (!tgt) return set_err(ctx, OPE_EEMPTY, "ope_icp_begin: no input target dataset was given");
+  ope_icp_params p;
+  ope_icp_default_params(&p);
+  if (params) p = *params;
+  if (p.use_reciprocal) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: reciprocal correspondences not implemented yet");
+  const bool need_src_nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
+  if (need_src_nrm && !src->d_nrm) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: source normals required but absent");
+  if (p.use_surface_normal_rej && !tgt->d_nrm)
+    return set_err(ctx, OPE_EINVAL, "ope_icp_begin: target normals required (build the index from a cloud with normals)");
+  if (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && (p.k_normal_shooting < 1 || p.k_normal_shooting > 32))
+    return set_err(ctx, OPE_EINVAL, "ope_icp_begin: 1 <= k_normal_shooting <= 32");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->corr_cap < src->n) {
+    if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
+    if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
+    ctx->d_corr_match = nullptr; ctx->d_corr_d2 = nullptr; ctx->corr_cap = 0;
+    OPE_HIP(ctx, hipMalloc((void **)&ctx->d_corr_match, sizeof(int32_t) * std::max<size_t>(src->n, 1)));
+    OPE_HIP(ctx, hipMalloc((void **)&ctx->d_corr_d2, sizeof(float) * std::max<size_t>(src->n, 1)));
+    ctx->corr_cap = std::max<size_t>(src->n, 1);
+  }
+  // every slot starts as "no correspondence" (non-finite points never get written)
+  OPE_HIP(ctx, hipMemsetAsync(ctx->d_corr_match, 0xff, sizeof(int32_t) * std::max<size_t>(src->n, 1), ctx->stream));
+
+  IcpState *h = ctx->h_state;
+  std::memset(h, 0, sizeof *h);
+  static const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const float *g = guess ? guess : I4;
+  for (int i = 0; i < 16; ++i) { h->F[i] = g[i]; h->Tk[i] = I4[i]; }
+  colmajor_to_rows(g, h->Ff);
+  for (int d = 0; d < 3; ++d) h->pivot[d] = tgt->pivot[d];
+  h->prev_mse = h->cur_mse = std::numeric_limits<double>::max();
+  // thresholds wired as at icp_mod.hpp:164-168 (quirk Q1: rotation threshold = 1 - transformation_epsilon)
+  h->rotation_threshold = 1.0 - p.transformation_epsilon;
+  h->translation_threshold = p.transformation_epsilon;
+  h->mse_threshold_relative = p.euclidean_fitness_epsilon;
+  h->mse_threshold_absolute = p.mse_threshold_absolute;
+  h->max_corr_dist = p.max_corr_dist;
+  h->max_d2 = p.max_corr_dist * p.max_corr_dist;
+  h->surface_normal_thr = p.surface_normal_thr;
+  h->self_occluded_thr = p.self_occluded_thr;
+  h->max_iterations = p.max_iterations;
+  h->failure_after_max_iter = p.failure_after_max_iter;
+  h->min_correspondences = p.min_correspondences;
+  h->corr_mode = p.corr_mode;
+  h->k_normal_shooting = p.k_normal_shooting;
+  h->use_surface_normal_rej = p.use_surface_normal_rej;
+  h->use_self_occluded_rej = p.use_self_occluded_rej;
+  OPE_HIP(ctx, hipMemcpyAsync(ctx->d_state, h, sizeof *h, hipMemcpyHostToDevice, ctx->stream));
+  // the pinned block is reused for read-back: make sure the upload is finished with it first
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+  ctx->run_src = src;
+  ctx->run_tgt = tgt;
+  ctx->run_params = p;
+  ctx->run_active = true;
+  ctx->iters_enqueued = 0;
+  const int block = (p.corr_mode == OPE_CORR_NEAREST) ? kAccBlock : 256;
+  ctx->acc_blocks = (int)std::min<size_t>(std::max<size_t>((src->n_valid + block - 1) / block, 1), kAccMaxBlocks);
+  if (ctx->n_src_total <= 0) ctx->n_src_total = (int64_t)src->n;
+  if (ctx->n_tgt_total <= 0) ctx->n_tgt_total = (int64_t)tgt->n_total;
+  return OPE_OK;
+}
+
+int ope_icp_accumulate(ope_ctx *ctx) {
+  if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_accumulate: no run in progress");
+  const ope_icp_params &p = ctx->run_params;
+  const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
+  launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, ctx->run_src->view(), ctx->run_tgt->view(),
+                        ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2);
+  launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, ctx->acc_blocks, /*do_update=*/false);
+  OPE_HIP(ctx, hipGetLastError());
+  return OPE_OK;
+}
+
+void *ope_icp_sums_device(ope_ctx *ctx) {
+  if (!ctx || !ctx->d_state) return nullptr;
+  return reinterpret_cast<unsigned char *>(ctx->d_state) + offsetof(IcpState, S);
+}
+
+int ope_icp_update(ope_ctx *ctx) {
+  if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_update: no run in progress");
+  launch_icp_update(ctx->stream, ctx->d_state);
+  OPE_HIP(ctx, hipGetLastError());
+  ++ctx->iters_enqueued;
+  return OPE_OK;
+}
+
+static void fill_result(const ope_ctx *ctx, ope_icp_result *r) {
+  const IcpState *h = ctx->h_state;
+  r->iterations = h->iterations;
+  r->converged = h->converged;
+  r->state = h->state;
+  r->last_mse = h->cur_mse;
+  r->n_corr = h->n_corr;
+  const double denom = (double)(ctx->n_src_total + ctx->n_tgt_total);
+  r->align_strength = denom > 0 ? (double)h->n_corr / denom : 0.0;
+}
+
+int ope_icp_poll(ope_ctx *ctx, ope_icp_result *result) {
+  if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_poll: no run in progress");
+  OPE_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (result) fill_result(ctx, result);
+  return OPE_OK;
+}
+
+int ope_icp_end(ope_ctx *ctx, float out_T[16], ope_icp_result *result) {
+  int rc = ope_icp_poll(ctx, result);
+  if (rc != OPE_OK) return rc;
+  if (out_T)
+    for (int i = 0; i < 16; ++i) out_T[i] = (float)ctx->h_state->F[i];
+  ctx->run_active = false;
+  ctx->n_src_total = ctx->n_tgt_total = 0;
+  return OPE_OK;
+}
+
+int ope_icp_run(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float *guess,
+                const ope_icp_params *params, float out_T[16], ope_icp_result *result) {
+  static const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  if (out_T) std::memcpy(out_T, I4, sizeof I4);
+  if (result) std::memset(result, 0, sizeof *result);
+  int rc = ope_icp_begin(ctx, src, tgt, guess, params);
+  if (rc != OPE_OK) return rc;
+  const ope_icp_params &p = ctx->run_params;
+  const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
+  const bool sharded = ctx->nccl_comm != nullptr && ctx->comm_nranks > 1;
+  const int max_it = std::max(p.max_iterations, 1);
+  int it = 0;
+  while (it < max_it) {
+    const int batch = p.check_every > 0 ? std::min(p.check_every, max_it - it) : (max_it - it);
+    for (int b = 0; b < batch; ++b) {
+      launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, src->view(), tgt->view(), ctx->d_state,
+                            ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2);
+      if (sharded) {
+        launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, ctx->acc_blocks, false);
+        rc = comm_allreduce_sums(ctx, static_cast<double *>(ope_icp_sums_device(ctx)), kNumSums);
+        if (rc != OPE_OK) { ctx->run_active = false; return rc; }
+        launch_icp_update(ctx->stream, ctx->d_state);
+      } else {
+        launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, ctx->acc_blocks, true);
+      }
+    }
+    it += batch;
+    ctx->iters_enqueued = it;
+    OPE_HIP(ctx, hipGetLastError());
+    if (it < max_it) {
+      rc = ope_icp_poll(ctx, nullptr);
+      if (rc != OPE_OK) { ctx->run_active = false; return rc; }
+      if (ctx->h_state->done) break;
+    }
+  }
+  return ope_icp_end(ctx, out_T, result);
+}
+
+int ope_icp_correspondences(ope_ctx *ctx, int32_t *index_query, int32_t *index_match, float *distance, size_t cap,
+                            size_t *n_out) {
+  if (!ctx || !ctx->run_src || !n_out) return set_err(ctx, OPE_EINVAL, "ope_icp_correspondences: bad argument");
+  const ope_cloud *src = ctx->run_src;
+  const size_t n = src->n;
+  std::vector<int32_t> hm(n);
+  std::vector<float> hd(n);
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  if (n) {
+    OPE_HIP(ctx, hipMemcpyAsync(hm.data(), ctx->d_corr_match, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    OPE_HIP(ctx, hipMemcpyAsync(hd.data(), ctx->d_corr_d2, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+    OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  std::vector<int32_t> by_orig(n, -1);
+  std::vector<float> d_by_orig(n, 0.f);
+  for (size_t i = 0; i < src->n_valid; ++i) {
+    by_orig[src->perm[i]] = hm[i];
+    d_by_orig[src->perm[i]] = hd[i];
+  }
+  size_t m = 0;
+  for (size_t o = 0; o < n; ++o) {
+    if (by_orig[o] < 0) continue;
+    if (m < cap) {
+      if (index_query) index_query[m] = (int32_t)o;
+      if (index_match) index_match[m] = by_orig[o];
+      if (distance) distance[m] = d_by_orig[o];
+    }
+    ++m;
+  }
+  *n_out = m;
+  return OPE_OK;
+}
+
+int ope_fitness(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float T[16], double max_range,
+                double *score, double *sum_out, int64_t *n_out) {
+  if (!ctx || !src || !tgt || !T) return set_err(ctx, OPE_EINVAL, "ope_fitness: bad argument");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  const int nblocks = (int)std::min<size_t>(std::max<size_t>((src->n_valid + 255) / 256, 1), 2048);
+  int rc = ensure_scratch(ctx, 1 << 16);
+  if (rc != OPE_OK) return rc;
+  float rows[12];
+  colmajor_to_rows(T, rows);
+  float *d_T = static_cast<float *>(ctx->d_scratch);
+  double *d_part = reinterpret_cast<double *>(static_cast<unsigned char *>(ctx->d_scratch) + 256);
+  OPE_HIP(ctx, hipMemcpyAsync(d_T, rows, sizeof rows, hipMemcpyHostToDevice, ctx->stream));
+  launch_fitness(ctx->stream, nblocks, src->view(), tgt->view(), d_T, max_range, d_part);
+  std::vector<double> hp(2 * (size_t)nblocks);
+  OPE_HIP(ctx, hipMemcpyAsync(hp.data(), d_part, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, ctx->stream));
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double s = 0, c = 0;
+  for (int b = 0; b < nblocks; ++b) { s += hp[2 * b]; c += hp[2 * b + 1]; }
+  if (sum_out) *sum_out = s;
+  if (n_out) *n_out = (int64_t)c;
+  if (score) *score = c > 0 ? s / c : std::numeric_limits<double>::max();
+  return OPE_OK;
+}
+
+int ope_transform_cloud(ope_ctx *ctx, const ope_cloud *cloud, const float T[16], float *out_xyz) {
+  if (!ctx || !cloud || !T || !out_xyz) return set_err(ctx, OPE_EINVAL, "ope_transform_cloud: bad argument");
+  for (size_t i = 0; i < cloud->n; ++i) {
+    const float *p = &cloud->h_xyz[3 * i];
+    float *o = out_xyz + 3 * i;
+    if (!finite3(p)) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; continue; }
+    o[0] = T[0] * p[0] + T[4] * p[1] + T[8] * p[2] + T[12];
+    o[1] = T[1] * p[0] + T[5] * p[1] + T[9] * p[2] + T[13];
+    o[2] = T[2] * p[0] + T[6] * p[1] + T[10] * p[2] + T[14];
+  }
+  return OPE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,511 @@
+// icp_kernels.hip — the per-iteration ICP kernels (gfx950, wave64).
+//
+// One ICP iteration of IterativeClosestPoint::computeTransformation (vPCL impl/icp_mod.hpp:171-259)
+// is two launches on one GPU:
+//   icp_accumulate_kernel : steps 2-3-5a fused.  Each lane takes one source point, applies the
+//       current final transform (never materialising the transformed cloud, icp_mod.hpp:246),
+//       finds its exact nearest target point by BVH traversal (correspondence_estimation_mod.hpp:170),
+//       applies the distance threshold (:171) and the optional normal-based rejectors
+//       (correspondence_rejection_mod.h:368-391), stores the correspondence and accumulates the
+//       17 sums TransformationEstimationSVD/umeyama needs.  Block partials go to a fixed slot:
+//       no atomics, so results are bit-reproducible for a given launch geometry.
+//   icp_reduce_update_kernel : fixed-order reduction of the block partials, then (one lane)
+//       mean/covariance -> 3x3 Jacobi SVD in fp64 -> incremental T, final_T = T * final_T
+//       (icp_mod.hpp:243-251) and DefaultConvergenceCriteria::hasConverged (:257).  The "done" flag
+//       stays on the device; later launches of a batch early-out on it, so the host enqueues
+//       iterations back-to-back and polls only every `check_every` iterations.
+// Sharded (multi-GPU) runs split the second launch: reduce -> [all-reduce of S] -> update.
+#include "bvh_traverse.hpp"
+
+namespace ope {
+
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// k-nearest list of one lane, kept in LDS with a per-thread stride (bank-conflict free).
+struct KnnVisitor {
+  float *d;       // &lds_d[threadIdx.x], element j at d[j*stride]
+  uint32_t *pos;  // reordered target position
+  int stride, k, count;
+  float worst;
+  __device__ __forceinline__ bool prune(float bound) const { return !(bound < worst); }
+  __device__ __forceinline__ void point(float dist, const float4 &, uint32_t i) {
+    if (!(dist < worst)) return;
+    int j = (count < k) ? count++ : k - 1;
+    while (j > 0 && d[(j - 1) * stride] > dist) {
+      d[j * stride] = d[(j - 1) * stride];
+      pos[j * stride] = pos[(j - 1) * stride];
+      --j;
+    }
+    d[j * stride] = dist;
+    pos[j * stride] = i;
+    if (count == k) worst = d[(k - 1) * stride];
+  }
+};
+
+constexpr int kKnnBlock = 256;
+constexpr int kKnnMaxK = 32;
+
+// MODE 0: 1-NN correspondences.  MODE 1: normal shooting over the k nearest.
+// NRM: source/target normals present (rejectors and/or normal shooting).
+template <int MODE, bool NRM>
+__global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock) void icp_accumulate_kernel(
+    CloudView src, BvhView tgt, const IcpState *__restrict__ st, double *__restrict__ partials,
+    int32_t *__restrict__ corr_match, float *__restrict__ corr_d2) {
+  if (st->done) return;
+  constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
+  __shared__ double s_red[BLOCK / 64][kNumSums];
+  extern __shared__ unsigned char s_dyn[];  // MODE 1: k-NN lists
+
+  float F[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) F[i] = st->Ff[i];
+  const float psx = (float)st->pivot[0], psy = (float)st->pivot[1], psz = (float)st->pivot[2];
+  const double max_d2 = st->max_d2;
+  const bool rej_sn = NRM && st->use_surface_normal_rej;
+  const bool rej_so = NRM && st->use_self_occluded_rej;
+  const double thr_sn = st->surface_normal_thr, thr_so = st->self_occluded_thr;
+  const double max_dist_unsq = st->max_corr_dist;
+  const int kk = st->k_normal_shooting;
+
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  int cnt = 0;
+
+  const uint32_t stride = gridDim.x * BLOCK;
+  for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < src.n_valid; i += stride) {
+    const float4 s = src.xyzw[i];
+    const float x = xform_row(F + 0, s.x, s.y, s.z);
+    const float y = xform_row(F + 4, s.x, s.y, s.z);
+    const float z = xform_row(F + 8, s.x, s.y, s.z);
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (NRM) {
+      const float4 n4 = src.nrm[i];
+      nx = rot_row(F + 0, n4.x, n4.y, n4.z);
+      ny = rot_row(F + 4, n4.x, n4.y, n4.z);
+      nz = rot_row(F + 8, n4.x, n4.y, n4.z);
+    }
+    bool ok;
+    float d2;
+    uint32_t pos = 0;
+    int match = -1;
+    if (MODE == 0) {
+      NearestVisitor v{INFINITY, -1, 0};
+      bvh_traverse(tgt, x, y, z, v);
+      ok = v.idx >= 0 && !((double)v.best > max_d2);
+      d2 = v.best;
+      pos = v.pos;
+      match = v.idx;
+    } else {
+      float *ld = reinterpret_cast<float *>(s_dyn) + threadIdx.x;
+      uint32_t *lp = reinterpret_cast<uint32_t *>(s_dyn + sizeof(float) * BLOCK * kKnnMaxK) + threadIdx.x;
+      KnnVisitor v{ld, lp, BLOCK, kk, 0, INFINITY};
+      bvh_traverse(tgt, x, y, z, v);
+      // among the k nearest, the one with the smallest squared distance to the line (s, n)
+      // (…normal_shooting_weighted.hpp:115-135; cross product in double)
+      double min_dist = 1.79769313486231570815e308;
+      int min_j = 0;
+      for (int j = 0; j < v.count; ++j) {
+        const float4 p = tgt.pts[lp[j * BLOCK]];
+        const double vx = (double)__fsub_rn(p.x, x), vy = (double)__fsub_rn(p.y, y), vz = (double)__fsub_rn(p.z, z);
+        const double cx = (double)ny * vz - (double)nz * vy;
+        const double cy = (double)nz * vx - (double)nx * vz;
+        const double cz = (double)nx * vy - (double)ny * vx;
+        const double dist = cx * cx + cy * cy + cz * cz;
+        if (dist < min_dist) { min_dist = dist; min_j = j; }
+      }
+      // quirk Q2: squared line distance against the UNSQUARED max distance (:136)
+      ok = v.count > 0 && !(min_dist > max_dist_unsq);
+      d2 = v.count > 0 ? ld[min_j * BLOCK] : INFINITY;
+      pos = v.count > 0 ? lp[min_j * BLOCK] : 0;
+      match = v.count > 0 ? __float_as_int(tgt.pts[pos].w) : -1;
+    }
+    if (NRM && ok && rej_sn) {
+      const float4 tn = tgt.nrm[pos];
+      const float score = __fadd_rn(__fadd_rn(__fmul_rn(nx, tn.x), __fmul_rn(ny, tn.y)), __fmul_rn(nz, tn.z));
+      ok = (double)score > thr_sn;
+    }
+    if (NRM && ok && rej_so) {
+      const double sl = sqrt((double)__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+      const double score = (double)nx * (-(double)x / sl) + (double)ny * (-(double)y / sl) + (double)nz * (-(double)z / sl);
+      ok = score > thr_so;
+    }
+    corr_match[i] = ok ? match : -1;
+    corr_d2[i] = d2;
+    if (ok) {
+      const float4 t = tgt.pts[pos];
+      const float sx = x - psx, sy = y - psy, sz = z - psz;
+      const float tx = t.x - psx, ty = t.y - psy, tz = t.z - psz;
+      ++cnt;
+      acc[0] += sx; acc[1] += sy; acc[2] += sz;
+      acc[3] += tx; acc[4] += ty; acc[5] += tz;
+      acc[6] += tx * sx; acc[7] += tx * sy; acc[8] += tx * sz;
+      acc[9] += ty * sx; acc[10] += ty * sy; acc[11] += ty * sz;
+      acc[12] += tz * sx; acc[13] += tz * sy; acc[14] += tz * sz;
+      acc[15] += d2;
+    }
+  }
+
+  // wave -> block reduction in fp64, fixed order
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double v0 = wave_sum((double)cnt);
+  if (lane == 0) s_red[wave][0] = v0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double v = wave_sum((double)acc[k]);
+    if (lane == 0) s_red[wave][k + 1] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNumSums) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) v += s_red[w][threadIdx.x];
+    partials[threadIdx.x * kAccMaxBlocks + blockIdx.x] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fp64 3x3 helpers for the update step (one lane)
+__device__ void jacobi_eig3(double S[9], double V[9]) {
+  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = fabs(S[1]) + fabs(S[2]) + fabs(S[5]);
+    const double diag = fabs(S[0]) + fabs(S[4]) + fabs(S[8]);
+    if (off <= 1e-300 || off <= 1e-17 * diag) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = S[3 * p + q];
+        if (apq == 0.0) continue;
+        const double theta = (S[3 * q + q] - S[3 * p + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) {
+          const double a = S[3 * k + p], b = S[3 * k + q];
+          S[3 * k + p] = c * a - s * b;
+          S[3 * k + q] = s * a + c * b;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double a = S[3 * p + k], b = S[3 * q + k];
+          S[3 * p + k] = c * a - s * b;
+          S[3 * q + k] = s * a + c * b;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double a = V[3 * k + p], b = V[3 * k + q];
+          V[3 * k + p] = c * a - s * b;
+          V[3 * k + q] = s * a + c * b;
+        }
+      }
+  }
+}
+
+__device__ double det3(const double M[9]) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// A = U diag(s) V^T, s descending (row-major 3x3)
+__device__ void svd3(const double A[9], double U[9], double s[3], double V[9]) {
+  double AtA[9], Vt[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += A[3 * k + i] * A[3 * k + j];
+      AtA[3 * i + j] = a;
+    }
+  jacobi_eig3(AtA, Vt);
+  const double ev[3] = {AtA[0], AtA[4], AtA[8]};
+  int ord[3] = {0, 1, 2};
+  for (int i = 0; i < 2; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (ev[ord[j]] > ev[ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) V[3 * r + c] = Vt[3 * r + ord[c]];
+  double Uc[3][3];
+  for (int c = 0; c < 3; ++c) {
+    for (int r = 0; r < 3; ++r) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += A[3 * r + k] * V[3 * k + c];
+      Uc[c][r] = a;
+    }
+    s[c] = sqrt(Uc[c][0] * Uc[c][0] + Uc[c][1] * Uc[c][1] + Uc[c][2] * Uc[c][2]);
+  }
+  const double tiny = 1e-14 * (s[0] > 0 ? s[0] : 1.0);
+  for (int c = 0; c < 3; ++c) {
+    double *u = Uc[c];
+    for (int p = 0; p < c; ++p) {
+      const double d = u[0] * Uc[p][0] + u[1] * Uc[p][1] + u[2] * Uc[p][2];
+      for (int r = 0; r < 3; ++r) u[r] -= d * Uc[p][r];
+    }
+    double nrm = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    if (s[c] <= tiny || nrm <= 1e-8 * (s[c] > 0 ? s[c] : 1.0) + 1e-300) {
+      if (c == 0) { u[0] = 1; u[1] = 0; u[2] = 0; }
+      else if (c == 1) {
+        const double *a = Uc[0];
+        const int m = fabs(a[0]) < fabs(a[1]) ? (fabs(a[0]) < fabs(a[2]) ? 0 : 2) : (fabs(a[1]) < fabs(a[2]) ? 1 : 2);
+        const double d = a[m];
+        for (int r = 0; r < 3; ++r) u[r] = (r == m ? 1.0 : 0.0) - d * a[r];
+      } else {
+        const double *a = Uc[0], *b = Uc[1];
+        u[0] = a[1] * b[2] - a[2] * b[1];
+        u[1] = a[2] * b[0] - a[0] * b[2];
+        u[2] = a[0] * b[1] - a[1] * b[0];
+      }
+      nrm = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    }
+    for (int r = 0; r < 3; ++r) u[r] /= nrm;
+  }
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) U[3 * r + c] = Uc[c][r];
+}
+
+// Eigen::umeyama(src, dst, false) from the 17 sums (taken about `pivot`), column-major fp64 out.
+__device__ void umeyama_from_sums(const double S[kNumSums], const double pivot[3], double T[16]) {
+  const double n = S[0];
+  double sm[3], dm[3], sigma[9];
+  for (int d = 0; d < 3; ++d) { sm[d] = S[1 + d] / n; dm[d] = S[4 + d] / n; }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) sigma[3 * r + c] = S[7 + 3 * r + c] / n - dm[r] * sm[c];
+  for (int d = 0; d < 3; ++d) { sm[d] += pivot[d]; dm[d] += pivot[d]; }
+  double U[9], sv[3], V[9];
+  svd3(sigma, U, sv, V);
+  double Sg[3] = {1, 1, 1};
+  if (det3(sigma) < 0) Sg[2] = -1;
+  int rank = 0;
+  for (int i = 0; i < 3; ++i)
+    if (!(fabs(sv[i]) <= fabs(sv[0]) * 1e-5)) ++rank;
+  if (rank == 2) {
+    Sg[0] = Sg[1] = 1;
+    Sg[2] = (det3(U) * det3(V) > 0) ? 1 : -1;
+  }
+  double R[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += U[3 * i + k] * Sg[k] * V[3 * j + k];
+      R[3 * i + j] = a;
+    }
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) T[4 * c + r] = R[3 * r + c];
+  T[3] = T[7] = T[11] = 0.0;
+  for (int i = 0; i < 3; ++i) T[12 + i] = dm[i] - (R[3 * i] * sm[0] + R[3 * i + 1] * sm[1] + R[3 * i + 2] * sm[2]);
+  T[15] = 1.0;
+}
+
+__device__ void icp_update_lane(IcpState *st) {
+  const double n = st->S[0];
+  st->n_corr = (long long)n;
+  // icp_mod.hpp:232-240
+  if ((long long)n < (long long)st->min_correspondences) {
+    st->state = OPE_CONV_NO_CORRESPONDENCES;
+    st->converged = 0;
+    st->done = 1;
+    return;
+  }
+  double Tk[16];
+  umeyama_from_sums(st->S, st->pivot, Tk);
+  // transformation_ is a Matrix4f in the reference
+  float Tf[16];
+  for (int i = 0; i < 16; ++i) { Tf[i] = (float)Tk[i]; st->Tk[i] = (double)Tf[i]; }
+  // final_transformation_ = transformation_ * final_transformation_ (icp_mod.hpp:249), kept in fp64
+  double Fn[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      double a = 0;
+      for (int k = 0; k < 4; ++k) a += (double)Tf[4 * k + r] * st->F[4 * c + k];
+      Fn[4 * c + r] = a;
+    }
+  for (int i = 0; i < 16; ++i) st->F[i] = Fn[i];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) st->Ff[4 * r + c] = (float)Fn[4 * c + r];
+  const int iterations = ++st->iterations;
+
+  // DefaultConvergenceCriteria::hasConverged (uPCL) with the thresholds wired at icp_mod.hpp:164-168
+  st->state = OPE_CONV_NOT_CONVERGED;
+  int conv = 0;
+  if (iterations >= st->max_iterations) {
+    if (!st->failure_after_max_iter) { st->state = OPE_CONV_ITERATIONS; conv = 1; }
+    st->converged = conv;
+    st->done = 1;
+    return;
+  }
+  const double cos_angle = 0.5 * ((double)Tf[0] + (double)Tf[5] + (double)Tf[10] - 1.0);
+  const double tr2 = (double)Tf[12] * Tf[12] + (double)Tf[13] * Tf[13] + (double)Tf[14] * Tf[14];
+  if (cos_angle >= st->rotation_threshold && tr2 <= st->translation_threshold) {
+    st->state = OPE_CONV_TRANSFORM;
+    conv = 1;
+  } else {
+    st->cur_mse = st->S[16] / n;
+    const double diff = fabs(st->cur_mse - st->prev_mse);
+    if (diff < st->mse_threshold_absolute) { st->state = OPE_CONV_ABS_MSE; conv = 1; }
+    else if (diff / st->prev_mse < st->mse_threshold_relative) { st->state = OPE_CONV_REL_MSE; conv = 1; }
+    else st->prev_mse = st->cur_mse;
+  }
+  st->converged = conv;
+  st->done = conv;
+}
+
+// Fixed-order reduction of the block partials: 1024 threads, one per partial row.
+__global__ __launch_bounds__(kAccMaxBlocks) void icp_reduce_update_kernel(IcpState *st, const double *__restrict__ partials,
+                                                                            int nblocks, int do_update) {
+  if (st->done) return;
+  __shared__ double s_red[kAccMaxBlocks / 64][kNumSums];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kNumSums; ++k) {
+    double v = ((int)threadIdx.x < nblocks) ? partials[k * kAccMaxBlocks + threadIdx.x] : 0.0;
+    v = wave_sum(v);
+    if (lane == 0) s_red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNumSums) {
+    double v = 0.0;
+    for (int w = 0; w < kAccMaxBlocks / 64; ++w) v += s_red[w][threadIdx.x];
+    st->S[threadIdx.x] = v;
+  }
+  if (do_update) {
+    __syncthreads();
+    if (threadIdx.x == 0) icp_update_lane(st);
+  }
+}
+
+__global__ void icp_update_kernel(IcpState *st) {
+  if (st->done) return;
+  if (threadIdx.x == 0) icp_update_lane(st);
+}
+
+// ------------------------------------------------------------------------------------------
+// plain searches (ope_nn_search / ope_knn_search) and the fitness pass
+__global__ __launch_bounds__(256) void nn_search_kernel(CloudView q, BvhView tgt, const float *__restrict__ T,
+                                                         int has_T, int32_t *__restrict__ out_idx,
+                                                         float *__restrict__ out_d2) {
+  float F[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) F[i] = has_T ? T[i] : ((i % 5 == 0) ? 1.f : 0.f);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < q.n; i += gridDim.x * 256) {
+    if (i >= q.n_valid) { out_idx[i] = -1; out_d2[i] = INFINITY; continue; }
+    const float4 s = q.xyzw[i];
+    float x = s.x, y = s.y, z = s.z;
+    if (has_T) {
+      x = xform_row(F + 0, s.x, s.y, s.z);
+      y = xform_row(F + 4, s.x, s.y, s.z);
+      z = xform_row(F + 8, s.x, s.y, s.z);
+    }
+    NearestVisitor v{INFINITY, -1, 0};
+    bvh_traverse(tgt, x, y, z, v);
+    out_idx[i] = v.idx;
+    out_d2[i] = v.best;
+  }
+}
+
+__global__ __launch_bounds__(kKnnBlock) void knn_search_kernel(CloudView q, BvhView tgt, const float *__restrict__ T,
+                                                                int has_T, int k, int32_t *__restrict__ out_idx,
+                                                                float *__restrict__ out_d2) {
+  extern __shared__ unsigned char s_dyn[];
+  float *ld = reinterpret_cast<float *>(s_dyn) + threadIdx.x;
+  uint32_t *lp = reinterpret_cast<uint32_t *>(s_dyn + sizeof(float) * kKnnBlock * kKnnMaxK) + threadIdx.x;
+  float F[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) F[i] = has_T ? T[i] : ((i % 5 == 0) ? 1.f : 0.f);
+  for (uint32_t i = blockIdx.x * kKnnBlock + threadIdx.x; i < q.n; i += gridDim.x * kKnnBlock) {
+    int count = 0;
+    if (i < q.n_valid) {
+      const float4 s = q.xyzw[i];
+      float x = s.x, y = s.y, z = s.z;
+      if (has_T) {
+        x = xform_row(F + 0, s.x, s.y, s.z);
+        y = xform_row(F + 4, s.x, s.y, s.z);
+        z = xform_row(F + 8, s.x, s.y, s.z);
+      }
+      KnnVisitor v{ld, lp, kKnnBlock, k, 0, INFINITY};
+      bvh_traverse(tgt, x, y, z, v);
+      count = v.count;
+    }
+    for (int j = 0; j < k; ++j) {
+      const bool have = j < count;
+      out_idx[(size_t)i * k + j] = have ? __float_as_int(tgt.pts[lp[j * kKnnBlock]].w) : -1;
+      out_d2[(size_t)i * k + j] = have ? ld[j * kKnnBlock] : INFINITY;
+    }
+  }
+}
+
+// Registration::getFitnessScore: partial sums {Σ d2 (d2 <= max_range), count} per block.
+__global__ __launch_bounds__(256) void fitness_kernel(CloudView q, BvhView tgt, const float *__restrict__ T,
+                                                       double max_range, double *__restrict__ partials) {
+  __shared__ double s_red[4][2];
+  float F[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) F[i] = T[i];
+  double sum = 0.0, cnt = 0.0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < q.n_valid; i += gridDim.x * 256) {
+    const float4 s = q.xyzw[i];
+    const float x = xform_row(F + 0, s.x, s.y, s.z);
+    const float y = xform_row(F + 4, s.x, s.y, s.z);
+    const float z = xform_row(F + 8, s.x, s.y, s.z);
+    NearestVisitor v{INFINITY, -1, 0};
+    bvh_traverse(tgt, x, y, z, v);
+    if (v.idx >= 0 && (double)v.best <= max_range) { sum += (double)v.best; cnt += 1.0; }
+  }
+  sum = wave_sum(sum);
+  cnt = wave_sum(cnt);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { s_red[wave][0] = sum; s_red[wave][1] = cnt; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    partials[2 * blockIdx.x + threadIdx.x] =
+        s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host launchers (called from api.hip)
+void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, const CloudView &src,
+                           const BvhView &tgt, const IcpState *st, double *partials, int32_t *corr_match,
+                           float *corr_d2) {
+  if (mode == 0) {
+    if (nrm)
+      hipLaunchKernelGGL((icp_accumulate_kernel<0, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, st,
+                         partials, corr_match, corr_d2);
+    else
+      hipLaunchKernelGGL((icp_accumulate_kernel<0, false>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, st,
+                         partials, corr_match, corr_d2);
+  } else {
+    const size_t lds = (sizeof(float) + sizeof(uint32_t)) * kKnnBlock * kKnnMaxK;
+    hipLaunchKernelGGL((icp_accumulate_kernel<1, true>), dim3(nblocks), dim3(kKnnBlock), lds, stream, src, tgt, st,
+                       partials, corr_match, corr_d2);
+  }
+}
+
+void launch_icp_reduce_update(hipStream_t stream, IcpState *st, const double *partials, int nblocks, bool do_update) {
+  hipLaunchKernelGGL(icp_reduce_update_kernel, dim3(1), dim3(kAccMaxBlocks), 0, stream, st, partials, nblocks,
+                     do_update ? 1 : 0);
+}
+
+void launch_icp_update(hipStream_t stream, IcpState *st) {
+  hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(64), 0, stream, st);
+}
+
+void launch_nn_search(hipStream_t stream, const CloudView &q, const BvhView &tgt, const float *d_T, int32_t *out_idx,
+                      float *out_d2) {
+  const int nblocks = (int)std::min<size_t>((q.n + 255) / 256, 4096);
+  hipLaunchKernelGGL(nn_search_kernel, dim3(std::max(nblocks, 1)), dim3(256), 0, stream, q, tgt, d_T, d_T ? 1 : 0,
+                     out_idx, out_d2);
+}
+
+void launch_knn_search(hipStream_t stream, const CloudView &q, const BvhView &tgt, const float *d_T, int k,
+                       int32_t *out_idx, float *out_d2) {
+  const int nblocks = (int)std::min<size_t>((q.n + kKnnBlock - 1) / kKnnBlock, 4096);
+  const size_t lds = (sizeof(float) + sizeof(uint32_t)) * kKnnBlock * kKnnMaxK;
+  hipLaunchKernelGGL(knn_search_kernel, dim3(std::max(nblocks, 1)), dim3(kKnnBlock), lds, stream, q, tgt, d_T,
+                     d_T ? 1 : 0, k, out_idx, out_d2);
+}
+
+void launch_fitness(hipStream_t stream, int nblocks, const CloudView &q, const BvhView &tgt, const float *d_T,
+                    double max_range, double *partials) {
+  hipLaunchKernelGGL(fitness_kernel, dim3(nblocks), dim3(256), 0, stream, q, tgt, d_T, max_range, partials);
+}
+
+}  // namespace ope

@@ -1,0 +1,140 @@
+// ope_internal.hpp — shared host/device definitions of libope_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ope.h"
+
+namespace ope {
+
+// ---------------------------------------------------------------------------
+// Device-side view of the target search index: an implicit, perfectly balanced
+// binary BVH.  Node ids are heap indices (root 1, children 2i / 2i+1); nodes at
+// depth D (ids 2^D … 2^(D+1)-1) are leaf buckets.  Leaf j owns the contiguous
+// point range [j*n >> D, (j+1)*n >> D) of `pts`.  boxes[6*id .. 6*id+5] is the
+// TIGHT fp32 AABB {lo.xyz, hi.xyz} of the subtree, so the two children of node i
+// are 48 contiguous, 16-byte aligned bytes at boxes + 12*i.
+// ---------------------------------------------------------------------------
+struct BvhView {
+  const float *boxes;   // (2^(D+1)) * 6 floats
+  const float4 *pts;    // n points, w = ORIGINAL index (int bits)
+  const float4 *nrm;    // optional normals in the same order (xyz, w = curvature)
+  uint32_t n;
+  int depth;            // D
+};
+
+// Device-side view of a (Morton-sorted) query cloud.
+struct CloudView {
+  const float4 *xyzw;   // n points, sorted; w = ORIGINAL index (int bits); non-finite points last
+  const float4 *nrm;    // optional, same order
+  uint32_t n;           // all points
+  uint32_t n_valid;     // finite points (a prefix of the sorted order)
+};
+
+// Per-run ICP state living in device memory (one per context).
+struct IcpState {
+  double F[16];        // final_transformation_, column-major, fp64
+  double Tk[16];       // last incremental transformation_
+  float Ff[12];        // F rounded to fp32: rows of the 3x4 [R|t] (r00 r01 r02 tx, …)
+  double S[17];        // reduced sums of the current iteration
+  double pivot[3];
+  double prev_mse, cur_mse;
+  double rotation_threshold, translation_threshold;
+  double mse_threshold_relative, mse_threshold_absolute;
+  double max_d2;       // max_corr_dist^2 (fp64, compared against fp32 d2 widened)
+  double max_corr_dist;
+  double surface_normal_thr, self_occluded_thr;
+  long long n_corr;
+  int max_iterations, failure_after_max_iter, min_correspondences;
+  int iterations, converged, state, done;
+  int corr_mode, k_normal_shooting, use_surface_normal_rej, use_self_occluded_rej;
+};
+
+constexpr int kNumSums = 17;
+constexpr int kAccBlock = 512;       // threads per block of the accumulate kernel
+constexpr int kAccMaxBlocks = 1024;  // partials rows; the update kernel reduces them with 1024 threads
+
+}  // namespace ope
+
+struct ope_ctx {
+  int device = -1;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // ICP run state
+  ope::IcpState *d_state = nullptr;
+  double *d_partials = nullptr;   // [kNumSums][kAccMaxBlocks]
+  int32_t *d_corr_match = nullptr;  // per sorted query: ORIGINAL target index or -1
+  float *d_corr_d2 = nullptr;
+  size_t corr_cap = 0;
+  ope::IcpState *h_state = nullptr;  // pinned
+  const ope_cloud *run_src = nullptr;
+  const ope_index *run_tgt = nullptr;
+  ope_icp_params run_params{};
+  bool run_active = false;
+  int acc_blocks = 0;
+  int64_t n_src_total = 0, n_tgt_total = 0;
+  int iters_enqueued = 0;
+
+  // RCCL (dlopen'ed lazily)
+  void *nccl_comm = nullptr;
+  int comm_nranks = 1, comm_rank = 0;
+
+  // scratch
+  void *d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+struct ope_cloud {
+  ope_ctx *ctx = nullptr;
+  size_t n = 0, n_valid = 0;
+  float4 *d_xyzw = nullptr;
+  float4 *d_nrm = nullptr;
+  std::vector<float> h_xyz;       // original order, n*3
+  std::vector<int32_t> perm;      // sorted position -> original index
+  float bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
+  ope::CloudView view() const {
+    return ope::CloudView{d_xyzw, d_nrm, (uint32_t)n, (uint32_t)n_valid};
+  }
+};
+
+struct ope_index {
+  ope_ctx *ctx = nullptr;
+  size_t n = 0;        // indexed (finite) points
+  size_t n_total = 0;  // size of the target cloud it was built from
+  int depth = 0;
+  float *d_boxes = nullptr;
+  float4 *d_pts = nullptr;
+  float4 *d_nrm = nullptr;
+  double pivot[3] = {0, 0, 0};
+  float bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
+  ope::BvhView view() const { return ope::BvhView{d_boxes, d_pts, d_nrm, (uint32_t)n, depth}; }
+};
+
+namespace ope {
+
+int set_err(ope_ctx *ctx, int code, const std::string &msg);
+
+#define OPE_HIP(ctx, call)                                                                       \
+  do {                                                                                           \
+    hipError_t e__ = (call);                                                                     \
+    if (e__ != hipSuccess)                                                                       \
+      return ::ope::set_err((ctx), OPE_EHIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+// Host-side index build (bvh_build.cpp).  pts: n*3 floats (finite only), ids: their ORIGINAL
+// indices, nrm optional n*3.  Outputs host arrays ready for upload.
+struct HostBvh {
+  int depth = 0;
+  std::vector<float> boxes;   // (2^(D+1))*6
+  std::vector<float> pts4;    // n*4 (x,y,z, original index bits)
+  std::vector<float> nrm4;    // n*4 or empty
+};
+void build_bvh_host(const float *xyz, const int32_t *ids, const float *nrm, size_t n, int leaf_size, HostBvh &out);
+
+}  // namespace ope

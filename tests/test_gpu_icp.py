@@ -1,0 +1,274 @@
+"""GPU parity tests for the ICP hot path: HIP kernels (through the C ABI) vs the CPU oracle.
+
+Tolerances (BASELINE.json north_star): final 4x4 within 1e-4 Frobenius of the reference path;
+nearest-neighbour indices/distances are integer/bit-exact work and are compared exactly.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+synth = __import__("importlib").import_module("object-pose-estimation_amd.synth")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    ope = load_pkg()
+    c = ope.Context(0)
+    yield c
+    c.close()
+
+
+def rigid(rx, ry, rz, t):
+    T = np.eye(4)
+    T[:3, :3] = synth.rot_xyz(rx, ry, rz)
+    T[:3, 3] = t
+    return T
+
+
+def apply(T, p):
+    return (p.astype(np.float64) @ np.asarray(T, np.float64)[:3, :3].T + np.asarray(T, np.float64)[:3, 3]).astype(np.float32)
+
+
+def frob(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)))
+
+
+# ------------------------------------------------------------------ exact NN (KAT-3 on the GPU)
+@pytest.mark.parametrize("nt,nq,leaf", [(1, 10, 16), (5, 100, 16), (1000, 5000, 4), (20000, 50000, 16), (20000, 50000, 64)])
+def test_nn_search_bit_exact_vs_oracle(ctx, nt, nq, leaf):
+    rng = np.random.default_rng(nt + nq)
+    tgt = rng.uniform(-0.1, 0.1, (nt, 3)).astype(np.float32)
+    q = rng.uniform(-0.25, 0.25, (nq, 3)).astype(np.float32)
+    ct, cq = ctx.upload(tgt), ctx.upload(q)
+    ix = ctx.build_index(ct, leaf_size=leaf)
+    idx, d2 = ctx.nn(cq, ix)
+    oi, od, _ = oracle.KdTree(tgt).knn(q, 1)
+    np.testing.assert_array_equal(d2, od[:, 0])           # same unfused fp32 arithmetic -> bit equal
+    same = idx == oi[:, 0]
+    if not same.all():                                    # only exact distance ties may pick another index
+        bad = np.where(~same)[0]
+        alt = ((q[bad] - tgt[idx[bad]]) ** 2).astype(np.float32)
+        assert np.allclose(alt.sum(1), od[bad, 0], rtol=1e-6)
+        assert len(bad) <= max(2, nq // 10000)
+
+
+def test_nn_search_with_transform_and_nan_queries(ctx):
+    rng = np.random.default_rng(1)
+    tgt = synth.model_surface(5000, 1)
+    q = synth.scene_cloud(20000)
+    q[::500] = np.nan
+    T = np.linalg.inv(synth.ground_truth_pose())
+    ct, cq = ctx.upload(tgt), ctx.upload(q)
+    ix = ctx.build_index(ct)
+    idx, d2 = ctx.nn(cq, ix, T)
+    qt = oracle.transform_points(q, T)
+    oi, od, found = oracle.KdTree(tgt).knn(qt, 1)
+    bad = ~np.isfinite(q).all(1)
+    assert (idx[bad] == -1).all() and np.isinf(d2[bad]).all()
+    np.testing.assert_array_equal(d2[~bad], od[~bad, 0])
+    assert (idx[~bad] == oi[~bad, 0]).mean() > 0.9999
+
+
+def test_nn_target_with_nonfinite_points_reports_original_indices(ctx):
+    tgt = np.array([[0, 0, 0], [np.nan, 0, 0], [0.5, 0, 0], [np.inf, 1, 1], [1.0, 0, 0]], np.float32)
+    q = np.array([[0.45, 0, 0], [0.9, 0, 0], [-1, 0, 0]], np.float32)
+    ix = ctx.build_index(ctx.upload(tgt))
+    idx, d2 = ctx.nn(ctx.upload(q), ix)
+    assert idx.tolist() == [2, 4, 0]
+
+
+@pytest.mark.parametrize("k", [1, 5, 20, 30])
+def test_knn_search_vs_oracle(ctx, k):
+    rng = np.random.default_rng(k)
+    tgt = synth.model_surface(8000, 3)
+    q = (tgt[:3000] + rng.normal(0, 0.003, (3000, 3))).astype(np.float32)
+    ix = ctx.build_index(ctx.upload(tgt))
+    idx, d2 = ctx.knn(ctx.upload(q), ix, k)
+    oi, od, _ = oracle.KdTree(tgt).knn(q, k)
+    np.testing.assert_array_equal(d2, od)
+    assert (idx == oi).mean() > 0.9999
+
+
+def test_knn_fewer_points_than_k(ctx):
+    tgt = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], np.float32)
+    ix = ctx.build_index(ctx.upload(tgt))
+    idx, d2 = ctx.knn(ctx.upload(np.array([[0.1, 0, 0]], np.float32)), ix, 5)
+    assert idx[0].tolist() == [0, 1, 2, -1, -1] and np.isinf(d2[0, 3:]).all()
+
+
+# ------------------------------------------------------------------ ICP parity
+def gpu_icp(ctx, src, tgt, src_nrm=None, tgt_nrm=None, guess=None, **kw):
+    ope = load_pkg()
+    cs = ctx.upload(src, src_nrm)
+    ct = ctx.upload(tgt, tgt_nrm)
+    ix = ctx.build_index(ct)
+    return ctx.icp(cs, ix, ope.default_icp_params(**kw), guess), cs, ix
+
+
+def orc_params(**kw):
+    p = oracle.default_icp_params()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+@pytest.mark.parametrize("pose", [(3, 0, 0, [0.005, 0, 0]), (5, 5, 5, [0.01, 0.01, 0.01]), (2, -9, -3, [0.01, -0.02, 0.005])])
+def test_icp_kat1_rigid_recovery(ctx, pose):
+    P = synth.bumpy_torus(2000)
+    Tgt = rigid(*pose)
+    Q = apply(Tgt, P)
+    out, cs, ix = gpu_icp(ctx, P, Q, max_iterations=60, transformation_epsilon=1e-12, euclidean_fitness_epsilon=1e-14)
+    assert out.converged
+    assert frob(out.T, Tgt) < 5e-5
+    assert out.n_corr == len(P)
+    assert out.align_strength == pytest.approx(len(P) / (2 * len(P)))
+    score, s, n = ctx.fitness(cs, ix, out.T)
+    assert n == len(P) and score < 1e-9
+
+
+@pytest.mark.parametrize("ns,nt", [(20000, 5000), (100000, 20000)])
+def test_icp_matches_oracle_on_synthetic_scene(ctx, ns, nt):
+    """BASELINE config C2 (and a smaller sibling): scene = source, model = target, 50 iterations."""
+    src = synth.scene_cloud(ns)
+    tgt = synth.model_surface(nt, 1)
+    kw = dict(max_iterations=50, transformation_epsilon=1e-10, euclidean_fitness_epsilon=1e-10)
+    out, cs, ix = gpu_icp(ctx, src, tgt, **kw)
+    ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=0, **kw))       # reference arithmetic
+    ref1 = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw))     # device-style composition
+    assert frob(out.T, ref.T) < 1e-4, (out, ref.T)
+    assert frob(out.T, ref1.T) < 1e-4
+    assert abs(out.iterations - ref.iterations) <= 2
+    assert out.state == ref.state or out.iterations != ref.iterations
+    assert out.n_corr == ref.n_corr == ns
+    assert out.last_mse == pytest.approx(ref.last_mse, rel=1e-3)
+    # fitness score and aligned strength (the two scalars the reference's caller thresholds)
+    score, _, n = ctx.fitness(cs, ix, out.T)
+    assert n == ns and score == pytest.approx(ref.fitness, rel=1e-3)
+    assert out.align_strength == pytest.approx(ref.align_strength)
+    # ground truth: the scene was posed by GT, so ICP must come back near GT^-1 (clutter biases it slightly)
+    Tinv = np.linalg.inv(synth.ground_truth_pose())
+    assert frob(out.T, Tinv) < 0.1
+
+
+def test_icp_fixed_iterations_per_iteration_parity(ctx):
+    """Convergence disabled: exactly K iterations, transform compared after every K."""
+    src = synth.scene_cloud(30000)
+    tgt = synth.model_surface(8000, 1)
+    for K in (1, 2, 5, 17):
+        kw = dict(max_iterations=K, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0)
+        out, _, _ = gpu_icp(ctx, src, tgt, mse_threshold_absolute=-1.0, **kw)
+        ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, mse_threshold_absolute=-1.0, **kw))
+        assert out.iterations == ref.iterations == K and out.state == ref.state == 1 and out.converged
+        assert frob(out.T, ref.T) < 2e-5, K
+
+
+def test_icp_correspondences_match_oracle(ctx):
+    src = synth.scene_cloud(20000)
+    tgt = synth.model_surface(5000, 1)
+    kw = dict(max_iterations=3, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, max_corr_dist=0.02)
+    out, cs, ix = gpu_icp(ctx, src, tgt, mse_threshold_absolute=-1.0, **kw)
+    ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, mse_threshold_absolute=-1.0, **kw))
+    q, m, d = ctx.icp_correspondences(len(src))
+    assert out.n_corr == len(q)
+    assert abs(len(q) - ref.n_corr) <= 3                   # points within rounding of the threshold
+    common, ia, ib = np.intersect1d(q, ref.corr_q, return_indices=True)
+    assert len(common) >= ref.n_corr - 3
+    assert (m[ia] == ref.corr_m[ib]).mean() > 0.999
+    np.testing.assert_allclose(d[ia], ref.corr_d2[ib], rtol=1e-3, atol=1e-9)
+    assert (np.diff(q) > 0).all()                          # query order, like PCL's compaction
+
+
+def test_icp_guess_is_applied(ctx):
+    P = synth.bumpy_torus(1500)
+    Tgt = rigid(4, -3, 8, [0.01, -0.01, 0.015])
+    Q = apply(Tgt, P)
+    guess = rigid(4, -3, 7, [0.01, -0.01, 0.014])
+    out, _, _ = gpu_icp(ctx, P, Q, guess=guess, max_iterations=40)
+    ref = oracle.icp(P, Q, orc_params(max_iterations=40, acc_mode=1), guess=guess)
+    assert frob(out.T, Tgt) < 5e-5 and frob(out.T, ref.T) < 5e-5
+
+
+def test_icp_no_correspondences_guard(ctx):
+    P = synth.bumpy_torus(500)
+    Q = apply(rigid(0, 0, 0, [1.0, 0, 0]), P)
+    out, _, _ = gpu_icp(ctx, P, Q, max_corr_dist=0.01)
+    assert not out.converged and out.state == 5 and out.iterations == 0
+    np.testing.assert_array_equal(out.T, np.eye(4, dtype=np.float32))
+
+
+def test_icp_nan_points_skipped(ctx):
+    P = synth.bumpy_torus(1000)
+    Q = apply(rigid(2, 0, 1, [0.004, 0, 0]), P)
+    Pn = P.copy(); Pn[::100] = np.nan
+    a, _, _ = gpu_icp(ctx, Pn, Q, max_iterations=30)
+    ref = oracle.icp(Pn, Q, orc_params(max_iterations=30, acc_mode=1))
+    assert a.n_corr == ref.n_corr == 990
+    assert frob(a.T, ref.T) < 2e-5
+
+
+def test_icp_empty_target_and_missing_target_error_codes(ctx):
+    ope = load_pkg()
+    P = synth.bumpy_torus(100)
+    cs = ctx.upload(P)
+    empty = ctx.upload(np.zeros((0, 3), np.float32))
+    with pytest.raises(ope.OpeError) as e:
+        ctx.build_index(empty)
+    assert e.value.code == ope.OPE_EEMPTY
+    with pytest.raises(ope.OpeError) as e:
+        ctx.icp(cs, None)
+    assert e.value.code == ope.OPE_EEMPTY
+
+
+def test_icp_normal_shooting_and_rejectors_match_oracle(ctx):
+    """The configuration estimateFinePose actually runs (poseestimator.cpp:242-246,331-337)."""
+    ope = load_pkg()
+    rng = np.random.default_rng(3)
+    u = rng.normal(size=(6000, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    c = np.array([0, 0, 1.0])
+    P = (0.1 * u + c).astype(np.float32); nP = u.astype(np.float32)
+    Tgt = rigid(1, -1, 2, [0.002, -0.001, 0.001])
+    Q = apply(Tgt, P); nQ = (nP.astype(np.float64) @ Tgt[:3, :3].T).astype(np.float32)
+    kw = dict(max_iterations=15, corr_mode=1, k_normal_shooting=20, use_surface_normal_rej=1, surface_normal_thr=0.7,
+              use_self_occluded_rej=1, self_occluded_thr=0.6)
+    out, cs, ix = gpu_icp(ctx, P, Q, src_nrm=nP, tgt_nrm=nQ, **kw)
+    ref = oracle.icp(P, Q, orc_params(acc_mode=1, transform_mode=1, **kw), src_nrm=nP, tgt_nrm=nQ)
+    assert out.iterations == ref.iterations
+    assert abs(out.n_corr - ref.n_corr) <= 3
+    assert frob(out.T, ref.T) < 1e-4
+    q, m, d = ctx.icp_correspondences(len(P))
+    common, ia, ib = np.intersect1d(q, ref.corr_q, return_indices=True)
+    assert (m[ia] == ref.corr_m[ib]).mean() > 0.99
+
+
+def test_icp_struct_upload_pointxyzrgbnormal_layout(ctx):
+    """Upload straight from a pcl::PointXYZRGBNormal-shaped buffer (48 B stride, normals at +16)."""
+    ope = load_pkg()
+    P = synth.bumpy_torus(800)
+    nP = np.tile(np.array([[0, 0, 1.0]], np.float32), (800, 1))
+    buf = np.zeros((800, 12), np.float32)
+    buf[:, 0:3] = P; buf[:, 3] = 1.0; buf[:, 4:7] = nP
+    cs = ctx.upload_struct(buf, 48, 0, 16)
+    ct = ctx.upload(apply(rigid(1, 2, 3, [0.002, 0.001, 0]), P))
+    ix = ctx.build_index(ct)
+    out = ctx.icp(cs, ix, ope.default_icp_params(max_iterations=30))
+    assert frob(out.T, rigid(1, 2, 3, [0.002, 0.001, 0])) < 5e-5
+
+
+def test_stepwise_api_equals_run(ctx):
+    ope = load_pkg()
+    src = synth.scene_cloud(20000)
+    tgt = synth.model_surface(5000, 1)
+    cs = ctx.upload(src); ix = ctx.build_index(ctx.upload(tgt))
+    p = ope.default_icp_params(max_iterations=8, mse_threshold_absolute=-1.0)
+    a = ctx.icp(cs, ix, p)
+    ctx.icp_begin(cs, ix, p)
+    for _ in range(8):
+        ctx.icp_accumulate()
+        ctx.icp_update()
+    b = ctx.icp_end()
+    np.testing.assert_array_equal(a.T, b.T)
+    assert a.iterations == b.iterations == 8
