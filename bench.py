@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — ICP iterations/sec on the BASELINE.json workload, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE ICP iteration (icp_mod.hpp:171-259: correspondence search over all scene points,
+17-sum reduction, SVD transform update, convergence test) on synthetic config C3: a 1 M-point scene
+(source/queries) against a 100 k-point model (target/indexed), inputs resident in HBM, target index
+prebuilt, early exit disabled so exactly W + K iterations execute.  With N > 1 the scene is sharded
+across ranks (strong scaling: total work fixed), the model index is replicated and the 17 fp64 sums
+are all-reduced over RCCL once per iteration.
+
+Rank 0 prints one JSON line with `roofline` (dominant kernel = icp_accumulate_kernel, timed with HIP
+events on its launch stream inside the timed region) and, at N = 1, `cpu_baseline` (the C oracle, a
+scalar single-thread port of the PCL path, on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+WORKLOADS = {
+    # name: (n_scene, n_model, description)
+    "C3": (1_000_000, 100_000, "C3: synthetic 1M-pt scene (source) vs 100k-pt model (target), point-to-point ICP"),
+    "C2": (100_000, 20_000, "C2: synthetic 100k-pt scene vs 20k-pt model, point-to-point ICP"),
+}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--comm", default="torch", choices=["torch", "native"],
+                    help="N>1: all-reduce through torch.distributed (RCCL) or the library's own RCCL communicator")
+    ap.add_argument("--leaf", type=int, default=0, help="index leaf size override (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
+            return 2
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the hot path is HIP-only and has no CPU fallback", file=sys.stderr)
+        return 3
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    ope = importlib.import_module("object-pose-estimation_amd")
+    synth = importlib.import_module("object-pose-estimation_amd.synth")
+
+    n_scene, n_model, desc = WORKLOADS[args.workload]
+    K, W = args.steps, args.warmup
+    scene = synth.scene_cloud(n_scene)
+    model = synth.model_surface(n_model, 1)
+    lo, hi = rank * n_scene // world, (rank + 1) * n_scene // world
+    shard = scene[lo:hi]
+
+    ctx = ope.Context(local_rank)
+    use_torch_comm = world > 1 and args.comm == "torch"
+    if world > 1:
+        # launch on torch's current stream so torch.distributed orders the collective with our kernels
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    cs = ctx.upload(shard)
+    ix = ctx.build_index(ctx.upload(model), leaf_size=args.leaf or None)
+    sums = None
+    if use_torch_comm:
+        sums = torch.zeros(17, dtype=torch.float64, device="cuda")
+        ctx.icp_set_sums_buffer(sums.data_ptr())
+    elif world > 1:
+        ids = [ope.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(ids[0], world, rank)
+
+    params = ope.default_icp_params(max_iterations=W + K + 1, transformation_epsilon=0.0,
+                                    euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0, check_every=0)
+    ctx.icp_set_global_sizes(n_scene, n_model)
+    ctx.icp_begin(cs, ix, params)
+
+    def step():
+        if use_torch_comm:
+            ctx.icp_accumulate()
+            dist.all_reduce(sums)
+            ctx.icp_update()
+        else:
+            ctx.icp_iterate(1)
+
+    def sync():
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(W):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    ctx.icp_profile(K)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kern_ms, kern_n = ctx.icp_profile_read()
+    ctx.icp_profile(0)
+    out = ctx.icp_end()
+    assert out.iterations == W + K, (out.iterations, W, K)
+
+    if world > 1:
+        t = torch.tensor([elapsed, kern_ms / max(kern_n, 1)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kern_avg_ms = float(t[0]), float(t[1])
+    else:
+        kern_avg_ms = kern_ms / max(kern_n, 1)
+
+    rc = 0
+    if rank == 0:
+        n_local = hi - lo
+        # 36 B per source point (read xyz 12 + gather match 12 + write correspondence 12)
+        # + 12 B per target point, per launch of the accumulate kernel on this rank
+        algo_bytes = 36.0 * n_local + 12.0 * n_model
+        achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if world == 1 and os.path.exists(tf):
+            try:
+                rec = json.load(open(tf)).get(args.workload)
+                if rec:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "ICP iterations/sec (1M scene pts vs 100k model pts)" if args.workload == "C3"
+                      else "ICP iterations/sec (100k scene pts vs 20k model pts)",
+            "value": K / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc, "n_scene": n_scene, "n_model": n_model, "scene_shard_per_gpu": n_local,
+                       "parallelism": f"scene-sharded x{world}, model index replicated, 17xfp64 all-reduce/iter"
+                                      + (f" ({args.comm})" if world > 1 else ""),
+                       "final_mse": out.last_mse, "n_corr": int(out.n_corr)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "icp_accumulate_kernel", "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(np, scene, model, args.cpu_iters)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return rc
+
+
+def cpu_baseline(np, scene, model, iters: int) -> dict:
+    """The C oracle (scalar, one thread) on a bounded sample: `iters` full ICP iterations of the same
+    workload from the identity guess, kd-tree prebuilt (as the GPU's index is)."""
+    import oracle
+    tree = oracle.KdTree(model)
+    pivot = 0.5 * (model.min(0).astype(np.float64) + model.max(0).astype(np.float64))
+    T = np.eye(4, dtype=np.float32)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        S = oracle.icp_partial_sums(scene, tree, T, float(np.sqrt(np.finfo(np.float64).max)), pivot)
+        Tk = oracle.umeyama_from_sums(S, pivot)
+        T = (Tk.astype(np.float64) @ T.astype(np.float64)).astype(np.float32)
+    dt = time.perf_counter() - t0
+    return {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{iters} full ICP iterations (1-NN over all {len(scene)} scene points + SVD update) of the same "
+                      f"workload from the identity guess, kd-tree prebuilt; gcc -O3, single thread; host has "
+                      f"{os.cpu_count()} logical cores"}
+
+
+if __name__ == "__main__":
+    sys.exit(main())

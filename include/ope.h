@@ -165,10 +165,22 @@ int ope_icp_accumulate(ope_ctx *ctx);
 /* Device pointer to the 17 fp64 sums {n, Σs[3], Σt[3], Σ t sᵀ[9], Σd²} (about the index pivot). */
 void *ope_icp_sums_device(ope_ctx *ctx);
 int ope_icp_update(ope_ctx *ctx);
+/* Use a caller-owned device buffer of 17 doubles for the sums (e.g. a torch tensor that
+ * torch.distributed all-reduces); NULL restores the internal buffer. */
+int ope_icp_set_sums_buffer(ope_ctx *ctx, void *device_ptr);
+/* Enqueue n whole iterations (accumulate -> reduce -> [RCCL all-reduce if ope_comm_init_rank was
+ * called] -> update) without synchronising the host. */
+int ope_icp_iterate(ope_ctx *ctx, int n_iterations);
 int ope_icp_poll(ope_ctx *ctx, ope_icp_result *result); /* syncs the stream */
 int ope_icp_end(ope_ctx *ctx, float out_T[16], ope_icp_result *result);
 /* In sharded runs: the sizes getAlignStrength divides by (defaults: local sizes). */
 int ope_icp_set_global_sizes(ope_ctx *ctx, int64_t n_src_total, int64_t n_tgt_total);
+
+/* Measurement hook: bracket up to max_launches launches of the accumulate kernel (the dominant
+ * kernel) with HIP events on the launch stream; 0 disables.  ope_icp_profile_read synchronises and
+ * returns the summed kernel time and the number of launches timed since ope_icp_profile. */
+int ope_icp_profile(ope_ctx *ctx, int max_launches);
+int ope_icp_profile_read(ope_ctx *ctx, double *total_ms, int *n_launches);
 
 /* Last iteration's post-rejection correspondences, compacted in query order
  * (pcl::Correspondences: index_query, index_match, distance = squared L2). */

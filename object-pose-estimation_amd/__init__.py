@@ -121,6 +121,10 @@ ABI = [
     ("ope_icp_accumulate", C.c_int, [_vp]),
     ("ope_icp_sums_device", _vp, [_vp]),
     ("ope_icp_update", C.c_int, [_vp]),
+    ("ope_icp_set_sums_buffer", C.c_int, [_vp, _vp]),
+    ("ope_icp_iterate", C.c_int, [_vp, C.c_int]),
+    ("ope_icp_profile", C.c_int, [_vp, C.c_int]),
+    ("ope_icp_profile_read", C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     ("ope_icp_poll", C.c_int, [_vp, C.POINTER(IcpResult)]),
     ("ope_icp_end", C.c_int, [_vp, _fp, C.POINTER(IcpResult)]),
     ("ope_icp_set_global_sizes", C.c_int, [_vp, C.c_int64, C.c_int64]),
@@ -310,6 +314,20 @@ class Context:
 
     def icp_update(self):
         self._chk(lib().ope_icp_update(self.h))
+
+    def icp_set_sums_buffer(self, device_ptr: int | None):
+        self._chk(lib().ope_icp_set_sums_buffer(self.h, _vp(device_ptr) if device_ptr else None))
+
+    def icp_iterate(self, n: int = 1):
+        self._chk(lib().ope_icp_iterate(self.h, n))
+
+    def icp_profile(self, max_launches: int):
+        self._chk(lib().ope_icp_profile(self.h, max_launches))
+
+    def icp_profile_read(self):
+        ms = C.c_double(0); n = C.c_int(0)
+        self._chk(lib().ope_icp_profile_read(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def icp_poll(self) -> IcpResult:
         r = IcpResult()

@@ -13,8 +13,8 @@ namespace ope {
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, const CloudView &, const BvhView &, const IcpState *, double *,
                            int32_t *, float *);
-void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, int, bool);
-void launch_icp_update(hipStream_t, IcpState *);
+void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool);
+void launch_icp_update(hipStream_t, IcpState *, const double *);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
 void launch_knn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int, int32_t *, float *);
 void launch_fitness(hipStream_t, int, const CloudView &, const BvhView &, const float *, double, double *);
@@ -52,6 +52,26 @@ static int ensure_scratch(ope_ctx *ctx, size_t bytes) {
   ctx->scratch_bytes = 0;
   OPE_HIP(ctx, hipMalloc(&ctx->d_scratch, bytes));
   ctx->scratch_bytes = bytes;
+  return OPE_OK;
+}
+
+static double *sums_ptr(ope_ctx *ctx) {
+  if (ctx->d_sums_ext) return ctx->d_sums_ext;
+  return reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(ctx->d_state) + offsetof(IcpState, S));
+}
+
+// One accumulate launch, optionally bracketed by HIP events on the launch stream (bench.py's roofline leg).
+static int enqueue_accumulate(ope_ctx *ctx) {
+  const ope_icp_params &p = ctx->run_params;
+  const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
+  const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
+  if (timed) OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], ctx->stream));
+  launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, ctx->run_src->view(), ctx->run_tgt->view(),
+                        ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2);
+  if (timed) {
+    OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
+    ++ctx->prof_used;
+  }
   return OPE_OK;
 }
 
@@ -97,6 +117,7 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   ope_comm_destroy(ctx);
+  for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
   if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
@@ -455,23 +476,74 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
 
 int ope_icp_accumulate(ope_ctx *ctx) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_accumulate: no run in progress");
-  const ope_icp_params &p = ctx->run_params;
-  const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
-  launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, ctx->run_src->view(), ctx->run_tgt->view(),
-                        ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2);
-  launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, ctx->acc_blocks, /*do_update=*/false);
+  int rc = enqueue_accumulate(ctx);
+  if (rc != OPE_OK) return rc;
+  launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, /*do_update=*/false);
   OPE_HIP(ctx, hipGetLastError());
   return OPE_OK;
 }
 
 void *ope_icp_sums_device(ope_ctx *ctx) {
   if (!ctx || !ctx->d_state) return nullptr;
-  return reinterpret_cast<unsigned char *>(ctx->d_state) + offsetof(IcpState, S);
+  return sums_ptr(ctx);
+}
+
+int ope_icp_set_sums_buffer(ope_ctx *ctx, void *device_ptr) {
+  if (!ctx) return OPE_EINVAL;
+  ctx->d_sums_ext = static_cast<double *>(device_ptr);
+  return OPE_OK;
+}
+
+int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
+  if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_iterate: no run in progress");
+  const bool sharded = ctx->nccl_comm != nullptr && ctx->comm_nranks > 1;
+  for (int b = 0; b < n_iterations; ++b) {
+    int rc = enqueue_accumulate(ctx);
+    if (rc != OPE_OK) return rc;
+    if (sharded) {
+      launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false);
+      rc = comm_allreduce_sums(ctx, sums_ptr(ctx), kNumSums);
+      if (rc != OPE_OK) return rc;
+      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx));
+    } else {
+      launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, true);
+    }
+  }
+  ctx->iters_enqueued += n_iterations;
+  OPE_HIP(ctx, hipGetLastError());
+  return OPE_OK;
+}
+
+int ope_icp_profile(ope_ctx *ctx, int max_launches) {
+  if (!ctx) return OPE_EINVAL;
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->prof_enabled = max_launches > 0;
+  ctx->prof_used = 0;
+  while (ctx->prof_events.size() < 2 * (size_t)std::max(max_launches, 0)) {
+    hipEvent_t e;
+    OPE_HIP(ctx, hipEventCreate(&e));
+    ctx->prof_events.push_back(e);
+  }
+  return OPE_OK;
+}
+
+int ope_icp_profile_read(ope_ctx *ctx, double *total_ms, int *n_launches) {
+  if (!ctx) return OPE_EINVAL;
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0;
+  for (size_t i = 0; i < ctx->prof_used; ++i) {
+    float ms = 0.f;
+    OPE_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (n_launches) *n_launches = (int)ctx->prof_used;
+  return OPE_OK;
 }
 
 int ope_icp_update(ope_ctx *ctx) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_update: no run in progress");
-  launch_icp_update(ctx->stream, ctx->d_state);
+  launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx));
   OPE_HIP(ctx, hipGetLastError());
   ++ctx->iters_enqueued;
   return OPE_OK;
@@ -514,27 +586,13 @@ int ope_icp_run(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const 
   int rc = ope_icp_begin(ctx, src, tgt, guess, params);
   if (rc != OPE_OK) return rc;
   const ope_icp_params &p = ctx->run_params;
-  const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
-  const bool sharded = ctx->nccl_comm != nullptr && ctx->comm_nranks > 1;
   const int max_it = std::max(p.max_iterations, 1);
   int it = 0;
   while (it < max_it) {
     const int batch = p.check_every > 0 ? std::min(p.check_every, max_it - it) : (max_it - it);
-    for (int b = 0; b < batch; ++b) {
-      launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, src->view(), tgt->view(), ctx->d_state,
-                            ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2);
-      if (sharded) {
-        launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, ctx->acc_blocks, false);
-        rc = comm_allreduce_sums(ctx, static_cast<double *>(ope_icp_sums_device(ctx)), kNumSums);
-        if (rc != OPE_OK) { ctx->run_active = false; return rc; }
-        launch_icp_update(ctx->stream, ctx->d_state);
-      } else {
-        launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, ctx->acc_blocks, true);
-      }
-    }
+    rc = ope_icp_iterate(ctx, batch);
+    if (rc != OPE_OK) { ctx->run_active = false; return rc; }
     it += batch;
-    ctx->iters_enqueued = it;
-    OPE_HIP(ctx, hipGetLastError());
     if (it < max_it) {
       rc = ope_icp_poll(ctx, nullptr);
       if (rc != OPE_OK) { ctx->run_active = false; return rc; }

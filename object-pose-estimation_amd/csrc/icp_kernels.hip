@@ -295,8 +295,8 @@ __device__ void umeyama_from_sums(const double S[kNumSums], const double pivot[3
   T[15] = 1.0;
 }
 
-__device__ void icp_update_lane(IcpState *st) {
-  const double n = st->S[0];
+__device__ void icp_update_lane(IcpState *st, const double *S) {
+  const double n = S[0];
   st->n_corr = (long long)n;
   // icp_mod.hpp:232-240
   if ((long long)n < (long long)st->min_correspondences) {
@@ -306,7 +306,7 @@ __device__ void icp_update_lane(IcpState *st) {
     return;
   }
   double Tk[16];
-  umeyama_from_sums(st->S, st->pivot, Tk);
+  umeyama_from_sums(S, st->pivot, Tk);
   // transformation_ is a Matrix4f in the reference
   float Tf[16];
   for (int i = 0; i < 16; ++i) { Tf[i] = (float)Tk[i]; st->Tk[i] = (double)Tf[i]; }
@@ -338,7 +338,7 @@ __device__ void icp_update_lane(IcpState *st) {
     st->state = OPE_CONV_TRANSFORM;
     conv = 1;
   } else {
-    st->cur_mse = st->S[16] / n;
+    st->cur_mse = S[16] / n;
     const double diff = fabs(st->cur_mse - st->prev_mse);
     if (diff < st->mse_threshold_absolute) { st->state = OPE_CONV_ABS_MSE; conv = 1; }
     else if (diff / st->prev_mse < st->mse_threshold_relative) { st->state = OPE_CONV_REL_MSE; conv = 1; }
@@ -350,7 +350,7 @@ __device__ void icp_update_lane(IcpState *st) {
 
 // Fixed-order reduction of the block partials: 1024 threads, one per partial row.
 __global__ __launch_bounds__(kAccMaxBlocks) void icp_reduce_update_kernel(IcpState *st, const double *__restrict__ partials,
-                                                                            int nblocks, int do_update) {
+                                                                            double *S, int nblocks, int do_update) {
   if (st->done) return;
   __shared__ double s_red[kAccMaxBlocks / 64][kNumSums];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -364,17 +364,17 @@ __global__ __launch_bounds__(kAccMaxBlocks) void icp_reduce_update_kernel(IcpSta
   if (threadIdx.x < kNumSums) {
     double v = 0.0;
     for (int w = 0; w < kAccMaxBlocks / 64; ++w) v += s_red[w][threadIdx.x];
-    st->S[threadIdx.x] = v;
+    S[threadIdx.x] = v;
   }
   if (do_update) {
-    __syncthreads();
-    if (threadIdx.x == 0) icp_update_lane(st);
+    __syncthreads();  // S was written by this block's own lanes: block-level visibility is enough
+    if (threadIdx.x == 0) icp_update_lane(st, S);
   }
 }
 
-__global__ void icp_update_kernel(IcpState *st) {
+__global__ void icp_update_kernel(IcpState *st, const double *S) {
   if (st->done) return;
-  if (threadIdx.x == 0) icp_update_lane(st);
+  if (threadIdx.x == 0) icp_update_lane(st, S);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -479,13 +479,14 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
   }
 }
 
-void launch_icp_reduce_update(hipStream_t stream, IcpState *st, const double *partials, int nblocks, bool do_update) {
-  hipLaunchKernelGGL(icp_reduce_update_kernel, dim3(1), dim3(kAccMaxBlocks), 0, stream, st, partials, nblocks,
+void launch_icp_reduce_update(hipStream_t stream, IcpState *st, const double *partials, double *S, int nblocks,
+                              bool do_update) {
+  hipLaunchKernelGGL(icp_reduce_update_kernel, dim3(1), dim3(kAccMaxBlocks), 0, stream, st, partials, S, nblocks,
                      do_update ? 1 : 0);
 }
 
-void launch_icp_update(hipStream_t stream, IcpState *st) {
-  hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(64), 0, stream, st);
+void launch_icp_update(hipStream_t stream, IcpState *st, const double *S) {
+  hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(64), 0, stream, st, S);
 }
 
 void launch_nn_search(hipStream_t stream, const CloudView &q, const BvhView &tgt, const float *d_T, int32_t *out_idx,

@@ -80,6 +80,12 @@ struct ope_ctx {
   int acc_blocks = 0;
   int64_t n_src_total = 0, n_tgt_total = 0;
   int iters_enqueued = 0;
+  double *d_sums_ext = nullptr;   // caller-owned 17-double buffer (e.g. a torch tensor) or null
+
+  // optional per-launch timing of the accumulate kernel (HIP events on the launch stream)
+  bool prof_enabled = false;
+  std::vector<hipEvent_t> prof_events;
+  size_t prof_used = 0;
 
   // RCCL (dlopen'ed lazily)
   void *nccl_comm = nullptr;
