@@ -12,8 +12,8 @@ namespace ope {
 
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, const CloudView &, const BvhView &, const IcpState *, double *,
-                           int32_t *, float *);
-void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool);
+                           int32_t *, float *, uint32_t *);
+void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
 void launch_icp_update(hipStream_t, IcpState *, const double *);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
 void launch_knn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int, int32_t *, float *);
@@ -67,7 +67,7 @@ static int enqueue_accumulate(ope_ctx *ctx) {
   const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
   if (timed) OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], ctx->stream));
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, ctx->run_src->view(), ctx->run_tgt->view(),
-                        ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2);
+                        ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter);
   if (timed) {
     OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
     ++ctx->prof_used;
@@ -105,6 +105,7 @@ int ope_ctx_create(ope_ctx **out, int device_ordinal) {
   ctx->stream = ctx->own_stream;
   if (hipMalloc(&ctx->d_state, sizeof(IcpState)) != hipSuccess ||
       hipMalloc(&ctx->d_partials, sizeof(double) * kNumSums * kAccMaxBlocks) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_work_counter, 256) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState)) != hipSuccess) {
     ope_ctx_destroy(ctx);
     return set_err(nullptr, OPE_ENOMEM, "context allocation failed");
@@ -120,6 +121,7 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+  if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
   if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
   if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -282,8 +284,8 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
   std::memcpy(ix->bb_lo, target->bb_lo, sizeof ix->bb_lo);
   std::memcpy(ix->bb_hi, target->bb_hi, sizeof ix->bb_hi);
   for (int d = 0; d < 3; ++d) ix->pivot[d] = 0.5 * ((double)target->bb_lo[d] + (double)target->bb_hi[d]);
-  hipError_t e = hipMalloc((void **)&ix->d_boxes, sizeof(float) * hb.boxes.size());
-  if (e == hipSuccess) e = hipMemcpy(ix->d_boxes, hb.boxes.data(), sizeof(float) * hb.boxes.size(), hipMemcpyHostToDevice);
+  hipError_t e = hipMalloc((void **)&ix->d_nodes, sizeof(float) * hb.nodes.size());
+  if (e == hipSuccess) e = hipMemcpy(ix->d_nodes, hb.nodes.data(), sizeof(float) * hb.nodes.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void **)&ix->d_pts, sizeof(float4) * n);
   if (e == hipSuccess) e = hipMemcpy(ix->d_pts, hb.pts4.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
   if (e == hipSuccess && !hb.nrm4.empty()) {
@@ -301,7 +303,7 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
 void ope_index_free(ope_index *index) {
   if (!index) return;
   if (index->ctx) (void)hipSetDevice(index->ctx->device);
-  if (index->d_boxes) (void)hipFree(index->d_boxes);
+  if (index->d_nodes) (void)hipFree(index->d_nodes);
   if (index->d_pts) (void)hipFree(index->d_pts);
   if (index->d_nrm) (void)hipFree(index->d_nrm);
   delete index;
@@ -459,6 +461,7 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   h->use_surface_normal_rej = p.use_surface_normal_rej;
   h->use_self_occluded_rej = p.use_self_occluded_rej;
   OPE_HIP(ctx, hipMemcpyAsync(ctx->d_state, h, sizeof *h, hipMemcpyHostToDevice, ctx->stream));
+  OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 256, ctx->stream));
   // the pinned block is reused for read-back: make sure the upload is finished with it first
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
@@ -469,6 +472,7 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   ctx->iters_enqueued = 0;
   const int block = (p.corr_mode == OPE_CORR_NEAREST) ? kAccBlock : 256;
   ctx->acc_blocks = (int)std::min<size_t>(std::max<size_t>((src->n_valid + block - 1) / block, 1), kAccMaxBlocks);
+  if (const char *e = getenv("OPE_ACC_BLOCKS")) ctx->acc_blocks = std::max(1, std::min(atoi(e), (int)kAccMaxBlocks));
   if (ctx->n_src_total <= 0) ctx->n_src_total = (int64_t)src->n;
   if (ctx->n_tgt_total <= 0) ctx->n_tgt_total = (int64_t)tgt->n_total;
   return OPE_OK;
@@ -478,7 +482,7 @@ int ope_icp_accumulate(ope_ctx *ctx) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_accumulate: no run in progress");
   int rc = enqueue_accumulate(ctx);
   if (rc != OPE_OK) return rc;
-  launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, /*do_update=*/false);
+  launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, /*do_update=*/false, ctx->d_work_counter);
   OPE_HIP(ctx, hipGetLastError());
   return OPE_OK;
 }
@@ -501,12 +505,12 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
     int rc = enqueue_accumulate(ctx);
     if (rc != OPE_OK) return rc;
     if (sharded) {
-      launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false);
+      launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
       rc = comm_allreduce_sums(ctx, sums_ptr(ctx), kNumSums);
       if (rc != OPE_OK) return rc;
       launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx));
     } else {
-      launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, true);
+      launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, true, ctx->d_work_counter);
     }
   }
   ctx->iters_enqueued += n_iterations;

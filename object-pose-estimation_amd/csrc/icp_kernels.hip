@@ -15,6 +15,8 @@
 //       stays on the device; later launches of a batch early-out on it, so the host enqueues
 //       iterations back-to-back and polls only every `check_every` iterations.
 // Sharded (multi-GPU) runs split the second launch: reduce -> [all-reduce of S] -> update.
+#include <cstdlib>
+
 #include "bvh_traverse.hpp"
 
 namespace ope {
@@ -45,6 +47,7 @@ struct KnnVisitor {
     pos[j * stride] = i;
     if (count == k) worst = d[(k - 1) * stride];
   }
+  __device__ __forceinline__ void on_node() {}
 };
 
 constexpr int kKnnBlock = 256;
@@ -55,10 +58,12 @@ constexpr int kKnnMaxK = 32;
 template <int MODE, bool NRM>
 __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock) void icp_accumulate_kernel(
     CloudView src, BvhView tgt, const IcpState *__restrict__ st, double *__restrict__ partials,
-    int32_t *__restrict__ corr_match, float *__restrict__ corr_d2) {
+    int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter) {
   if (st->done) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   __shared__ double s_red[BLOCK / 64][kNumSums];
+  __shared__ float s_stk[kMaxDepth + 1][BLOCK];  // pending-sibling bounds of the traversal
+  float *stk = &s_stk[0][threadIdx.x];
   extern __shared__ unsigned char s_dyn[];  // MODE 1: k-NN lists
 
   float F[12];
@@ -77,15 +82,25 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock) void icp_accumul
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   int cnt = 0;
 
-  const uint32_t stride = gridDim.x * BLOCK;
-  for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < src.n_valid; i += stride) {
-    const float4 s = src.xyzw[i];
+  // Dynamic work distribution: query cost is very uneven (a clutter point far from the model walks
+  // 10-40x more nodes than a surface point), so each WAVE pulls the next 64-query chunk of the Morton
+  // order from a device-wide ticket counter (reset by the reduce kernel).  Which wave sums which chunk
+  // only changes the fp32 partial-sum grouping, i.e. the last bits of the fp64 totals.
+  const uint32_t lane_id = threadIdx.x & 63u;
+  for (;;) {
+    uint32_t ticket = 0;
+    if (lane_id == 0) ticket = atomicAdd(work_counter, 1u);
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket) * 64u;
+    if (base >= src.n_valid) break;
+    const uint32_t i = base + lane_id;
+    const bool active = i < src.n_valid;
+    const float4 s = src.xyzw[active ? i : base];
     const float x = xform_row(F + 0, s.x, s.y, s.z);
     const float y = xform_row(F + 4, s.x, s.y, s.z);
     const float z = xform_row(F + 8, s.x, s.y, s.z);
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (NRM) {
-      const float4 n4 = src.nrm[i];
+      const float4 n4 = src.nrm[active ? i : base];
       nx = rot_row(F + 0, n4.x, n4.y, n4.z);
       ny = rot_row(F + 4, n4.x, n4.y, n4.z);
       nz = rot_row(F + 8, n4.x, n4.y, n4.z);
@@ -95,17 +110,17 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock) void icp_accumul
     uint32_t pos = 0;
     int match = -1;
     if (MODE == 0) {
-      NearestVisitor v{INFINITY, -1, 0};
-      bvh_traverse(tgt, x, y, z, v);
-      ok = v.idx >= 0 && !((double)v.best > max_d2);
+      NearestVisitor v{active ? INFINITY : -INFINITY, -1, 0};
+      bvh_traverse(tgt, x, y, z, v, stk, BLOCK);
+      ok = active && v.idx >= 0 && !((double)v.best > max_d2);
       d2 = v.best;
       pos = v.pos;
       match = v.idx;
     } else {
       float *ld = reinterpret_cast<float *>(s_dyn) + threadIdx.x;
       uint32_t *lp = reinterpret_cast<uint32_t *>(s_dyn + sizeof(float) * BLOCK * kKnnMaxK) + threadIdx.x;
-      KnnVisitor v{ld, lp, BLOCK, kk, 0, INFINITY};
-      bvh_traverse(tgt, x, y, z, v);
+      KnnVisitor v{ld, lp, BLOCK, kk, 0, active ? INFINITY : -INFINITY};
+      bvh_traverse(tgt, x, y, z, v, stk, BLOCK);
       // among the k nearest, the one with the smallest squared distance to the line (s, n)
       // (…normal_shooting_weighted.hpp:115-135; cross product in double)
       double min_dist = 1.79769313486231570815e308;
@@ -120,7 +135,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock) void icp_accumul
         if (dist < min_dist) { min_dist = dist; min_j = j; }
       }
       // quirk Q2: squared line distance against the UNSQUARED max distance (:136)
-      ok = v.count > 0 && !(min_dist > max_dist_unsq);
+      ok = active && v.count > 0 && !(min_dist > max_dist_unsq);
       d2 = v.count > 0 ? ld[min_j * BLOCK] : INFINITY;
       pos = v.count > 0 ? lp[min_j * BLOCK] : 0;
       match = v.count > 0 ? __float_as_int(tgt.pts[pos].w) : -1;
@@ -135,8 +150,10 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock) void icp_accumul
       const double score = (double)nx * (-(double)x / sl) + (double)ny * (-(double)y / sl) + (double)nz * (-(double)z / sl);
       ok = score > thr_so;
     }
-    corr_match[i] = ok ? match : -1;
-    corr_d2[i] = d2;
+    if (active) {
+      corr_match[i] = ok ? match : -1;
+      corr_d2[i] = d2;
+    }
     if (ok) {
       const float4 t = tgt.pts[pos];
       const float sx = x - psx, sy = y - psy, sz = z - psz;
@@ -350,8 +367,10 @@ __device__ void icp_update_lane(IcpState *st, const double *S) {
 
 // Fixed-order reduction of the block partials: 1024 threads, one per partial row.
 __global__ __launch_bounds__(kAccMaxBlocks) void icp_reduce_update_kernel(IcpState *st, const double *__restrict__ partials,
-                                                                            double *S, int nblocks, int do_update) {
+                                                                            double *S, int nblocks, int do_update,
+                                                                            uint32_t *work_counter) {
   if (st->done) return;
+  if (threadIdx.x == 0) *work_counter = 0u;  // ticket counter of the next accumulate launch
   __shared__ double s_red[kAccMaxBlocks / 64][kNumSums];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -382,22 +401,28 @@ __global__ void icp_update_kernel(IcpState *st, const double *S) {
 __global__ __launch_bounds__(256) void nn_search_kernel(CloudView q, BvhView tgt, const float *__restrict__ T,
                                                          int has_T, int32_t *__restrict__ out_idx,
                                                          float *__restrict__ out_d2) {
+  __shared__ float s_stk[kMaxDepth + 1][256];
+  float *stk = &s_stk[0][threadIdx.x];
   float F[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) F[i] = has_T ? T[i] : ((i % 5 == 0) ? 1.f : 0.f);
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < q.n; i += gridDim.x * 256) {
-    if (i >= q.n_valid) { out_idx[i] = -1; out_d2[i] = INFINITY; continue; }
-    const float4 s = q.xyzw[i];
+  const uint32_t lane_id = threadIdx.x & 63u;
+  for (uint32_t base = blockIdx.x * 256 + (threadIdx.x & ~63u); base < q.n; base += gridDim.x * 256) {
+    const uint32_t i = base + lane_id;
+    const bool active = i < q.n_valid;
+    const float4 s = q.xyzw[active ? i : 0];
     float x = s.x, y = s.y, z = s.z;
     if (has_T) {
       x = xform_row(F + 0, s.x, s.y, s.z);
       y = xform_row(F + 4, s.x, s.y, s.z);
       z = xform_row(F + 8, s.x, s.y, s.z);
     }
-    NearestVisitor v{INFINITY, -1, 0};
-    bvh_traverse(tgt, x, y, z, v);
-    out_idx[i] = v.idx;
-    out_d2[i] = v.best;
+    NearestVisitor v{active ? INFINITY : -INFINITY, -1, 0};
+    if (active) bvh_traverse(tgt, x, y, z, v, stk, 256);
+    if (i < q.n) {
+      out_idx[i] = active ? v.idx : -1;
+      out_d2[i] = active ? v.best : INFINITY;
+    }
   }
 }
 
@@ -407,27 +432,30 @@ __global__ __launch_bounds__(kKnnBlock) void knn_search_kernel(CloudView q, BvhV
   extern __shared__ unsigned char s_dyn[];
   float *ld = reinterpret_cast<float *>(s_dyn) + threadIdx.x;
   uint32_t *lp = reinterpret_cast<uint32_t *>(s_dyn + sizeof(float) * kKnnBlock * kKnnMaxK) + threadIdx.x;
+  __shared__ float s_stk[kMaxDepth + 1][kKnnBlock];
+  float *stk = &s_stk[0][threadIdx.x];
   float F[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) F[i] = has_T ? T[i] : ((i % 5 == 0) ? 1.f : 0.f);
-  for (uint32_t i = blockIdx.x * kKnnBlock + threadIdx.x; i < q.n; i += gridDim.x * kKnnBlock) {
-    int count = 0;
-    if (i < q.n_valid) {
-      const float4 s = q.xyzw[i];
-      float x = s.x, y = s.y, z = s.z;
-      if (has_T) {
-        x = xform_row(F + 0, s.x, s.y, s.z);
-        y = xform_row(F + 4, s.x, s.y, s.z);
-        z = xform_row(F + 8, s.x, s.y, s.z);
-      }
-      KnnVisitor v{ld, lp, kKnnBlock, k, 0, INFINITY};
-      bvh_traverse(tgt, x, y, z, v);
-      count = v.count;
+  const uint32_t lane_id = threadIdx.x & 63u;
+  for (uint32_t base = blockIdx.x * kKnnBlock + (threadIdx.x & ~63u); base < q.n; base += gridDim.x * kKnnBlock) {
+    const uint32_t i = base + lane_id;
+    const bool active = i < q.n_valid;
+    const float4 s = q.xyzw[active ? i : 0];
+    float x = s.x, y = s.y, z = s.z;
+    if (has_T) {
+      x = xform_row(F + 0, s.x, s.y, s.z);
+      y = xform_row(F + 4, s.x, s.y, s.z);
+      z = xform_row(F + 8, s.x, s.y, s.z);
     }
-    for (int j = 0; j < k; ++j) {
-      const bool have = j < count;
-      out_idx[(size_t)i * k + j] = have ? __float_as_int(tgt.pts[lp[j * kKnnBlock]].w) : -1;
-      out_d2[(size_t)i * k + j] = have ? ld[j * kKnnBlock] : INFINITY;
+    KnnVisitor v{ld, lp, kKnnBlock, k, 0, active ? INFINITY : -INFINITY};
+    if (active) bvh_traverse(tgt, x, y, z, v, stk, kKnnBlock);
+    if (i < q.n) {
+      for (int j = 0; j < k; ++j) {
+        const bool have = j < v.count;
+        out_idx[(size_t)i * k + j] = have ? __float_as_int(tgt.pts[lp[j * kKnnBlock]].w) : -1;
+        out_d2[(size_t)i * k + j] = have ? ld[j * kKnnBlock] : INFINITY;
+      }
     }
   }
 }
@@ -436,18 +464,23 @@ __global__ __launch_bounds__(kKnnBlock) void knn_search_kernel(CloudView q, BvhV
 __global__ __launch_bounds__(256) void fitness_kernel(CloudView q, BvhView tgt, const float *__restrict__ T,
                                                        double max_range, double *__restrict__ partials) {
   __shared__ double s_red[4][2];
+  __shared__ float s_stk[kMaxDepth + 1][256];
+  float *stk = &s_stk[0][threadIdx.x];
   float F[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) F[i] = T[i];
   double sum = 0.0, cnt = 0.0;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < q.n_valid; i += gridDim.x * 256) {
-    const float4 s = q.xyzw[i];
+  const uint32_t lane_id = threadIdx.x & 63u;
+  for (uint32_t base = blockIdx.x * 256 + (threadIdx.x & ~63u); base < q.n_valid; base += gridDim.x * 256) {
+    const uint32_t i = base + lane_id;
+    const bool active = i < q.n_valid;
+    const float4 s = q.xyzw[active ? i : base];
     const float x = xform_row(F + 0, s.x, s.y, s.z);
     const float y = xform_row(F + 4, s.x, s.y, s.z);
     const float z = xform_row(F + 8, s.x, s.y, s.z);
-    NearestVisitor v{INFINITY, -1, 0};
-    bvh_traverse(tgt, x, y, z, v);
-    if (v.idx >= 0 && (double)v.best <= max_range) { sum += (double)v.best; cnt += 1.0; }
+    NearestVisitor v{active ? INFINITY : -INFINITY, -1, 0};
+    if (active) bvh_traverse(tgt, x, y, z, v, stk, 256);
+    if (active && v.idx >= 0 && (double)v.best <= max_range) { sum += (double)v.best; cnt += 1.0; }
   }
   sum = wave_sum(sum);
   cnt = wave_sum(cnt);
@@ -464,25 +497,25 @@ __global__ __launch_bounds__(256) void fitness_kernel(CloudView q, BvhView tgt, 
 // host launchers (called from api.hip)
 void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, const CloudView &src,
                            const BvhView &tgt, const IcpState *st, double *partials, int32_t *corr_match,
-                           float *corr_d2) {
+                           float *corr_d2, uint32_t *work_counter) {
   if (mode == 0) {
     if (nrm)
       hipLaunchKernelGGL((icp_accumulate_kernel<0, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, st,
-                         partials, corr_match, corr_d2);
+                         partials, corr_match, corr_d2, work_counter);
     else
       hipLaunchKernelGGL((icp_accumulate_kernel<0, false>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, st,
-                         partials, corr_match, corr_d2);
+                         partials, corr_match, corr_d2, work_counter);
   } else {
     const size_t lds = (sizeof(float) + sizeof(uint32_t)) * kKnnBlock * kKnnMaxK;
     hipLaunchKernelGGL((icp_accumulate_kernel<1, true>), dim3(nblocks), dim3(kKnnBlock), lds, stream, src, tgt, st,
-                       partials, corr_match, corr_d2);
+                       partials, corr_match, corr_d2, work_counter);
   }
 }
 
 void launch_icp_reduce_update(hipStream_t stream, IcpState *st, const double *partials, double *S, int nblocks,
-                              bool do_update) {
+                              bool do_update, uint32_t *work_counter) {
   hipLaunchKernelGGL(icp_reduce_update_kernel, dim3(1), dim3(kAccMaxBlocks), 0, stream, st, partials, S, nblocks,
-                     do_update ? 1 : 0);
+                     do_update ? 1 : 0, work_counter);
 }
 
 void launch_icp_update(hipStream_t stream, IcpState *st, const double *S) {
@@ -510,3 +543,57 @@ void launch_fitness(hipStream_t stream, int nblocks, const CloudView &q, const B
 }
 
 }  // namespace ope
+
+// ------------------------------------------------------------------------------------------
+// Developer instrumentation (tools/visit_stats.py): per-query node / leaf-point visit counts of the
+// private per-lane traversal.  Not part of include/ope.h.
+namespace ope {
+struct CountingVisitor {
+  float best;
+  int idx;
+  int points, nodes;
+  __device__ __forceinline__ bool prune(float bound) const { return !(bound < best); }
+  __device__ __forceinline__ void point(float d, const float4 &p, uint32_t) {
+    ++points;
+    if (d < best) { best = d; idx = __float_as_int(p.w); }
+  }
+  __device__ __forceinline__ void on_node() { ++nodes; }
+};
+
+__global__ __launch_bounds__(256) void debug_visit_kernel(CloudView q, BvhView t, const float *__restrict__ T,
+                                                           int32_t *nodes_out, int32_t *points_out) {
+  __shared__ float s_stk[kMaxDepth + 1][256];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= q.n_valid) return;
+  const float4 s = q.xyzw[i];
+  const float qx = xform_row(T + 0, s.x, s.y, s.z), qy = xform_row(T + 4, s.x, s.y, s.z), qz = xform_row(T + 8, s.x, s.y, s.z);
+  CountingVisitor v{INFINITY, -1, 0, 0};
+  bvh_traverse(t, qx, qy, qz, v, &s_stk[0][threadIdx.x], 256);
+  nodes_out[i] = v.nodes;
+  points_out[i] = v.points;
+}
+}  // namespace ope
+
+extern "C" int ope_debug_visit_counts(ope_ctx *ctx, const ope_cloud *q, const ope_index *ix, const float *T_colmajor,
+                                      int32_t *nodes, int32_t *points) {
+  using namespace ope;
+  const size_t n = q->n_valid;
+  int32_t *d_n, *d_p;
+  float *d_T;
+  float rows[12];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) rows[4 * r + c] = T_colmajor[4 * c + r];
+  OPE_HIP(ctx, hipMalloc((void **)&d_n, 4 * n));
+  OPE_HIP(ctx, hipMalloc((void **)&d_p, 4 * n));
+  OPE_HIP(ctx, hipMalloc((void **)&d_T, sizeof rows));
+  OPE_HIP(ctx, hipMemcpy(d_T, rows, sizeof rows, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(debug_visit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, q->view(), ix->view(),
+                     d_T, d_n, d_p);
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<int32_t> hn(n), hp(n);
+  OPE_HIP(ctx, hipMemcpy(hn.data(), d_n, 4 * n, hipMemcpyDeviceToHost));
+  OPE_HIP(ctx, hipMemcpy(hp.data(), d_p, 4 * n, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) { nodes[q->perm[i]] = hn[i]; points[q->perm[i]] = hp[i]; }
+  (void)hipFree(d_n); (void)hipFree(d_p); (void)hipFree(d_T);
+  return OPE_OK;
+}

@@ -13,18 +13,23 @@ namespace ope {
 
 // ---------------------------------------------------------------------------
 // Device-side view of the target search index: an implicit, perfectly balanced
-// binary BVH.  Node ids are heap indices (root 1, children 2i / 2i+1); nodes at
-// depth D (ids 2^D … 2^(D+1)-1) are leaf buckets.  Leaf j owns the contiguous
-// point range [j*n >> D, (j+1)*n >> D) of `pts`.  boxes[6*id .. 6*id+5] is the
-// TIGHT fp32 AABB {lo.xyz, hi.xyz} of the subtree, so the two children of node i
-// are 48 contiguous, 16-byte aligned bytes at boxes + 12*i.
+// binary tree of ORIENTED bounding boxes.  Node ids are heap indices (root 1,
+// children 2i / 2i+1); nodes at depth D (ids 2^D … 2^(D+1)-1) are leaf buckets.
+// Leaf j owns the contiguous point range [j*n >> D, (j+1)*n >> D) of `pts`.
+// A node is 3 float4 (48 B):  {c.xyz, h0} {a0.xyz, h1} {a1.xyz, h2}
+//   c = box centre, a0/a1 = two unit axes (the third is a0 x a1), h = half extents
+//   (already inflated by the build-time rounding margin).
+// The two children of node i are 96 contiguous bytes at nodes + 6*i float4.
 // ---------------------------------------------------------------------------
+constexpr int kNodeFloats = 12;
+constexpr int kMaxDepth = 18;  // one pending-bound LDS slot per level and lane
+
 struct BvhView {
-  const float *boxes;   // (2^(D+1)) * 6 floats
+  const float4 *nodes;  // (2^(D+1)) * 3 float4
   const float4 *pts;    // n points, w = ORIGINAL index (int bits)
   const float4 *nrm;    // optional normals in the same order (xyz, w = curvature)
   uint32_t n;
-  int depth;            // D
+  int depth;            // D <= kMaxDepth
 };
 
 // Device-side view of a (Morton-sorted) query cloud.
@@ -69,6 +74,7 @@ struct ope_ctx {
   // ICP run state
   ope::IcpState *d_state = nullptr;
   double *d_partials = nullptr;   // [kNumSums][kAccMaxBlocks]
+  uint32_t *d_work_counter = nullptr;  // ticket counter of the accumulate kernel's dynamic work queue
   int32_t *d_corr_match = nullptr;  // per sorted query: ORIGINAL target index or -1
   float *d_corr_d2 = nullptr;
   size_t corr_cap = 0;
@@ -114,12 +120,12 @@ struct ope_index {
   size_t n = 0;        // indexed (finite) points
   size_t n_total = 0;  // size of the target cloud it was built from
   int depth = 0;
-  float *d_boxes = nullptr;
+  float4 *d_nodes = nullptr;
   float4 *d_pts = nullptr;
   float4 *d_nrm = nullptr;
   double pivot[3] = {0, 0, 0};
   float bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
-  ope::BvhView view() const { return ope::BvhView{d_boxes, d_pts, d_nrm, (uint32_t)n, depth}; }
+  ope::BvhView view() const { return ope::BvhView{d_nodes, d_pts, d_nrm, (uint32_t)n, depth}; }
 };
 
 namespace ope {
@@ -137,7 +143,7 @@ int set_err(ope_ctx *ctx, int code, const std::string &msg);
 // indices, nrm optional n*3.  Outputs host arrays ready for upload.
 struct HostBvh {
   int depth = 0;
-  std::vector<float> boxes;   // (2^(D+1))*6
+  std::vector<float> nodes;   // (2^(D+1))*kNodeFloats
   std::vector<float> pts4;    // n*4 (x,y,z, original index bits)
   std::vector<float> nrm4;    // n*4 or empty
 };
