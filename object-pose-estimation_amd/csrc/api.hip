@@ -12,7 +12,7 @@ namespace ope {
 
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, const CloudView &, const BvhView &, const IcpState *, double *,
-                           int32_t *, float *, uint32_t *);
+                           int32_t *, float *, uint32_t *, uint32_t *);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
 void launch_icp_update(hipStream_t, IcpState *, const double *);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
@@ -67,7 +67,7 @@ static int enqueue_accumulate(ope_ctx *ctx) {
   const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
   if (timed) OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], ctx->stream));
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, ctx->run_src->view(), ctx->run_tgt->view(),
-                        ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter);
+                        ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint);
   if (timed) {
     OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
     ++ctx->prof_used;
@@ -124,6 +124,7 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
   if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
   if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
+  if (ctx->d_hint) (void)hipFree(ctx->d_hint);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->h_state) (void)hipHostFree(ctx->h_state);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -428,13 +429,17 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   if (ctx->corr_cap < src->n) {
     if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
     if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
-    ctx->d_corr_match = nullptr; ctx->d_corr_d2 = nullptr; ctx->corr_cap = 0;
+    if (ctx->d_hint) (void)hipFree(ctx->d_hint);
+    ctx->d_corr_match = nullptr; ctx->d_corr_d2 = nullptr; ctx->d_hint = nullptr; ctx->corr_cap = 0;
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_corr_match, sizeof(int32_t) * std::max<size_t>(src->n, 1)));
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_corr_d2, sizeof(float) * std::max<size_t>(src->n, 1)));
+    OPE_HIP(ctx, hipMalloc((void **)&ctx->d_hint, sizeof(uint32_t) * std::max<size_t>(src->n, 1)));
     ctx->corr_cap = std::max<size_t>(src->n, 1);
   }
   // every slot starts as "no correspondence" (non-finite points never get written)
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_corr_match, 0xff, sizeof(int32_t) * std::max<size_t>(src->n, 1), ctx->stream));
+  // no start hints yet: the first iteration walks top-down (hints belong to one (src, tgt) pairing)
+  OPE_HIP(ctx, hipMemsetAsync(ctx->d_hint, 0, sizeof(uint32_t) * std::max<size_t>(src->n, 1), ctx->stream));
 
   IcpState *h = ctx->h_state;
   std::memset(h, 0, sizeof *h);
@@ -462,6 +467,8 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   h->use_self_occluded_rej = p.use_self_occluded_rej;
   OPE_HIP(ctx, hipMemcpyAsync(ctx->d_state, h, sizeof *h, hipMemcpyHostToDevice, ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 256, ctx->stream));
+  // partial-sum rows of blocks that do not exist in this run must read as zero
+  OPE_HIP(ctx, hipMemsetAsync(ctx->d_partials, 0, sizeof(double) * kNumSums * kAccMaxBlocks, ctx->stream));
   // the pinned block is reused for read-back: make sure the upload is finished with it first
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
@@ -501,6 +508,7 @@ int ope_icp_set_sums_buffer(ope_ctx *ctx, void *device_ptr) {
 int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_iterate: no run in progress");
   const bool sharded = ctx->nccl_comm != nullptr && ctx->comm_nranks > 1;
+  static const bool split_update = getenv("OPE_SPLIT_UPDATE") != nullptr;  // developer A/B switch
   for (int b = 0; b < n_iterations; ++b) {
     int rc = enqueue_accumulate(ctx);
     if (rc != OPE_OK) return rc;
@@ -508,6 +516,9 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
       launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
       rc = comm_allreduce_sums(ctx, sums_ptr(ctx), kNumSums);
       if (rc != OPE_OK) return rc;
+      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx));
+    } else if (split_update) {
+      launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
       launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx));
     } else {
       launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, true, ctx->d_work_counter);

@@ -22,13 +22,17 @@
 
 namespace ope {
 
+// Native 16-byte vector: a load through this type is ONE global_load_dwordx4 (loads through HIP's
+// float4 struct were split into odd 4/8/12-byte pieces by the load vectoriser).
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f ld16(const float4 *p) { return *reinterpret_cast<const v4f *>(p); }
+
 __device__ __forceinline__ float sq_dist3(float dx, float dy, float dz) {
   return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
 // squared distance lower bound from q to the oriented box {n0, n1, n2} (see BvhView)
-__device__ __forceinline__ float obb_dist2(const float4 n0, const float4 n1, const float4 n2, float qx, float qy,
-                                           float qz) {
+__device__ __forceinline__ float obb_dist2(const v4f n0, const v4f n1, const v4f n2, float qx, float qy, float qz) {
   const float dx = qx - n0.x, dy = qy - n0.y, dz = qz - n0.z;
   const float a2x = n1.y * n2.z - n1.z * n2.y;
   const float a2y = n1.z * n2.x - n1.x * n2.z;
@@ -40,22 +44,36 @@ __device__ __forceinline__ float obb_dist2(const float4 n0, const float4 n1, con
 }
 
 // Visitor concept:
-//   bool prune(float bound) const                      -> subtree with this lower bound can be skipped
-//   void point(float d2, const float4& p, uint32_t pos) -> candidate at reordered position pos
-//   void on_node()                                      -> instrumentation hook (empty in product visitors)
+//   bool prune(float bound) const                                    -> subtree with this lower bound can be skipped
+//   void point(float d2, uint32_t pos, uint32_t leaf)                 -> candidate at reordered position pos (may repeat)
+//   void on_node()                                                    -> instrumentation hook (empty in product visitors)
 // `stk` points at this lane's slot of an LDS array float[kMaxDepth + 1][stk_stride].
+//
+// start_leaf == 0: classic top-down walk from the root.
+// start_leaf != 0 (heap id of a leaf, e.g. the leaf that held this query's nearest neighbour in the
+// previous ICP iteration): the walk starts by scanning that leaf, which usually yields the final
+// best at once, and then backs up the ancestor chain testing ONE box per level (the sibling's own
+// 48 bytes, "unknown bound" bit set) instead of descending through the 96-byte child pairs of all
+// D levels; only siblings that beat the current best are expanded.  Same exact result, about a
+// third of the memory instructions in ICP's steady state.
 template <class Visitor>
 __device__ __forceinline__ void bvh_traverse(const BvhView &t, float qx, float qy, float qz, Visitor &v, float *stk,
-                                             int stk_stride) {
+                                             int stk_stride, uint32_t start_leaf = 0) {
   const uint32_t leaf0 = 1u << t.depth;
   uint32_t node = 1;
-  uint32_t trail = 0;
-  if (v.prune(obb_dist2(t.nodes[3], t.nodes[4], t.nodes[5], qx, qy, qz))) return;
+  uint32_t trail = 0;  // bit k: the sibling of the k-th ancestor (bit 0: of `node` itself) is pending
+  uint32_t unk = 0;    // same indexing: that pending sibling's bound has not been evaluated yet
+  if (start_leaf != 0) {
+    node = start_leaf;
+    trail = unk = leaf0 - 1u;
+  } else if (v.prune(obb_dist2(ld16(t.nodes + 3), ld16(t.nodes + 4), ld16(t.nodes + 5), qx, qy, qz))) {
+    return;
+  }
   for (;;) {
     if (node < leaf0) {
       v.on_node();
       const float4 *c = t.nodes + 6 * (size_t)node;
-      const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+      const v4f c0 = ld16(c), c1 = ld16(c + 1), c2 = ld16(c + 2), c3 = ld16(c + 3), c4 = ld16(c + 4), c5 = ld16(c + 5);
       const float d0 = obb_dist2(c0, c1, c2, qx, qy, qz);
       const float d1 = obb_dist2(c3, c4, c5, qx, qy, qz);
       const bool right = d1 < d0;
@@ -65,6 +83,7 @@ __device__ __forceinline__ void bvh_traverse(const BvhView &t, float qx, float q
         node = 2 * node + (right ? 1u : 0u);
         const bool pend = !v.prune(df);
         trail = (trail << 1) | (pend ? 1u : 0u);
+        unk <<= 1;
         if (pend) stk[(31 - __clz(node)) * stk_stride] = df;
         continue;
       }
@@ -72,31 +91,47 @@ __device__ __forceinline__ void bvh_traverse(const BvhView &t, float qx, float q
       const uint32_t j = node - leaf0;
       const uint32_t s = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
       const uint32_t e = (uint32_t)(((unsigned long long)(j + 1) * t.n) >> t.depth);
-#pragma unroll 4
-      for (uint32_t i = s; i < e; ++i) {
-        const float4 p = t.pts[i];
-        const float d = sq_dist3(__fsub_rn(qx, p.x), __fsub_rn(qy, p.y), __fsub_rn(qz, p.z));
-        v.point(d, p, i);
+      // four independent 16-byte loads in flight per batch (indices clamped to the leaf: a repeated
+      // point cannot win again under the strict <)
+      for (uint32_t i = s; i < e; i += 4) {
+        const uint32_t i1 = min(i + 1, e - 1), i2 = min(i + 2, e - 1), i3 = min(i + 3, e - 1);
+        const v4f p0 = ld16(t.pts + i), p1 = ld16(t.pts + i1), p2 = ld16(t.pts + i2), p3 = ld16(t.pts + i3);
+        v.point(sq_dist3(__fsub_rn(qx, p0.x), __fsub_rn(qy, p0.y), __fsub_rn(qz, p0.z)), i, node);
+        v.point(sq_dist3(__fsub_rn(qx, p1.x), __fsub_rn(qy, p1.y), __fsub_rn(qz, p1.z)), i1, node);
+        v.point(sq_dist3(__fsub_rn(qx, p2.x), __fsub_rn(qy, p2.y), __fsub_rn(qz, p2.z)), i2, node);
+        v.point(sq_dist3(__fsub_rn(qx, p3.x), __fsub_rn(qy, p3.y), __fsub_rn(qz, p3.z)), i3, node);
       }
     }
-    // back up to the deepest pending sibling whose parked bound still beats the current best
+    // back up to the deepest pending sibling whose bound still beats the current best
     for (;;) {
       if (trail == 0) return;
       const int k = __builtin_ctz(trail);
       node = (node >> k) ^ 1u;
       trail = (trail >> k) & ~1u;
-      if (!v.prune(stk[(31 - __clz(node)) * stk_stride])) break;
+      unk >>= k;
+      float b;
+      if (unk & 1u) {
+        v.on_node();
+        const float4 *o = t.nodes + 3 * (size_t)node;
+        b = obb_dist2(ld16(o), ld16(o + 1), ld16(o + 2), qx, qy, qz);
+        unk &= ~1u;
+      } else {
+        b = stk[(31 - __clz(node)) * stk_stride];
+      }
+      if (!v.prune(b)) break;
     }
   }
 }
 
+constexpr uint32_t kNoPos = 0xffffffffu;
+
 struct NearestVisitor {
   float best;
-  int idx;  // ORIGINAL target index
-  uint32_t pos;
+  uint32_t pos;   // reordered target position of the best point, kNoPos if none
+  uint32_t leaf;  // heap id of the leaf that holds it (next iteration's start hint)
   __device__ __forceinline__ bool prune(float bound) const { return !(bound < best); }
-  __device__ __forceinline__ void point(float d, const float4 &p, uint32_t i) {
-    if (d < best) { best = d; idx = __float_as_int(p.w); pos = i; }
+  __device__ __forceinline__ void point(float d, uint32_t i, uint32_t lf) {
+    if (d < best) { best = d; pos = i; leaf = lf; }
   }
   __device__ __forceinline__ void on_node() {}
 };

@@ -28,6 +28,12 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 // k-nearest list of one lane, kept in LDS with a per-thread stride (bank-conflict free).
 struct KnnVisitor {
   float *d;       // &lds_d[threadIdx.x], element j at d[j*stride]
@@ -35,8 +41,10 @@ struct KnnVisitor {
   int stride, k, count;
   float worst;
   __device__ __forceinline__ bool prune(float bound) const { return !(bound < worst); }
-  __device__ __forceinline__ void point(float dist, const float4 &, uint32_t i) {
+  __device__ __forceinline__ void point(float dist, uint32_t i, uint32_t) {
     if (!(dist < worst)) return;
+    for (int j = 0; j < count; ++j)
+      if (pos[j * stride] == i) return;  // the clamped leaf scan may present a point twice
     int j = (count < k) ? count++ : k - 1;
     while (j > 0 && d[(j - 1) * stride] > dist) {
       d[j * stride] = d[(j - 1) * stride];
@@ -56,9 +64,10 @@ constexpr int kKnnMaxK = 32;
 // MODE 0: 1-NN correspondences.  MODE 1: normal shooting over the k nearest.
 // NRM: source/target normals present (rejectors and/or normal shooting).
 template <int MODE, bool NRM>
-__global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock) void icp_accumulate_kernel(
+__global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 4) void icp_accumulate_kernel(
     CloudView src, BvhView tgt, const IcpState *__restrict__ st, double *__restrict__ partials,
-    int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter) {
+    int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
+    uint32_t *__restrict__ hint) {
   if (st->done) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   __shared__ double s_red[BLOCK / 64][kNumSums];
@@ -77,10 +86,10 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock) void icp_accumul
   const double max_dist_unsq = st->max_corr_dist;
   const int kk = st->k_normal_shooting;
 
-  float acc[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  int cnt = 0;
+  // Running sums: lane k (k < 17) of each wave owns component k of {n, Σs, Σt, Σ t sᵀ, Σd²}.  The 17
+  // per-lane terms of a chunk are wave-reduced right away (fp32 butterflies, fixed order), so only
+  // this one fp64 register stays live across the traversal instead of 17 accumulators.
+  double tot = 0.0;
 
   // Dynamic work distribution: query cost is very uneven (a clutter point far from the model walks
   // 10-40x more nodes than a surface point), so each WAVE pulls the next 64-query chunk of the Morton
@@ -110,12 +119,15 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock) void icp_accumul
     uint32_t pos = 0;
     int match = -1;
     if (MODE == 0) {
-      NearestVisitor v{active ? INFINITY : -INFINITY, -1, 0};
-      bvh_traverse(tgt, x, y, z, v, stk, BLOCK);
-      ok = active && v.idx >= 0 && !((double)v.best > max_d2);
+      NearestVisitor v{active ? INFINITY : -INFINITY, kNoPos, 0};
+      // start at the leaf that held this query's nearest neighbour one iteration ago (0 = none yet)
+      if (active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, hint[i]);
+      if (active) hint[i] = v.leaf;
+      const bool found = active && v.pos != kNoPos;
+      ok = found && !((double)v.best > max_d2);
       d2 = v.best;
-      pos = v.pos;
-      match = v.idx;
+      pos = found ? v.pos : 0;
+      match = found ? __float_as_int(tgt.pts[pos].w) : -1;
     } else {
       float *ld = reinterpret_cast<float *>(s_dyn) + threadIdx.x;
       uint32_t *lp = reinterpret_cast<uint32_t *>(s_dyn + sizeof(float) * BLOCK * kKnnMaxK) + threadIdx.x;
@@ -154,29 +166,30 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock) void icp_accumul
       corr_match[i] = ok ? match : -1;
       corr_d2[i] = d2;
     }
-    if (ok) {
-      const float4 t = tgt.pts[pos];
-      const float sx = x - psx, sy = y - psy, sz = z - psz;
-      const float tx = t.x - psx, ty = t.y - psy, tz = t.z - psz;
-      ++cnt;
-      acc[0] += sx; acc[1] += sy; acc[2] += sz;
-      acc[3] += tx; acc[4] += ty; acc[5] += tz;
-      acc[6] += tx * sx; acc[7] += tx * sy; acc[8] += tx * sz;
-      acc[9] += ty * sx; acc[10] += ty * sy; acc[11] += ty * sz;
-      acc[12] += tz * sx; acc[13] += tz * sy; acc[14] += tz * sz;
-      acc[15] += d2;
+    {
+      const float4 t = tgt.pts[ok ? pos : 0];
+      const float w = ok ? 1.f : 0.f;
+      const float sx = w * (x - psx), sy = w * (y - psy), sz = w * (z - psz);
+      const float tx = w * (t.x - psx), ty = w * (t.y - psy), tz = w * (t.z - psz);
+      float term[kNumSums];
+      term[0] = w;
+      term[1] = sx; term[2] = sy; term[3] = sz;
+      term[4] = tx; term[5] = ty; term[6] = tz;
+      term[7] = tx * sx; term[8] = tx * sy; term[9] = tx * sz;
+      term[10] = ty * sx; term[11] = ty * sy; term[12] = ty * sz;
+      term[13] = tz * sx; term[14] = tz * sy; term[15] = tz * sz;
+      term[16] = ok ? d2 : 0.f;
+#pragma unroll
+      for (int k = 0; k < kNumSums; ++k) {
+        const float r = wave_sum_f32(term[k]);
+        if (lane_id == (uint32_t)k) tot += (double)r;
+      }
     }
   }
 
   // wave -> block reduction in fp64, fixed order
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double v0 = wave_sum((double)cnt);
-  if (lane == 0) s_red[wave][0] = v0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const double v = wave_sum((double)acc[k]);
-    if (lane == 0) s_red[wave][k + 1] = v;
-  }
+  const int wave = threadIdx.x >> 6;
+  if (lane_id < (uint32_t)kNumSums) s_red[wave][lane_id] = tot;
   __syncthreads();
   if (threadIdx.x < kNumSums) {
     double v = 0.0;
@@ -188,110 +201,162 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock) void icp_accumul
 
 // ------------------------------------------------------------------------------------------
 // fp64 3x3 helpers for the update step (one lane)
-__device__ void jacobi_eig3(double S[9], double V[9]) {
-  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    const double off = fabs(S[1]) + fabs(S[2]) + fabs(S[5]);
-    const double diag = fabs(S[0]) + fabs(S[4]) + fabs(S[8]);
-    if (off <= 1e-300 || off <= 1e-17 * diag) break;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        const double apq = S[3 * p + q];
-        if (apq == 0.0) continue;
-        const double theta = (S[3 * q + q] - S[3 * p + p]) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 3; ++k) {
-          const double a = S[3 * k + p], b = S[3 * k + q];
-          S[3 * k + p] = c * a - s * b;
-          S[3 * k + q] = s * a + c * b;
-        }
-        for (int k = 0; k < 3; ++k) {
-          const double a = S[3 * p + k], b = S[3 * q + k];
-          S[3 * p + k] = c * a - s * b;
-          S[3 * q + k] = s * a + c * b;
-        }
-        for (int k = 0; k < 3; ++k) {
-          const double a = V[3 * k + p], b = V[3 * k + q];
-          V[3 * k + p] = c * a - s * b;
-          V[3 * k + q] = s * a + c * b;
-        }
-      }
+// The update is a serial tail of every iteration, so its fp64 divisions / square roots use the
+// hardware seed (v_rcp_f64 / v_rsq_f64) plus Newton steps instead of the ~40-instruction IEEE
+// sequences: ~1e-16 relative error, 22 us -> a few us per iteration.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+__device__ __forceinline__ double fast_sqrt(double x) { return x > 0.0 ? x * fast_rsqrt(x) : 0.0; }
+// All indices below are compile-time constants after unrolling, so the 3x3 work stays in registers
+// (a first version with run-time indices put 368 bytes per lane in scratch and took ~18 us).
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rotate(double (&S)[9], double (&V)[9]) {
+  const double apq = S[3 * P + Q];
+  if (apq == 0.0) return;
+  const double theta = (S[3 * Q + Q] - S[3 * P + P]) * fast_rcp(2.0 * apq);
+  const double t = (theta >= 0 ? 1.0 : -1.0) * fast_rcp(fabs(theta) + fast_sqrt(theta * theta + 1.0));
+  const double c = fast_rsqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double a = S[3 * k + P], b = S[3 * k + Q];
+    S[3 * k + P] = c * a - s * b;
+    S[3 * k + Q] = s * a + c * b;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double a = S[3 * P + k], b = S[3 * Q + k];
+    S[3 * P + k] = c * a - s * b;
+    S[3 * Q + k] = s * a + c * b;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double a = V[3 * k + P], b = V[3 * k + Q];
+    V[3 * k + P] = c * a - s * b;
+    V[3 * k + Q] = s * a + c * b;
   }
 }
 
-__device__ double det3(const double M[9]) {
+__device__ __forceinline__ void jacobi_eig3(double (&S)[9], double (&V)[9]) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    const double off = fabs(S[1]) + fabs(S[2]) + fabs(S[5]);
+    const double diag = fabs(S[0]) + fabs(S[4]) + fabs(S[8]);
+    // fp64 rounding keeps `off` near 1e-17*diag forever: stop at 1e-15 (rotation error ~1e-15)
+    if (off <= 1e-300 || off <= 1e-15 * diag) break;
+    jacobi_rotate<0, 1>(S, V);
+    jacobi_rotate<0, 2>(S, V);
+    jacobi_rotate<1, 2>(S, V);
+  }
+}
+
+__device__ __forceinline__ double det3(const double (&M)[9]) {
   return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
 }
 
+template <int A, int B>
+__device__ __forceinline__ void sort_cols_desc(double (&ev)[3], double (&V)[9]) {
+  if (ev[B] > ev[A]) {
+    const double t = ev[A]; ev[A] = ev[B]; ev[B] = t;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { const double u = V[3 * r + A]; V[3 * r + A] = V[3 * r + B]; V[3 * r + B] = u; }
+  }
+}
+
 // A = U diag(s) V^T, s descending (row-major 3x3)
-__device__ void svd3(const double A[9], double U[9], double s[3], double V[9]) {
-  double AtA[9], Vt[9];
+__device__ __forceinline__ void svd3(const double (&A)[9], double (&U)[9], double (&s)[3], double (&V)[9]) {
+  double AtA[9];
+#pragma unroll
   for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      double a = 0;
-      for (int k = 0; k < 3; ++k) a += A[3 * k + i] * A[3 * k + j];
-      AtA[3 * i + j] = a;
-    }
-  jacobi_eig3(AtA, Vt);
-  const double ev[3] = {AtA[0], AtA[4], AtA[8]};
-  int ord[3] = {0, 1, 2};
-  for (int i = 0; i < 2; ++i)
-    for (int j = i + 1; j < 3; ++j)
-      if (ev[ord[j]] > ev[ord[i]]) { const int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
-  for (int c = 0; c < 3; ++c)
-    for (int r = 0; r < 3; ++r) V[3 * r + c] = Vt[3 * r + ord[c]];
-  double Uc[3][3];
-  for (int c = 0; c < 3; ++c) {
-    for (int r = 0; r < 3; ++r) {
-      double a = 0;
-      for (int k = 0; k < 3; ++k) a += A[3 * r + k] * V[3 * k + c];
-      Uc[c][r] = a;
-    }
-    s[c] = sqrt(Uc[c][0] * Uc[c][0] + Uc[c][1] * Uc[c][1] + Uc[c][2] * Uc[c][2]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) AtA[3 * i + j] = A[i] * A[j] + A[3 + i] * A[3 + j] + A[6 + i] * A[6 + j];
+  jacobi_eig3(AtA, V);
+  double ev[3] = {AtA[0], AtA[4], AtA[8]};
+  sort_cols_desc<0, 1>(ev, V);
+  sort_cols_desc<0, 2>(ev, V);
+  sort_cols_desc<1, 2>(ev, V);
+  // U columns = A v_c, then modified Gram-Schmidt with completion for (near-)null directions
+  double u0[3], u1[3], u2[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    u0[r] = A[3 * r] * V[0] + A[3 * r + 1] * V[3] + A[3 * r + 2] * V[6];
+    u1[r] = A[3 * r] * V[1] + A[3 * r + 1] * V[4] + A[3 * r + 2] * V[7];
+    u2[r] = A[3 * r] * V[2] + A[3 * r + 1] * V[5] + A[3 * r + 2] * V[8];
   }
+  s[0] = fast_sqrt(u0[0] * u0[0] + u0[1] * u0[1] + u0[2] * u0[2]);
+  s[1] = fast_sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+  s[2] = fast_sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
   const double tiny = 1e-14 * (s[0] > 0 ? s[0] : 1.0);
-  for (int c = 0; c < 3; ++c) {
-    double *u = Uc[c];
-    for (int p = 0; p < c; ++p) {
-      const double d = u[0] * Uc[p][0] + u[1] * Uc[p][1] + u[2] * Uc[p][2];
-      for (int r = 0; r < 3; ++r) u[r] -= d * Uc[p][r];
+  // column 0
+  if (s[0] <= tiny) { u0[0] = 1; u0[1] = 0; u0[2] = 0; }
+  else { const double i0 = fast_rcp(s[0]); u0[0] *= i0; u0[1] *= i0; u0[2] *= i0; }
+  // column 1
+  {
+    const double d = u1[0] * u0[0] + u1[1] * u0[1] + u1[2] * u0[2];
+    u1[0] -= d * u0[0]; u1[1] -= d * u0[1]; u1[2] -= d * u0[2];
+    double n1 = fast_sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    if (s[1] <= tiny || n1 <= 1e-8 * s[1] + 1e-300) {
+      // unit vector along the axis u0 is least aligned with, made orthogonal to u0
+      const double ax = fabs(u0[0]), ay = fabs(u0[1]), az = fabs(u0[2]);
+      const bool mx = ax < ay ? (ax < az) : false;
+      const bool my = !mx && (ax < ay ? false : (ay < az));
+      const double ex = mx ? 1.0 : 0.0, ey = my ? 1.0 : 0.0, ez = (!mx && !my) ? 1.0 : 0.0;
+      const double dd = ex * u0[0] + ey * u0[1] + ez * u0[2];
+      u1[0] = ex - dd * u0[0]; u1[1] = ey - dd * u0[1]; u1[2] = ez - dd * u0[2];
+      n1 = fast_sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
     }
-    double nrm = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    if (s[c] <= tiny || nrm <= 1e-8 * (s[c] > 0 ? s[c] : 1.0) + 1e-300) {
-      if (c == 0) { u[0] = 1; u[1] = 0; u[2] = 0; }
-      else if (c == 1) {
-        const double *a = Uc[0];
-        const int m = fabs(a[0]) < fabs(a[1]) ? (fabs(a[0]) < fabs(a[2]) ? 0 : 2) : (fabs(a[1]) < fabs(a[2]) ? 1 : 2);
-        const double d = a[m];
-        for (int r = 0; r < 3; ++r) u[r] = (r == m ? 1.0 : 0.0) - d * a[r];
-      } else {
-        const double *a = Uc[0], *b = Uc[1];
-        u[0] = a[1] * b[2] - a[2] * b[1];
-        u[1] = a[2] * b[0] - a[0] * b[2];
-        u[2] = a[0] * b[1] - a[1] * b[0];
-      }
-      nrm = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    }
-    for (int r = 0; r < 3; ++r) u[r] /= nrm;
+    const double i1 = fast_rcp(n1);
+    u1[0] *= i1; u1[1] *= i1; u1[2] *= i1;
   }
-  for (int c = 0; c < 3; ++c)
-    for (int r = 0; r < 3; ++r) U[3 * r + c] = Uc[c][r];
+  // column 2
+  {
+    const double d0 = u2[0] * u0[0] + u2[1] * u0[1] + u2[2] * u0[2];
+    u2[0] -= d0 * u0[0]; u2[1] -= d0 * u0[1]; u2[2] -= d0 * u0[2];
+    const double d1 = u2[0] * u1[0] + u2[1] * u1[1] + u2[2] * u1[2];
+    u2[0] -= d1 * u1[0]; u2[1] -= d1 * u1[1]; u2[2] -= d1 * u1[2];
+    double n2 = fast_sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    if (s[2] <= tiny || n2 <= 1e-8 * s[2] + 1e-300) {
+      u2[0] = u0[1] * u1[2] - u0[2] * u1[1];
+      u2[1] = u0[2] * u1[0] - u0[0] * u1[2];
+      u2[2] = u0[0] * u1[1] - u0[1] * u1[0];
+      n2 = fast_sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    }
+    const double i2 = fast_rcp(n2);
+    u2[0] *= i2; u2[1] *= i2; u2[2] *= i2;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { U[3 * r] = u0[r]; U[3 * r + 1] = u1[r]; U[3 * r + 2] = u2[r]; }
 }
 
 // Eigen::umeyama(src, dst, false) from the 17 sums (taken about `pivot`), column-major fp64 out.
-__device__ void umeyama_from_sums(const double S[kNumSums], const double pivot[3], double T[16]) {
+__device__ __forceinline__ void umeyama_from_sums(const double *S, const double *pivot, double (&T)[16]) {
   const double n = S[0];
   double sm[3], dm[3], sigma[9];
-  for (int d = 0; d < 3; ++d) { sm[d] = S[1 + d] / n; dm[d] = S[4 + d] / n; }
+  const double inv_n = 1.0 / n;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { sm[d] = S[1 + d] * inv_n; dm[d] = S[4 + d] * inv_n; }
+#pragma unroll
   for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) sigma[3 * r + c] = S[7 + 3 * r + c] / n - dm[r] * sm[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sigma[3 * r + c] = S[7 + 3 * r + c] * inv_n - dm[r] * sm[c];
+#pragma unroll
   for (int d = 0; d < 3; ++d) { sm[d] += pivot[d]; dm[d] += pivot[d]; }
   double U[9], sv[3], V[9];
   svd3(sigma, U, sv, V);
   double Sg[3] = {1, 1, 1};
   if (det3(sigma) < 0) Sg[2] = -1;
   int rank = 0;
+#pragma unroll
   for (int i = 0; i < 3; ++i)
     if (!(fabs(sv[i]) <= fabs(sv[0]) * 1e-5)) ++rank;
   if (rank == 2) {
@@ -299,20 +364,26 @@ __device__ void umeyama_from_sums(const double S[kNumSums], const double pivot[3
     Sg[2] = (det3(U) * det3(V) > 0) ? 1 : -1;
   }
   double R[9];
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       double a = 0;
+#pragma unroll
       for (int k = 0; k < 3; ++k) a += U[3 * i + k] * Sg[k] * V[3 * j + k];
       R[3 * i + j] = a;
     }
+#pragma unroll
   for (int c = 0; c < 3; ++c)
+#pragma unroll
     for (int r = 0; r < 3; ++r) T[4 * c + r] = R[3 * r + c];
   T[3] = T[7] = T[11] = 0.0;
+#pragma unroll
   for (int i = 0; i < 3; ++i) T[12 + i] = dm[i] - (R[3 * i] * sm[0] + R[3 * i + 1] * sm[1] + R[3 * i + 2] * sm[2]);
   T[15] = 1.0;
 }
 
-__device__ void icp_update_lane(IcpState *st, const double *S) {
+__device__ __forceinline__ void icp_update_lane(IcpState *st, const double *S) {
   const double n = S[0];
   st->n_corr = (long long)n;
   // icp_mod.hpp:232-240
@@ -326,17 +397,24 @@ __device__ void icp_update_lane(IcpState *st, const double *S) {
   umeyama_from_sums(S, st->pivot, Tk);
   // transformation_ is a Matrix4f in the reference
   float Tf[16];
+#pragma unroll
   for (int i = 0; i < 16; ++i) { Tf[i] = (float)Tk[i]; st->Tk[i] = (double)Tf[i]; }
   // final_transformation_ = transformation_ * final_transformation_ (icp_mod.hpp:249), kept in fp64
   double Fn[16];
+#pragma unroll
   for (int c = 0; c < 4; ++c)
+#pragma unroll
     for (int r = 0; r < 4; ++r) {
       double a = 0;
+#pragma unroll
       for (int k = 0; k < 4; ++k) a += (double)Tf[4 * k + r] * st->F[4 * c + k];
       Fn[4 * c + r] = a;
     }
+#pragma unroll
   for (int i = 0; i < 16; ++i) st->F[i] = Fn[i];
+#pragma unroll
   for (int r = 0; r < 3; ++r)
+#pragma unroll
     for (int c = 0; c < 4; ++c) st->Ff[4 * r + c] = (float)Fn[4 * c + r];
   const int iterations = ++st->iterations;
 
@@ -365,35 +443,76 @@ __device__ void icp_update_lane(IcpState *st, const double *S) {
   st->done = conv;
 }
 
-// Fixed-order reduction of the block partials: 1024 threads, one per partial row.
-__global__ __launch_bounds__(kAccMaxBlocks) void icp_reduce_update_kernel(IcpState *st, const double *__restrict__ partials,
+// The update lane works on an LDS copy of the state: its ~60 dependent accesses then cost LDS
+// latency instead of one L2 round trip each (the global version took 18 us of a 22 us launch).
+__device__ __forceinline__ void state_to_lds(IcpState *dst, const IcpState *src) {
+  constexpr int kWords = (int)(sizeof(IcpState) / 4);
+  static_assert(sizeof(IcpState) % 4 == 0, "IcpState must be a whole number of dwords");
+  for (int i = threadIdx.x; i < kWords; i += blockDim.x)
+    reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+}
+
+// Fixed-order reduction of the block partials.  256 threads (4 partial rows each) so that the update
+// lane may use the whole 512-register file instead of spilling its fp64 3x3 algebra.
+constexpr int kRedBlock = 256;
+__global__ __launch_bounds__(kRedBlock) void icp_reduce_update_kernel(IcpState *st, const double *__restrict__ partials,
                                                                             double *S, int nblocks, int do_update,
                                                                             uint32_t *work_counter) {
   if (st->done) return;
   if (threadIdx.x == 0) *work_counter = 0u;  // ticket counter of the next accumulate launch
-  __shared__ double s_red[kAccMaxBlocks / 64][kNumSums];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // LDS tree in a fixed order (cross-lane fp64 shuffles serialised into ~200 dependent
+  // ds_bpermutes and took 15 us): rows -> 256 per-thread sums -> 8 group sums -> total.
+  __shared__ double s_part[kNumSums][kRedBlock];
+  __shared__ double s_grp[kNumSums][8];
+  __shared__ double s_S[kNumSums];
+  __shared__ IcpState s_st;
+  if (do_update) state_to_lds(&s_st, st);
 #pragma unroll
   for (int k = 0; k < kNumSums; ++k) {
-    double v = ((int)threadIdx.x < nblocks) ? partials[k * kAccMaxBlocks + threadIdx.x] : 0.0;
-    v = wave_sum(v);
-    if (lane == 0) s_red[wave][k] = v;
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j < kAccMaxBlocks / kRedBlock; ++j) {
+      // unconditional, independent loads: rows >= nblocks were zero-filled by ope_icp_begin
+      v += partials[k * kAccMaxBlocks + (int)threadIdx.x + j * kRedBlock];
+    }
+    s_part[k][threadIdx.x] = v;
+  }
+  __syncthreads();
+  {
+    const int k = threadIdx.x >> 3, g = threadIdx.x & 7;
+    if (k < kNumSums) {
+      double v = 0.0;
+#pragma unroll
+      for (int j = 0; j < kRedBlock / 8; ++j) v += s_part[k][g * (kRedBlock / 8) + j];
+      s_grp[k][g] = v;
+    }
   }
   __syncthreads();
   if (threadIdx.x < kNumSums) {
     double v = 0.0;
-    for (int w = 0; w < kAccMaxBlocks / 64; ++w) v += s_red[w][threadIdx.x];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v += s_grp[threadIdx.x][g];
     S[threadIdx.x] = v;
+    s_S[threadIdx.x] = v;
   }
   if (do_update) {
-    __syncthreads();  // S was written by this block's own lanes: block-level visibility is enough
-    if (threadIdx.x == 0) icp_update_lane(st, S);
+    __syncthreads();
+    if (threadIdx.x == 0) icp_update_lane(&s_st, s_S);
+    __syncthreads();
+    state_to_lds(st, &s_st);
   }
 }
 
-__global__ void icp_update_kernel(IcpState *st, const double *S) {
+__global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, const double *S) {
   if (st->done) return;
-  if (threadIdx.x == 0) icp_update_lane(st, S);
+  __shared__ double s_S[kNumSums];
+  __shared__ IcpState s_st;
+  state_to_lds(&s_st, st);
+  if (threadIdx.x < kNumSums) s_S[threadIdx.x] = S[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) icp_update_lane(&s_st, s_S);
+  __syncthreads();
+  state_to_lds(st, &s_st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -417,11 +536,12 @@ __global__ __launch_bounds__(256) void nn_search_kernel(CloudView q, BvhView tgt
       y = xform_row(F + 4, s.x, s.y, s.z);
       z = xform_row(F + 8, s.x, s.y, s.z);
     }
-    NearestVisitor v{active ? INFINITY : -INFINITY, -1, 0};
+    NearestVisitor v{active ? INFINITY : -INFINITY, kNoPos, 0};
     if (active) bvh_traverse(tgt, x, y, z, v, stk, 256);
     if (i < q.n) {
-      out_idx[i] = active ? v.idx : -1;
-      out_d2[i] = active ? v.best : INFINITY;
+      const bool found = active && v.pos != kNoPos;
+      out_idx[i] = found ? __float_as_int(tgt.pts[v.pos].w) : -1;
+      out_d2[i] = found ? v.best : INFINITY;
     }
   }
 }
@@ -478,9 +598,9 @@ __global__ __launch_bounds__(256) void fitness_kernel(CloudView q, BvhView tgt, 
     const float x = xform_row(F + 0, s.x, s.y, s.z);
     const float y = xform_row(F + 4, s.x, s.y, s.z);
     const float z = xform_row(F + 8, s.x, s.y, s.z);
-    NearestVisitor v{active ? INFINITY : -INFINITY, -1, 0};
+    NearestVisitor v{active ? INFINITY : -INFINITY, kNoPos, 0};
     if (active) bvh_traverse(tgt, x, y, z, v, stk, 256);
-    if (active && v.idx >= 0 && (double)v.best <= max_range) { sum += (double)v.best; cnt += 1.0; }
+    if (active && v.pos != kNoPos && (double)v.best <= max_range) { sum += (double)v.best; cnt += 1.0; }
   }
   sum = wave_sum(sum);
   cnt = wave_sum(cnt);
@@ -497,24 +617,24 @@ __global__ __launch_bounds__(256) void fitness_kernel(CloudView q, BvhView tgt, 
 // host launchers (called from api.hip)
 void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, const CloudView &src,
                            const BvhView &tgt, const IcpState *st, double *partials, int32_t *corr_match,
-                           float *corr_d2, uint32_t *work_counter) {
+                           float *corr_d2, uint32_t *work_counter, uint32_t *hint) {
   if (mode == 0) {
     if (nrm)
       hipLaunchKernelGGL((icp_accumulate_kernel<0, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, st,
-                         partials, corr_match, corr_d2, work_counter);
+                         partials, corr_match, corr_d2, work_counter, hint);
     else
       hipLaunchKernelGGL((icp_accumulate_kernel<0, false>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, st,
-                         partials, corr_match, corr_d2, work_counter);
+                         partials, corr_match, corr_d2, work_counter, hint);
   } else {
     const size_t lds = (sizeof(float) + sizeof(uint32_t)) * kKnnBlock * kKnnMaxK;
     hipLaunchKernelGGL((icp_accumulate_kernel<1, true>), dim3(nblocks), dim3(kKnnBlock), lds, stream, src, tgt, st,
-                       partials, corr_match, corr_d2, work_counter);
+                       partials, corr_match, corr_d2, work_counter, hint);
   }
 }
 
 void launch_icp_reduce_update(hipStream_t stream, IcpState *st, const double *partials, double *S, int nblocks,
                               bool do_update, uint32_t *work_counter) {
-  hipLaunchKernelGGL(icp_reduce_update_kernel, dim3(1), dim3(kAccMaxBlocks), 0, stream, st, partials, S, nblocks,
+  hipLaunchKernelGGL(icp_reduce_update_kernel, dim3(1), dim3(kRedBlock), 0, stream, st, partials, S, nblocks,
                      do_update ? 1 : 0, work_counter);
 }
 
@@ -550,12 +670,11 @@ void launch_fitness(hipStream_t stream, int nblocks, const CloudView &q, const B
 namespace ope {
 struct CountingVisitor {
   float best;
-  int idx;
   int points, nodes;
   __device__ __forceinline__ bool prune(float bound) const { return !(bound < best); }
-  __device__ __forceinline__ void point(float d, const float4 &p, uint32_t) {
+  __device__ __forceinline__ void point(float d, uint32_t, uint32_t) {
     ++points;
-    if (d < best) { best = d; idx = __float_as_int(p.w); }
+    if (d < best) best = d;
   }
   __device__ __forceinline__ void on_node() { ++nodes; }
 };
@@ -567,7 +686,7 @@ __global__ __launch_bounds__(256) void debug_visit_kernel(CloudView q, BvhView t
   if (i >= q.n_valid) return;
   const float4 s = q.xyzw[i];
   const float qx = xform_row(T + 0, s.x, s.y, s.z), qy = xform_row(T + 4, s.x, s.y, s.z), qz = xform_row(T + 8, s.x, s.y, s.z);
-  CountingVisitor v{INFINITY, -1, 0, 0};
+  CountingVisitor v{INFINITY, 0, 0};
   bvh_traverse(t, qx, qy, qz, v, &s_stk[0][threadIdx.x], 256);
   nodes_out[i] = v.nodes;
   points_out[i] = v.points;

@@ -77,6 +77,7 @@ struct ope_ctx {
   uint32_t *d_work_counter = nullptr;  // ticket counter of the accumulate kernel's dynamic work queue
   int32_t *d_corr_match = nullptr;  // per sorted query: ORIGINAL target index or -1
   float *d_corr_d2 = nullptr;
+  uint32_t *d_hint = nullptr;       // per sorted query: leaf (heap id) of the previous iteration's match, 0 = none
   size_t corr_cap = 0;
   ope::IcpState *h_state = nullptr;  // pinned
   const ope_cloud *run_src = nullptr;
