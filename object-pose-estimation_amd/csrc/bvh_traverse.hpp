@@ -45,7 +45,7 @@ __device__ __forceinline__ float obb_dist2(const v4f n0, const v4f n1, const v4f
 
 // Visitor concept:
 //   bool prune(float bound) const                                    -> subtree with this lower bound can be skipped
-//   void point(float d2, uint32_t pos, uint32_t leaf)                 -> candidate at reordered position pos (may repeat)
+//   void point(float d2, const v4f& p, uint32_t pos, uint32_t leaf)   -> candidate p (w = original index bits) at reordered position pos
 //   void on_node()                                                    -> instrumentation hook (empty in product visitors)
 // `stk` points at this lane's slot of an LDS array float[kMaxDepth + 1][stk_stride].
 //
@@ -91,15 +91,15 @@ __device__ __forceinline__ void bvh_traverse(const BvhView &t, float qx, float q
       const uint32_t j = node - leaf0;
       const uint32_t s = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
       const uint32_t e = (uint32_t)(((unsigned long long)(j + 1) * t.n) >> t.depth);
-      // four independent 16-byte loads in flight per batch (indices clamped to the leaf: a repeated
-      // point cannot win again under the strict <)
+      // four independent 16-byte loads in flight per batch (load indices clamped to the leaf, visitor
+      // calls guarded, so every point is presented exactly once)
       for (uint32_t i = s; i < e; i += 4) {
         const uint32_t i1 = min(i + 1, e - 1), i2 = min(i + 2, e - 1), i3 = min(i + 3, e - 1);
         const v4f p0 = ld16(t.pts + i), p1 = ld16(t.pts + i1), p2 = ld16(t.pts + i2), p3 = ld16(t.pts + i3);
-        v.point(sq_dist3(__fsub_rn(qx, p0.x), __fsub_rn(qy, p0.y), __fsub_rn(qz, p0.z)), i, node);
-        v.point(sq_dist3(__fsub_rn(qx, p1.x), __fsub_rn(qy, p1.y), __fsub_rn(qz, p1.z)), i1, node);
-        v.point(sq_dist3(__fsub_rn(qx, p2.x), __fsub_rn(qy, p2.y), __fsub_rn(qz, p2.z)), i2, node);
-        v.point(sq_dist3(__fsub_rn(qx, p3.x), __fsub_rn(qy, p3.y), __fsub_rn(qz, p3.z)), i3, node);
+        v.point(sq_dist3(__fsub_rn(qx, p0.x), __fsub_rn(qy, p0.y), __fsub_rn(qz, p0.z)), p0, i, node);
+        if (i + 1 < e) v.point(sq_dist3(__fsub_rn(qx, p1.x), __fsub_rn(qy, p1.y), __fsub_rn(qz, p1.z)), p1, i1, node);
+        if (i + 2 < e) v.point(sq_dist3(__fsub_rn(qx, p2.x), __fsub_rn(qy, p2.y), __fsub_rn(qz, p2.z)), p2, i2, node);
+        if (i + 3 < e) v.point(sq_dist3(__fsub_rn(qx, p3.x), __fsub_rn(qy, p3.y), __fsub_rn(qz, p3.z)), p3, i3, node);
       }
     }
     // back up to the deepest pending sibling whose bound still beats the current best
@@ -130,11 +130,50 @@ struct NearestVisitor {
   uint32_t pos;   // reordered target position of the best point, kNoPos if none
   uint32_t leaf;  // heap id of the leaf that holds it (next iteration's start hint)
   __device__ __forceinline__ bool prune(float bound) const { return !(bound < best); }
-  __device__ __forceinline__ void point(float d, uint32_t i, uint32_t lf) {
+  __device__ __forceinline__ void point(float d, const v4f &, uint32_t i, uint32_t lf) {
     if (d < best) { best = d; pos = i; leaf = lf; }
   }
   __device__ __forceinline__ void on_node() {}
 };
+
+// k-nearest list of one lane, kept in LDS with a per-thread stride (bank-conflict free), ascending.
+// `worst` starts at +inf for plain k-NN, or just above r^2 for "the k nearest within radius r".
+struct KnnVisitor {
+  float *d;       // &lds_d[threadIdx.x], element j at d[j*stride]
+  uint32_t *pos;  // reordered target position
+  int stride, k, count;
+  float worst;
+  __device__ __forceinline__ bool prune(float bound) const { return !(bound < worst); }
+  __device__ __forceinline__ void point(float dist, const v4f &, uint32_t i, uint32_t) {
+    if (!(dist < worst)) return;
+    int j = (count < k) ? count++ : k - 1;
+    while (j > 0 && d[(j - 1) * stride] > dist) {
+      d[j * stride] = d[(j - 1) * stride];
+      pos[j * stride] = pos[(j - 1) * stride];
+      --j;
+    }
+    d[j * stride] = dist;
+    pos[j * stride] = i;
+    if (count == k) worst = d[(k - 1) * stride];
+  }
+  __device__ __forceinline__ void on_node() {}
+};
+
+constexpr int kKnnBlock = 256;
+constexpr int kKnnMaxK = 32;
+constexpr size_t kKnnLdsBytes = (sizeof(float) + sizeof(uint32_t)) * kKnnBlock * kKnnMaxK;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
 
 // Apply the 3x4 fp32 transform rows (r00 r01 r02 tx | r10 … | r20 …) with the oracle's operation
 // order: ((r0*x + r1*y) + r2*z) + t, unfused.

@@ -21,46 +21,6 @@
 
 namespace ope {
 
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-__device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-// k-nearest list of one lane, kept in LDS with a per-thread stride (bank-conflict free).
-struct KnnVisitor {
-  float *d;       // &lds_d[threadIdx.x], element j at d[j*stride]
-  uint32_t *pos;  // reordered target position
-  int stride, k, count;
-  float worst;
-  __device__ __forceinline__ bool prune(float bound) const { return !(bound < worst); }
-  __device__ __forceinline__ void point(float dist, uint32_t i, uint32_t) {
-    if (!(dist < worst)) return;
-    for (int j = 0; j < count; ++j)
-      if (pos[j * stride] == i) return;  // the clamped leaf scan may present a point twice
-    int j = (count < k) ? count++ : k - 1;
-    while (j > 0 && d[(j - 1) * stride] > dist) {
-      d[j * stride] = d[(j - 1) * stride];
-      pos[j * stride] = pos[(j - 1) * stride];
-      --j;
-    }
-    d[j * stride] = dist;
-    pos[j * stride] = i;
-    if (count == k) worst = d[(k - 1) * stride];
-  }
-  __device__ __forceinline__ void on_node() {}
-};
-
-constexpr int kKnnBlock = 256;
-constexpr int kKnnMaxK = 32;
-
 // MODE 0: 1-NN correspondences.  MODE 1: normal shooting over the k nearest.
 // NRM: source/target normals present (rejectors and/or normal shooting).
 template <int MODE, bool NRM>
@@ -626,7 +586,7 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
       hipLaunchKernelGGL((icp_accumulate_kernel<0, false>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, st,
                          partials, corr_match, corr_d2, work_counter, hint);
   } else {
-    const size_t lds = (sizeof(float) + sizeof(uint32_t)) * kKnnBlock * kKnnMaxK;
+    const size_t lds = kKnnLdsBytes;
     hipLaunchKernelGGL((icp_accumulate_kernel<1, true>), dim3(nblocks), dim3(kKnnBlock), lds, stream, src, tgt, st,
                        partials, corr_match, corr_d2, work_counter, hint);
   }
@@ -652,7 +612,7 @@ void launch_nn_search(hipStream_t stream, const CloudView &q, const BvhView &tgt
 void launch_knn_search(hipStream_t stream, const CloudView &q, const BvhView &tgt, const float *d_T, int k,
                        int32_t *out_idx, float *out_d2) {
   const int nblocks = (int)std::min<size_t>((q.n + kKnnBlock - 1) / kKnnBlock, 4096);
-  const size_t lds = (sizeof(float) + sizeof(uint32_t)) * kKnnBlock * kKnnMaxK;
+  const size_t lds = kKnnLdsBytes;
   hipLaunchKernelGGL(knn_search_kernel, dim3(std::max(nblocks, 1)), dim3(kKnnBlock), lds, stream, q, tgt, d_T,
                      d_T ? 1 : 0, k, out_idx, out_d2);
 }
@@ -672,7 +632,7 @@ struct CountingVisitor {
   float best;
   int points, nodes;
   __device__ __forceinline__ bool prune(float bound) const { return !(bound < best); }
-  __device__ __forceinline__ void point(float d, uint32_t, uint32_t) {
+  __device__ __forceinline__ void point(float d, const v4f &, uint32_t, uint32_t) {
     ++points;
     if (d < best) best = d;
   }

@@ -1,0 +1,127 @@
+// sampling.hip — pcl::UniformSampling::compute(PointCloud<int>&) on the device
+// (reference call: DetectAndLocalize/src/poseestimator.cpp:141-145, PCL <= 1.7 keypoints API).
+//
+// PCL hashes points into voxels of edge `leaf` and keeps, per voxel, the input index whose point is
+// "closest to the voxel's integer coordinates" — it subtracts INTEGER voxel indices from METRIC
+// coordinates (and carries the w = 1 lane into the norm), first index winning ties (quirk Q7) — and
+// emits survivors in boost::unordered_map order.  Here: one 64-bit key (voxel << 32 | input index)
+// per point, a rocPRIM radix sort, one lane per voxel segment replaying PCL's comparison in input
+// order, and a rocPRIM select; survivors therefore come out in ascending voxel-key order, which is
+// deterministic (the reference's order is unspecified).
+#include <cstring>
+#include <string>
+
+#include <rocprim/rocprim.hpp>
+
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+#include "ope_internal.hpp"
+
+namespace ope {
+
+__global__ __launch_bounds__(256) void voxel_key_kernel(CloudView c, float inv_leaf, int min_bx, int min_by, int min_bz,
+                                                         unsigned div_x, unsigned div_xy, unsigned long long *keys,
+                                                         uint32_t *vals) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c.n) return;
+  vals[i] = i;
+  if (i >= c.n_valid) { keys[i] = ~0ull; return; }
+  const float4 p = c.xyzw[i];
+  const int ix = (int)floorf(p.x * inv_leaf) - min_bx, iy = (int)floorf(p.y * inv_leaf) - min_by,
+            iz = (int)floorf(p.z * inv_leaf) - min_bz;
+  const unsigned long long voxel = (unsigned long long)ix + (unsigned long long)iy * div_x + (unsigned long long)iz * div_xy;
+  keys[i] = (voxel << 32) | (unsigned long long)(uint32_t)__float_as_int(p.w);
+}
+
+__global__ __launch_bounds__(256) void voxel_winner_kernel(CloudView c, float inv_leaf, const unsigned long long *keys,
+                                                            const uint32_t *vals, uint32_t n_valid, int32_t *winner,
+                                                            unsigned char *flags) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= c.n) return;
+  bool start = false;
+  if (p < n_valid) {
+    const unsigned long long vox = keys[p] >> 32;
+    start = (p == 0) || ((keys[p - 1] >> 32) != vox);
+    if (start) {
+      // members arrive in ascending input index: the first one is PCL's initial leaf.idx
+      float4 b = c.xyzw[vals[p]];
+      const float ix = floorf(b.x * inv_leaf), iy = floorf(b.y * inv_leaf), iz = floorf(b.z * inv_leaf);
+      int32_t best = __float_as_int(b.w);
+      for (uint32_t j = p + 1; j < n_valid && (keys[j] >> 32) == vox; ++j) {
+        const float4 q = c.xyzw[vals[j]];
+        const float dc = (q.x - ix) * (q.x - ix) + (q.y - iy) * (q.y - iy) + (q.z - iz) * (q.z - iz) + 1.0f;
+        const float dp = (b.x - ix) * (b.x - ix) + (b.y - iy) * (b.y - iy) + (b.z - iz) * (b.z - iz) + 1.0f;
+        if (dc < dp) { b = q; best = __float_as_int(q.w); }
+      }
+      winner[p] = best;
+    }
+  }
+  if (!start) winner[p] = -1;
+  flags[p] = start ? 1 : 0;
+}
+
+}  // namespace ope
+
+using namespace ope;
+
+extern "C" int ope_uniform_sampling(ope_ctx *ctx, const ope_cloud *cloud, float leaf, int32_t *out_idx, size_t *n_out) {
+  if (!ctx || !cloud || !out_idx || !n_out || !(leaf > 0)) return set_err(ctx, OPE_EINVAL, "ope_uniform_sampling: bad argument");
+  *n_out = 0;
+  const size_t n = cloud->n;
+  if (n == 0 || cloud->n_valid == 0) return OPE_OK;
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  const float inv = 1.0f / leaf;
+  long long min_b[3], div_b[3];
+  for (int d = 0; d < 3; ++d) {
+    min_b[d] = (long long)std::floor(cloud->bb_lo[d] * inv);
+    div_b[d] = (long long)std::floor(cloud->bb_hi[d] * inv) - min_b[d] + 1;
+  }
+  // PCL's own leaf index is a 32-bit int: "Leaf size is too small for the input dataset"
+  if ((double)div_b[0] * (double)div_b[1] * (double)div_b[2] >= 2147483648.0)
+    return set_err(ctx, OPE_EINVAL, "ope_uniform_sampling: leaf size too small for the input dataset (voxel index overflows)");
+  unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+  uint32_t *d_vals = nullptr, *d_vals2 = nullptr;
+  int32_t *d_win = nullptr, *d_out = nullptr;
+  unsigned char *d_flags = nullptr;
+  unsigned int *d_count = nullptr;
+  void *d_tmp = nullptr;
+  hipError_t e = hipMalloc((void **)&d_keys, 8 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_keys2, 8 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_vals, 4 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_vals2, 4 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_win, 4 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_out, 4 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_flags, n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_count, 4);
+  unsigned int count = 0;
+  if (e == hipSuccess) {
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(256), 0, ctx->stream, cloud->view(), inv, (int)min_b[0], (int)min_b[1],
+                       (int)min_b[2], (unsigned)div_b[0], (unsigned)(div_b[0] * div_b[1]), d_keys, d_vals);
+    size_t tmp_sort = 0, tmp_sel = 0;
+    e = rocprim::radix_sort_pairs(nullptr, tmp_sort, d_keys, d_keys2, d_vals, d_vals2, n, 0, 64, ctx->stream);
+    if (e == hipSuccess)
+      e = rocprim::select(nullptr, tmp_sel, d_win, d_flags, d_out, d_count, n, ctx->stream);
+    const size_t tmp_bytes = std::max(tmp_sort, tmp_sel);
+    if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16));
+    size_t tb = tmp_bytes;
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 64, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(voxel_winner_kernel, dim3(nb), dim3(256), 0, ctx->stream, cloud->view(), inv, d_keys2, d_vals2,
+                         (uint32_t)cloud->n_valid, d_win, d_flags);
+      tb = tmp_bytes;
+      e = rocprim::select(d_tmp, tb, d_win, d_flags, d_out, d_count, n, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && count) e = hipMemcpy(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost);
+  }
+  for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_vals, (void *)d_vals2, (void *)d_win, (void *)d_out,
+                  (void *)d_flags, (void *)d_count, d_tmp})
+    if (p) (void)hipFree(p);
+  if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_uniform_sampling: ") + hipGetErrorString(e));
+  *n_out = count;
+  return OPE_OK;
+}
