@@ -192,6 +192,11 @@ int ope_icp_correspondences(ope_ctx *ctx, int32_t *index_query, int32_t *index_m
 int ope_fitness(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float T[16], double max_range,
                 double *score, double *sum_out, int64_t *n_out);
 
+/* registration::TransformationEstimationSVD::estimateRigidTransformation(src, tgt, correspondences, T)
+ * (called stand-alone at poseestimator.cpp:429-435 with identity correspondences over the model).
+ * src_xyz / tgt_xyz: n already-paired points, packed float[3] each.  Needs n >= 1. */
+int ope_rigid_transform_svd(ope_ctx *ctx, const float *src_xyz, const float *tgt_xyz, size_t n, float out_T[16]);
+
 /* pcl::transformPointCloud on the host copy of a result (float math): out = T * in. */
 int ope_transform_cloud(ope_ctx *ctx, const ope_cloud *cloud, const float T[16], float *out_xyz);
 

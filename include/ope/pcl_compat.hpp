@@ -1,0 +1,462 @@
+// pcl_compat.hpp — header-only C++ façade over the C ABI (include/ope.h) that re-creates the PCL call
+// shapes the reference consumes, so that DetectAndLocalize/src/poseestimator.cpp and
+// BuildModel/src/regmeshpcd.cpp can be re-pointed with a namespace alias:
+//
+//     namespace pcl = ope::compat;          // instead of #include <pcl/...>
+//
+// Mirrored interfaces (names, argument meaning and error behaviour follow the reference):
+//   Registration / IterativeClosestPoint[WithNormals]   vPCL registration_mod.h:151-479, icp_mod.h:165-281
+//   registration::CorrespondenceEstimationNormalShooting poseestimator.cpp:242-246
+//   registration::CorrespondenceRejectorSurfaceNormal    poseestimator.cpp:264-272
+//   registration::CorrespondenceRejectorSelfOccludedNormal vPCL correspondence_rejection_self_occluded_normal.h
+//   registration::TransformationEstimationSVD            poseestimator.cpp:306,435
+//   NormalEstimation / FPFHEstimation / UniformSampling  poseestimator.cpp:121-125,141-156
+//   SampleConsensusInitialAlignment                      poseestimator.cpp:50-64
+// Point types are layout-compatible PODs (x@0,y@4,z@8; normal@16 in PointXYZRGBNormal; 16-byte aligned).
+// Errors never throw on the hot path: like PCL, a failed call logs to stderr and leaves
+// hasConverged() == false / the transform at identity (registration_mod.hpp:60-64,73-77).
+#pragma once
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../ope.h"
+
+namespace ope {
+namespace compat {
+
+// ------------------------------------------------------------------------------------------ PODs
+struct alignas(16) PointXYZ { float x, y, z, data3 = 1.f; };
+struct alignas(16) Normal { float normal_x, normal_y, normal_z, data_n3 = 0.f; float curvature = 0.f, pad_[3] = {0, 0, 0}; };
+struct alignas(16) PointXYZRGB { float x, y, z, data3 = 1.f; float rgb = 0.f, pad_[3] = {0, 0, 0}; };
+struct alignas(16) PointXYZRGBNormal {
+  float x, y, z, data3 = 1.f;
+  float normal_x = 0.f, normal_y = 0.f, normal_z = 0.f, data_n3 = 0.f;
+  float rgb = 0.f, curvature = 0.f, pad_[2] = {0, 0};
+};
+struct FPFHSignature33 { float histogram[33]; };
+struct Correspondence { int index_query = 0; int index_match = -1; float distance = FLT_MAX; };
+typedef std::vector<Correspondence> Correspondences;
+static_assert(sizeof(PointXYZ) == 16 && sizeof(Normal) == 32 && sizeof(PointXYZRGB) == 32 &&
+              sizeof(PointXYZRGBNormal) == 48 && sizeof(FPFHSignature33) == 132 && sizeof(Correspondence) == 12,
+              "PCL layouts");
+
+template <class T> struct point_traits { static constexpr ptrdiff_t normal_offset = -1; };
+template <> struct point_traits<PointXYZRGBNormal> { static constexpr ptrdiff_t normal_offset = 16; };
+template <> struct point_traits<Normal> { static constexpr ptrdiff_t normal_offset = 0; };
+
+template <class PointT> struct PointCloud {
+  typedef std::shared_ptr<PointCloud<PointT>> Ptr;
+  typedef std::shared_ptr<const PointCloud<PointT>> ConstPtr;
+  std::vector<PointT> points;
+  uint32_t width = 0, height = 1;
+  bool is_dense = true;
+  size_t size() const { return points.size(); }
+  bool empty() const { return points.empty(); }
+  void clear() { points.clear(); width = 0; height = 1; }
+  void resize(size_t n) { points.resize(n); width = (uint32_t)n; height = 1; }
+  void push_back(const PointT &p) { points.push_back(p); width = (uint32_t)points.size(); height = 1; }
+  PointT &operator[](size_t i) { return points[i]; }
+  const PointT &operator[](size_t i) const { return points[i]; }
+};
+
+// Column-major 4x4, the memory layout of Eigen::Matrix4f.
+struct Matrix4f {
+  float m[16];
+  static Matrix4f Identity() { Matrix4f r; std::memset(r.m, 0, sizeof r.m); r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.f; return r; }
+  float &operator()(int r, int c) { return m[4 * c + r]; }
+  float operator()(int r, int c) const { return m[4 * c + r]; }
+  Matrix4f operator*(const Matrix4f &b) const {
+    Matrix4f o;
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 4; ++r) {
+        float a = 0.f;
+        for (int k = 0; k < 4; ++k) a += m[4 * k + r] * b.m[4 * c + k];
+        o.m[4 * c + r] = a;
+      }
+    return o;
+  }
+  bool operator!=(const Matrix4f &b) const { return std::memcmp(m, b.m, sizeof m) != 0; }
+  const float *data() const { return m; }
+  float *data() { return m; }
+};
+
+// ------------------------------------------------------------------------------------------ plumbing
+inline ope_ctx *default_context(int device = 0) {
+  static ope_ctx *ctx = nullptr;
+  if (!ctx && ope_ctx_create(&ctx, device) != OPE_OK) {
+    std::fprintf(stderr, "[ope] cannot create a GPU context: %s\n", ope_last_error(nullptr));
+    ctx = nullptr;
+  }
+  return ctx;
+}
+inline void log_error(const char *where, ope_ctx *ctx) { std::fprintf(stderr, "[ope::%s] %s\n", where, ope_last_error(ctx)); }
+
+struct CloudHandle {
+  ope_cloud *h = nullptr;
+  ~CloudHandle() { if (h) ope_cloud_free(h); }
+};
+struct IndexHandle {
+  ope_index *h = nullptr;
+  ~IndexHandle() { if (h) ope_index_free(h); }
+};
+
+template <class PointT> inline std::shared_ptr<CloudHandle> upload(const PointCloud<PointT> &c, bool with_normals) {
+  auto r = std::make_shared<CloudHandle>();
+  ope_ctx *ctx = default_context();
+  if (!ctx) return r;
+  const ptrdiff_t noff = with_normals ? point_traits<PointT>::normal_offset : -1;
+  if (ope_cloud_upload(ctx, c.points.data(), c.points.size(), sizeof(PointT), 0, noff, &r->h) != OPE_OK) log_error("upload", ctx);
+  return r;
+}
+
+template <class PointT> inline void transformPointCloud(const PointCloud<PointT> &in, PointCloud<PointT> &out, const Matrix4f &T) {
+  if (&in != &out) out = in;
+  for (auto &p : out.points) {
+    if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+    const float x = p.x, y = p.y, z = p.z;
+    p.x = T.m[0] * x + T.m[4] * y + T.m[8] * z + T.m[12];
+    p.y = T.m[1] * x + T.m[5] * y + T.m[9] * z + T.m[13];
+    p.z = T.m[2] * x + T.m[6] * y + T.m[10] * z + T.m[14];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ strategies
+namespace registration {
+
+struct CorrespondenceEstimationBase {
+  virtual ~CorrespondenceEstimationBase() {}
+  virtual int mode() const { return OPE_CORR_NEAREST; }
+  virtual int k() const { return 1; }
+};
+template <class S, class T, class Scalar = float> struct CorrespondenceEstimation : CorrespondenceEstimationBase {
+  typedef std::shared_ptr<CorrespondenceEstimation> Ptr;
+};
+template <class S, class T, class N, class Scalar = float> struct CorrespondenceEstimationNormalShooting : CorrespondenceEstimationBase {
+  typedef std::shared_ptr<CorrespondenceEstimationNormalShooting> Ptr;
+  int k_ = 10;
+  void setKSearch(int k) { k_ = k; }
+  int mode() const override { return OPE_CORR_NORMAL_SHOOTING; }
+  int k() const override { return k_; }
+  // the reference also calls these on the stand-alone object (poseestimator.cpp:243-245); the ICP
+  // object re-feeds source/target every iteration, so they are accepted and not needed here
+  template <class P> void setInputSource(const P &) {}
+  template <class P> void setSourceNormals(const P &) {}
+  template <class P> void setInputTarget(const P &) {}
+};
+
+struct CorrespondenceRejector {
+  typedef std::shared_ptr<CorrespondenceRejector> Ptr;
+  virtual ~CorrespondenceRejector() {}
+  virtual void apply(ope_icp_params &p) const = 0;
+};
+struct CorrespondenceRejectorSurfaceNormal : CorrespondenceRejector {
+  typedef std::shared_ptr<CorrespondenceRejectorSurfaceNormal> Ptr;
+  double threshold_ = 1.0;
+  void setThreshold(double t) { threshold_ = t; }
+  template <class P, class N> void initializeDataContainer() {}
+  void apply(ope_icp_params &p) const override { p.use_surface_normal_rej = 1; p.surface_normal_thr = threshold_; }
+};
+struct CorrespondenceRejectorSelfOccludedNormal : CorrespondenceRejector {
+  typedef std::shared_ptr<CorrespondenceRejectorSelfOccludedNormal> Ptr;
+  double threshold_ = 1.0;
+  void setThreshold(double t) { threshold_ = t; }
+  void apply(ope_icp_params &p) const override { p.use_self_occluded_rej = 1; p.self_occluded_thr = threshold_; }
+};
+
+template <class S, class T, class Scalar = float> struct TransformationEstimationSVD {
+  typedef std::shared_ptr<TransformationEstimationSVD> Ptr;
+  void estimateRigidTransformation(const PointCloud<S> &src, const PointCloud<T> &tgt, const Correspondences &corrs,
+                                   Matrix4f &out) const {
+    out = Matrix4f::Identity();
+    ope_ctx *ctx = default_context();
+    if (!ctx || corrs.empty()) return;
+    std::vector<float> a(3 * corrs.size()), b(3 * corrs.size());
+    for (size_t i = 0; i < corrs.size(); ++i) {
+      const S &s = src.points[corrs[i].index_query];
+      const T &t = tgt.points[corrs[i].index_match];
+      a[3 * i] = s.x; a[3 * i + 1] = s.y; a[3 * i + 2] = s.z;
+      b[3 * i] = t.x; b[3 * i + 1] = t.y; b[3 * i + 2] = t.z;
+    }
+    if (ope_rigid_transform_svd(ctx, a.data(), b.data(), corrs.size(), out.m) != OPE_OK) log_error("TransformationEstimationSVD", ctx);
+  }
+};
+
+// DefaultConvergenceCriteria knobs the reference can reach through getConvergeCriteria()
+struct DefaultConvergenceCriteria {
+  enum ConvergenceState {
+    CONVERGENCE_CRITERIA_NOT_CONVERGED, CONVERGENCE_CRITERIA_ITERATIONS, CONVERGENCE_CRITERIA_TRANSFORM,
+    CONVERGENCE_CRITERIA_ABS_MSE, CONVERGENCE_CRITERIA_REL_MSE, CONVERGENCE_CRITERIA_NO_CORRESPONDENCES
+  };
+  double mse_threshold_absolute_ = 1e-12;
+  bool failure_after_max_iter_ = false;
+  ConvergenceState state_ = CONVERGENCE_CRITERIA_NOT_CONVERGED;
+  void setAbsoluteMSE(double v) { mse_threshold_absolute_ = v; }
+  double getAbsoluteMSE() const { return mse_threshold_absolute_; }
+  void setFailureAfterMaximumIterations(bool v) { failure_after_max_iter_ = v; }
+  ConvergenceState getConvergenceState() const { return state_; }
+};
+
+}  // namespace registration
+
+// ------------------------------------------------------------------------------------------ ICP
+template <class PointSource, class PointTarget, class Scalar = float> class IterativeClosestPoint {
+ public:
+  typedef PointCloud<PointSource> PointCloudSource;
+  typedef PointCloud<PointTarget> PointCloudTarget;
+  typedef Matrix4f Matrix4;
+
+  IterativeClosestPoint() { ope_icp_default_params(&params_); criteria_ = std::make_shared<registration::DefaultConvergenceCriteria>(); }
+  virtual ~IterativeClosestPoint() {}
+
+  void setInputSource(const typename PointCloudSource::ConstPtr &cloud) { input_ = cloud; src_dev_.reset(); }
+  void setInputCloud(const typename PointCloudSource::ConstPtr &cloud) { setInputSource(cloud); }
+  void setInputTarget(const typename PointCloudTarget::ConstPtr &cloud) {
+    if (!cloud || cloud->points.empty()) {  // registration_mod.hpp:60-64
+      std::fprintf(stderr, "[ope::IterativeClosestPoint::setInputTarget] Invalid or empty point cloud dataset given!\n");
+      return;
+    }
+    target_ = cloud;
+    tgt_dev_.reset(); tgt_index_.reset();
+  }
+  void setMaximumIterations(int n) { params_.max_iterations = n; }
+  void setTransformationEpsilon(double e) { params_.transformation_epsilon = e; }
+  void setEuclideanFitnessEpsilon(double e) { params_.euclidean_fitness_epsilon = e; }
+  void setMaxCorrespondenceDistance(double d) { params_.max_corr_dist = d; }
+  void setRANSACOutlierRejectionThreshold(double) {}  // accepted and unused, as in the reference (poseestimator.cpp:319)
+  void setUseReciprocalCorrespondences(bool b) { params_.use_reciprocal = b ? 1 : 0; }
+  void setCorrespondenceEstimation(const std::shared_ptr<registration::CorrespondenceEstimationBase> &ce) { corr_est_ = ce; }
+  void addCorrespondenceRejector(const registration::CorrespondenceRejector::Ptr &r) { rejectors_.push_back(r); }
+  template <class TE> void setTransformationEstimation(const std::shared_ptr<TE> &) {}  // SVD is the built-in estimator
+  std::shared_ptr<registration::DefaultConvergenceCriteria> getConvergeCriteria() { return criteria_; }
+
+  void align(PointCloudSource &output) { align(output, Matrix4f::Identity()); }
+  void align(PointCloudSource &output, const Matrix4f &guess) {
+    converged_ = false;
+    final_ = Matrix4f::Identity();
+    nr_iterations_ = 0;
+    n_corr_ = 0;
+    ope_ctx *ctx = default_context();
+    if (!ctx) return;
+    if (!target_) {  // registration_mod.hpp:73-77
+      std::fprintf(stderr, "[ope::IterativeClosestPoint::compute] No input target dataset was given!\n");
+      return;
+    }
+    if (!input_) return;
+    ope_icp_params p = params_;
+    p.corr_mode = corr_est_ ? corr_est_->mode() : OPE_CORR_NEAREST;
+    if (corr_est_) p.k_normal_shooting = corr_est_->k();
+    p.use_surface_normal_rej = p.use_self_occluded_rej = 0;
+    for (auto &r : rejectors_) r->apply(p);
+    p.mse_threshold_absolute = criteria_->mse_threshold_absolute_;
+    p.failure_after_max_iter = criteria_->failure_after_max_iter_ ? 1 : 0;
+    const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
+    if (!src_dev_) src_dev_ = upload(*input_, nrm);
+    if (!tgt_index_) {
+      tgt_dev_ = upload(*target_, nrm);
+      tgt_index_ = std::make_shared<IndexHandle>();
+      if (tgt_dev_->h && ope_index_build(ctx, tgt_dev_->h, nullptr, &tgt_index_->h) != OPE_OK) log_error("align", ctx);
+    }
+    if (!src_dev_->h || !tgt_index_->h) return;
+    ope_icp_result res;
+    if (ope_icp_run(ctx, src_dev_->h, tgt_index_->h, guess.m, &p, final_.m, &res) != OPE_OK) {
+      log_error("align", ctx);
+      final_ = Matrix4f::Identity();
+      return;
+    }
+    converged_ = res.converged != 0;
+    nr_iterations_ = res.iterations;
+    n_corr_ = res.n_corr;
+    criteria_->state_ = (registration::DefaultConvergenceCriteria::ConvergenceState)res.state;
+    output = *input_;  // icp_mod.hpp:269-271
+    transformPointCloud(*input_, output, final_);
+  }
+
+  Matrix4f getFinalTransformation() const { return final_; }
+  bool hasConverged() const { return converged_; }
+  int getNumberOfIterations() const { return nr_iterations_; }
+  double getFitnessScore(double max_range = DBL_MAX) {
+    ope_ctx *ctx = default_context();
+    double score = DBL_MAX;
+    if (ctx && src_dev_ && tgt_index_ && src_dev_->h && tgt_index_->h &&
+        ope_fitness(ctx, src_dev_->h, tgt_index_->h, final_.m, max_range, &score, nullptr, nullptr) != OPE_OK)
+      log_error("getFitnessScore", ctx);
+    return score;
+  }
+  // icp_mod.h:249-260
+  double getAlignStrength() const {
+    const double denom = (double)((input_ ? input_->size() : 0) + (target_ ? target_->size() : 0));
+    return denom > 0 ? (double)n_corr_ / denom : 0.0;
+  }
+  // pcl::Correspondences of the last iteration (post-rejection), query order
+  Correspondences getCorrespondences() const {
+    Correspondences out;
+    ope_ctx *ctx = default_context();
+    if (!ctx || !input_) return out;
+    std::vector<int32_t> q(input_->size()), m(input_->size());
+    std::vector<float> d(input_->size());
+    size_t n = 0;
+    if (ope_icp_correspondences(ctx, q.data(), m.data(), d.data(), q.size(), &n) != OPE_OK) return out;
+    out.resize(n);
+    for (size_t i = 0; i < n; ++i) { out[i].index_query = q[i]; out[i].index_match = m[i]; out[i].distance = d[i]; }
+    return out;
+  }
+
+ protected:
+  typename PointCloudSource::ConstPtr input_;
+  typename PointCloudTarget::ConstPtr target_;
+  std::shared_ptr<CloudHandle> src_dev_, tgt_dev_;
+  std::shared_ptr<IndexHandle> tgt_index_;
+  ope_icp_params params_;
+  std::shared_ptr<registration::CorrespondenceEstimationBase> corr_est_;
+  std::vector<registration::CorrespondenceRejector::Ptr> rejectors_;
+  std::shared_ptr<registration::DefaultConvergenceCriteria> criteria_;
+  Matrix4f final_ = Matrix4f::Identity();
+  bool converged_ = false;
+  int nr_iterations_ = 0;
+  int64_t n_corr_ = 0;
+};
+
+// Differs from the base only in transforming the normals too, which the kernels always do.
+template <class S, class T, class Scalar = float> class IterativeClosestPointWithNormals : public IterativeClosestPoint<S, T, Scalar> {};
+
+// ------------------------------------------------------------------------------------------ features
+namespace search { template <class P> struct KdTree { typedef std::shared_ptr<KdTree> Ptr; explicit KdTree(bool = true) {} }; }
+
+template <class PointInT, class PointOutT = Normal> class NormalEstimation {
+ public:
+  void setInputCloud(const typename PointCloud<PointInT>::ConstPtr &c) { input_ = c; }
+  template <class Tree> void setSearchMethod(const Tree &) {}  // the GPU index replaces the kd-tree
+  void setKSearch(int k) { k_ = k; }
+  void setViewPoint(float x, float y, float z) { vp_[0] = x; vp_[1] = y; vp_[2] = z; }
+  void compute(PointCloud<PointOutT> &out) {
+    out.clear();
+    ope_ctx *ctx = default_context();
+    if (!ctx || !input_) return;
+    auto dev = upload(*input_, false);
+    if (!dev->h) return;
+    const size_t n = input_->size();
+    std::vector<float> nrm(3 * n), curv(n);
+    if (ope_normals(ctx, dev->h, k_, vp_, nrm.data(), curv.data()) != OPE_OK) { log_error("NormalEstimation", ctx); return; }
+    out.resize(n);
+    out.is_dense = true;
+    for (size_t i = 0; i < n; ++i) {
+      out.points[i].normal_x = nrm[3 * i]; out.points[i].normal_y = nrm[3 * i + 1]; out.points[i].normal_z = nrm[3 * i + 2];
+      out.points[i].curvature = curv[i];
+      if (!std::isfinite(nrm[3 * i])) out.is_dense = false;
+    }
+  }
+ private:
+  typename PointCloud<PointInT>::ConstPtr input_;
+  int k_ = 0;
+  float vp_[3] = {0, 0, 0};
+};
+
+template <class PointInT, class PointNT = Normal, class PointOutT = FPFHSignature33> class FPFHEstimation {
+ public:
+  void setInputCloud(const typename PointCloud<PointInT>::ConstPtr &c) { input_ = c; }
+  void setInputNormals(const typename PointCloud<PointNT>::ConstPtr &n) { normals_ = n; }
+  void setRadiusSearch(double r) { radius_ = r; }
+  template <class Tree> void setSearchMethod(const Tree &) {}
+  void compute(PointCloud<PointOutT> &out) {
+    out.clear();
+    ope_ctx *ctx = default_context();
+    if (!ctx || !input_ || !normals_ || normals_->size() != input_->size()) return;
+    auto dev = upload(*input_, false);
+    if (!dev->h) return;
+    const size_t n = input_->size();
+    std::vector<float> nrm(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+      nrm[3 * i] = normals_->points[i].normal_x; nrm[3 * i + 1] = normals_->points[i].normal_y; nrm[3 * i + 2] = normals_->points[i].normal_z;
+    }
+    out.resize(n);
+    if (ope_cloud_set_normals(ctx, dev->h, nrm.data()) != OPE_OK ||
+        ope_fpfh(ctx, dev->h, (float)radius_, &out.points[0].histogram[0]) != OPE_OK) {
+      log_error("FPFHEstimation", ctx);
+      out.clear();
+    }
+  }
+ private:
+  typename PointCloud<PointInT>::ConstPtr input_;
+  typename PointCloud<PointNT>::ConstPtr normals_;
+  double radius_ = 0;
+};
+
+template <class PointInT> class UniformSampling {
+ public:
+  void setInputCloud(const typename PointCloud<PointInT>::ConstPtr &c) { input_ = c; }
+  void setRadiusSearch(double leaf) { leaf_ = leaf; }
+  void compute(PointCloud<int> &out) {
+    out.clear();
+    ope_ctx *ctx = default_context();
+    if (!ctx || !input_) return;
+    auto dev = upload(*input_, false);
+    if (!dev->h) return;
+    std::vector<int32_t> idx(input_->size());
+    size_t n = 0;
+    if (ope_uniform_sampling(ctx, dev->h, (float)leaf_, idx.data(), &n) != OPE_OK) { log_error("UniformSampling", ctx); return; }
+    out.points.assign(idx.begin(), idx.begin() + n);
+    out.width = (uint32_t)n;
+  }
+ private:
+  typename PointCloud<PointInT>::ConstPtr input_;
+  double leaf_ = 0.01;
+};
+
+template <class P> inline void copyPointCloud(const PointCloud<P> &in, const std::vector<int> &indices, PointCloud<P> &out) {
+  out.clear();
+  out.points.reserve(indices.size());
+  for (int i : indices) out.points.push_back(in.points[i]);
+  out.width = (uint32_t)out.points.size();
+}
+
+template <class PointSource, class PointTarget, class FeatureT> class SampleConsensusInitialAlignment {
+ public:
+  SampleConsensusInitialAlignment() { ope_sacia_default_params(&p_); p_.max_iterations = 10; p_.nr_samples = 3; p_.k_correspondences = 10; p_.min_sample_dist = 0.f; p_.max_corr_dist = std::sqrt(DBL_MAX); }
+  void setInputSource(const typename PointCloud<PointSource>::ConstPtr &c) { src_ = c; }
+  void setInputTarget(const typename PointCloud<PointTarget>::ConstPtr &c) { tgt_ = c; }
+  void setSourceFeatures(const typename PointCloud<FeatureT>::ConstPtr &f) { sf_ = f; }
+  void setTargetFeatures(const typename PointCloud<FeatureT>::ConstPtr &f) { tf_ = f; }
+  void setMaximumIterations(int n) { p_.max_iterations = n; }
+  void setNumberOfSamples(int n) { p_.nr_samples = n; }
+  void setCorrespondenceRandomness(int k) { p_.k_correspondences = k; }
+  void setMaxCorrespondenceDistance(double d) { p_.max_corr_dist = d; }
+  void setMinSampleDistance(float d) { p_.min_sample_dist = d; }
+  void setSeed(uint64_t s) { p_.seed = s; }  // PCL draws from unseeded rand(): made explicit here
+  void align(PointCloud<PointSource> &output) {
+    final_ = Matrix4f::Identity();
+    converged_ = false;
+    ope_ctx *ctx = default_context();
+    if (!ctx || !src_ || !tgt_ || !sf_ || !tf_ || sf_->size() != src_->size() || tf_->size() != tgt_->size()) return;
+    auto ds = upload(*src_, false), dt = upload(*tgt_, false);
+    IndexHandle ix;
+    if (!ds->h || !dt->h || ope_index_build(ctx, dt->h, nullptr, &ix.h) != OPE_OK) return;
+    double err = 0;
+    int32_t best = -1;
+    if (ope_sacia(ctx, ds->h, &sf_->points[0].histogram[0], dt->h, ix.h, &tf_->points[0].histogram[0], &p_, nullptr,
+                  final_.m, &err, &best) != OPE_OK) { log_error("SampleConsensusInitialAlignment", ctx); return; }
+    converged_ = best >= 0;
+    error_ = err;
+    transformPointCloud(*src_, output, final_);
+  }
+  Matrix4f getFinalTransformation() const { return final_; }
+  bool hasConverged() const { return converged_; }
+  double getLowestError() const { return error_; }
+ private:
+  typename PointCloud<PointSource>::ConstPtr src_;
+  typename PointCloud<PointTarget>::ConstPtr tgt_;
+  typename PointCloud<FeatureT>::ConstPtr sf_, tf_;
+  ope_sacia_params p_;
+  Matrix4f final_ = Matrix4f::Identity();
+  bool converged_ = false;
+  double error_ = 0;
+};
+
+}  // namespace compat
+}  // namespace ope

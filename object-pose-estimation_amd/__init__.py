@@ -130,6 +130,7 @@ ABI = [
     ("ope_icp_set_global_sizes", C.c_int, [_vp, C.c_int64, C.c_int64]),
     ("ope_icp_correspondences", C.c_int, [_vp, _ip, _ip, _fp, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ope_fitness", C.c_int, [_vp, _vp, _vp, _fp, C.c_double, _dp, _dp, C.POINTER(C.c_int64)]),
+    ("ope_rigid_transform_svd", C.c_int, [_vp, _fp, _fp, C.c_size_t, _fp]),
     ("ope_transform_cloud", C.c_int, [_vp, _vp, _fp, _fp]),
     ("ope_comm_get_unique_id", C.c_int, [C.c_char_p]),
     ("ope_comm_init_rank", C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
@@ -355,6 +356,14 @@ class Context:
         score = C.c_double(0); s = C.c_double(0); n = C.c_int64(0)
         self._chk(lib().ope_fitness(self.h, src.h, tgt.h, _p(t, _fp), max_range, C.byref(score), C.byref(s), C.byref(n)))
         return score.value, s.value, n.value
+
+    def rigid_transform_svd(self, src_xyz, tgt_xyz) -> np.ndarray:
+        a, b = _f32(src_xyz, 3), _f32(tgt_xyz, 3)
+        if len(a) != len(b):
+            raise ValueError("paired arrays must have equal length")
+        T = np.empty(16, np.float32)
+        self._chk(lib().ope_rigid_transform_svd(self.h, _p(a, _fp), _p(b, _fp), len(a), _p(T, _fp)))
+        return from_colmajor(T)
 
     def transform_cloud(self, cloud: "Cloud", T) -> np.ndarray:
         out = np.empty((cloud.n, 3), np.float32)

@@ -18,6 +18,7 @@ void launch_icp_update(hipStream_t, IcpState *, const double *);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
 void launch_knn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int, int32_t *, float *);
 void launch_fitness(hipStream_t, int, const CloudView &, const BvhView &, const float *, double, double *);
+void launch_pairs_svd(hipStream_t, const float *, const float *, uint32_t, double *, int, float *);
 // comm.cpp
 int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count);
 
@@ -671,6 +672,32 @@ int ope_fitness(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const 
   if (sum_out) *sum_out = s;
   if (n_out) *n_out = (int64_t)c;
   if (score) *score = c > 0 ? s / c : std::numeric_limits<double>::max();
+  return OPE_OK;
+}
+
+int ope_rigid_transform_svd(ope_ctx *ctx, const float *src_xyz, const float *tgt_xyz, size_t n, float out_T[16]) {
+  if (!ctx || !src_xyz || !tgt_xyz || !out_T || n < 1 || n > (size_t)0x7fffffff)
+    return set_err(ctx, OPE_EINVAL, "ope_rigid_transform_svd: bad argument");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  const int nblocks = (int)std::min<size_t>((n + 255) / 256, 512);
+  float *d_src = nullptr, *d_tgt = nullptr, *d_T = nullptr;
+  double *d_part = nullptr;
+  hipError_t e = hipMalloc((void **)&d_src, 12 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_tgt, 12 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_T, 64);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_part, sizeof(double) * kNumSums * nblocks);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_src, src_xyz, 12 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_tgt, tgt_xyz, 12 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    launch_pairs_svd(ctx->stream, d_src, d_tgt, (uint32_t)n, d_part, nblocks, d_T);
+    e = hipMemcpyAsync(out_T, d_T, 64, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  if (d_src) (void)hipFree(d_src);
+  if (d_tgt) (void)hipFree(d_tgt);
+  if (d_T) (void)hipFree(d_T);
+  if (d_part) (void)hipFree(d_part);
+  if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_rigid_transform_svd: ") + hipGetErrorString(e));
   return OPE_OK;
 }
 

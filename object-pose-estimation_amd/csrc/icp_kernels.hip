@@ -476,6 +476,62 @@ __global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, const doub
 }
 
 // ------------------------------------------------------------------------------------------
+// Stand-alone TransformationEstimationSVD on n given pairs (poseestimator.cpp:429-435):
+// the same 17 sums, about the first source point, then the same umeyama lane.
+__global__ __launch_bounds__(256) void pairs_sums_kernel(const float *__restrict__ src, const float *__restrict__ tgt,
+                                                          uint32_t n, double *__restrict__ partials /*[17][gridDim.x]*/) {
+  __shared__ double s_red[4][kNumSums];
+  const float px = src[0], py = src[1], pz = src[2];
+  double acc[kNumSums];
+#pragma unroll
+  for (int k = 0; k < kNumSums; ++k) acc[k] = 0.0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const double sx = (double)src[3 * i] - px, sy = (double)src[3 * i + 1] - py, sz = (double)src[3 * i + 2] - pz;
+    const double tx = (double)tgt[3 * i] - px, ty = (double)tgt[3 * i + 1] - py, tz = (double)tgt[3 * i + 2] - pz;
+    acc[0] += 1.0;
+    acc[1] += sx; acc[2] += sy; acc[3] += sz;
+    acc[4] += tx; acc[5] += ty; acc[6] += tz;
+    acc[7] += tx * sx; acc[8] += tx * sy; acc[9] += tx * sz;
+    acc[10] += ty * sx; acc[11] += ty * sy; acc[12] += ty * sz;
+    acc[13] += tz * sx; acc[14] += tz * sy; acc[15] += tz * sz;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kNumSums; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) s_red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNumSums)
+    partials[threadIdx.x * gridDim.x + blockIdx.x] =
+        s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void pairs_umeyama_kernel(const double *__restrict__ partials, int nblocks,
+                                                            const float *__restrict__ src, float *__restrict__ out_T) {
+  __shared__ double s_S[kNumSums];
+  if (threadIdx.x < kNumSums) {
+    double v = 0.0;
+    for (int b = 0; b < nblocks; ++b) v += partials[threadIdx.x * nblocks + b];
+    s_S[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double pivot[3] = {(double)src[0], (double)src[1], (double)src[2]};
+    double T[16];
+    umeyama_from_sums(s_S, pivot, T);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out_T[i] = (float)T[i];
+  }
+}
+
+void launch_pairs_svd(hipStream_t stream, const float *d_src, const float *d_tgt, uint32_t n, double *d_partials,
+                      int nblocks, float *d_out_T) {
+  hipLaunchKernelGGL(pairs_sums_kernel, dim3(nblocks), dim3(256), 0, stream, d_src, d_tgt, n, d_partials);
+  hipLaunchKernelGGL(pairs_umeyama_kernel, dim3(1), dim3(64), 0, stream, d_partials, nblocks, d_src, d_out_T);
+}
+
+// ------------------------------------------------------------------------------------------
 // plain searches (ope_nn_search / ope_knn_search) and the fitness pass
 __global__ __launch_bounds__(256) void nn_search_kernel(CloudView q, BvhView tgt, const float *__restrict__ T,
                                                          int has_T, int32_t *__restrict__ out_idx,
