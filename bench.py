@@ -47,6 +47,7 @@ def main() -> int:
                     help="N>1: all-reduce through torch.distributed (RCCL) or the library's own RCCL communicator")
     ap.add_argument("--leaf", type=int, default=0, help="index leaf size override (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-coarse", action="store_true", help="skip the FPFH + SAC-IA initial alignment (identity start)")
     ap.add_argument("--cpu-iters", type=int, default=3)
     args = ap.parse_args()
 
@@ -67,7 +68,10 @@ def main() -> int:
         print("bench.py: no GPU visible; the hot path is HIP-only and has no CPU fallback", file=sys.stderr)
         return 3
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (even with one rank): go through the process group, so the
+    # collective path is the one exercised
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -82,8 +86,8 @@ def main() -> int:
     shard = scene[lo:hi]
 
     ctx = ope.Context(local_rank)
-    use_torch_comm = world > 1 and args.comm == "torch"
-    if world > 1:
+    use_torch_comm = launched and args.comm == "torch"
+    if launched:
         # launch on torch's current stream so torch.distributed orders the collective with our kernels
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     cs = ctx.upload(shard)
@@ -92,15 +96,40 @@ def main() -> int:
     if use_torch_comm:
         sums = torch.zeros(17, dtype=torch.float64, device="cuda")
         ctx.icp_set_sums_buffer(sums.data_ptr())
-    elif world > 1:
+    elif launched:
         ids = [ope.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(ids[0], world, rank)
 
+    # ---- coarse stage (the "FPFH init" of config C3), as estimateCoarsePose runs it (poseestimator.cpp:16-73):
+    # uniform keypoints (leaf 0.01) -> normals (k=30) -> FPFH (r=0.03) on both clouds -> SAC-IA (400 x 5 x 5).
+    # Every rank computes the same (deterministic) initial pose; it is reported, not part of `value`.
+    coarse = None
+    guess = None
+    if not args.no_coarse:
+        t_c = time.perf_counter()
+        stage = {}
+        feats, kclouds = [], []
+        for name, cloud in (("scene", scene), ("model", model)):
+            t1 = time.perf_counter(); full = ctx.upload(cloud); keep = ctx.uniform_sampling(full, 0.01)
+            t2 = time.perf_counter(); kc = ctx.upload(cloud[keep]); ctx.normals(kc, 30)
+            t3 = time.perf_counter(); feats.append(ctx.fpfh(kc, 0.03))
+            t4 = time.perf_counter()
+            stage[name] = {"keypoints": int(len(keep)), "uniform_sampling_ms": (t2 - t1) * 1e3, "normals_ms": (t3 - t2) * 1e3,
+                           "fpfh_ms": (t4 - t3) * 1e3}
+            kclouds.append(kc)
+        t5 = time.perf_counter()
+        kix = ctx.build_index(kclouds[1])
+        guess, sac_err, sac_it = ctx.sacia(kclouds[0], feats[0], kclouds[1], kix, feats[1], ope.default_sacia_params(seed=1))
+        t6 = time.perf_counter()
+        coarse = {"total_ms": (t6 - t_c) * 1e3, "sacia_ms": (t6 - t5) * 1e3, "sacia_hypotheses": 400,
+                  "sacia_best_iteration": int(sac_it), "stages": stage,
+                  "note": "host wall-clock incl. uploads and host-side index builds; not part of value"}
+
     params = ope.default_icp_params(max_iterations=W + K + 1, transformation_epsilon=0.0,
                                     euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0, check_every=0)
     ctx.icp_set_global_sizes(n_scene, n_model)
-    ctx.icp_begin(cs, ix, params)
+    ctx.icp_begin(cs, ix, params, guess)
 
     def step():
         if use_torch_comm:
@@ -117,7 +146,7 @@ def main() -> int:
     for _ in range(W):
         step()
     sync()
-    if world > 1:
+    if launched:
         dist.barrier()
     ctx.icp_profile(K)
     sync()
@@ -125,7 +154,7 @@ def main() -> int:
     for _ in range(K):
         step()
     sync()
-    if world > 1:
+    if launched:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
@@ -134,7 +163,7 @@ def main() -> int:
     out = ctx.icp_end()
     assert out.iterations == W + K, (out.iterations, W, K)
 
-    if world > 1:
+    if launched:
         t = torch.tensor([elapsed, kern_ms / max(kern_n, 1)], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_avg_ms = float(t[0]), float(t[1])
@@ -173,30 +202,32 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": desc, "n_scene": n_scene, "n_model": n_model, "scene_shard_per_gpu": n_local,
                        "parallelism": f"scene-sharded x{world}, model index replicated, 17xfp64 all-reduce/iter"
-                                      + (f" ({args.comm})" if world > 1 else ""),
+                                      + (f" ({args.comm})" if launched else ""),
                        "final_mse": out.last_mse, "n_corr": int(out.n_corr)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "icp_accumulate_kernel", "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
+        if coarse is not None:
+            line["coarse_stage"] = coarse
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(np, scene, model, args.cpu_iters)
+            line["cpu_baseline"] = cpu_baseline(np, scene, model, args.cpu_iters, guess)
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
     return rc
 
 
-def cpu_baseline(np, scene, model, iters: int) -> dict:
+def cpu_baseline(np, scene, model, iters: int, guess=None) -> dict:
     """The C oracle (scalar, one thread) on a bounded sample: `iters` full ICP iterations of the same
-    workload from the identity guess, kd-tree prebuilt (as the GPU's index is)."""
+    workload from the same initial pose, kd-tree prebuilt (as the GPU's index is)."""
     import oracle
     tree = oracle.KdTree(model)
     pivot = 0.5 * (model.min(0).astype(np.float64) + model.max(0).astype(np.float64))
-    T = np.eye(4, dtype=np.float32)
+    T = np.eye(4, dtype=np.float32) if guess is None else np.asarray(guess, np.float32)
     t0 = time.perf_counter()
     for _ in range(iters):
         S = oracle.icp_partial_sums(scene, tree, T, float(np.sqrt(np.finfo(np.float64).max)), pivot)
@@ -205,7 +236,7 @@ def cpu_baseline(np, scene, model, iters: int) -> dict:
     dt = time.perf_counter() - t0
     return {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
             "sample": f"{iters} full ICP iterations (1-NN over all {len(scene)} scene points + SVD update) of the same "
-                      f"workload from the identity guess, kd-tree prebuilt; gcc -O3, single thread; host has "
+                      f"workload from the same initial pose, kd-tree prebuilt; gcc -O3, single thread; host has "
                       f"{os.cpu_count()} logical cores"}
 
 
