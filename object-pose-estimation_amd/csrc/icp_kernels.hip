@@ -32,7 +32,10 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   __shared__ double s_red[BLOCK / 64][kNumSums];
   __shared__ float s_stk[kMaxDepth + 1][BLOCK];  // pending-sibling bounds of the traversal
+  __shared__ v4f s_top[3 * kTopNodes];           // boxes of the first tree levels
   float *stk = &s_stk[0][threadIdx.x];
+  fill_top_nodes(tgt, s_top);
+  __syncthreads();
   extern __shared__ unsigned char s_dyn[];  // MODE 1: k-NN lists
 
   float F[12];
@@ -56,10 +59,9 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 
   // order from a device-wide ticket counter (reset by the reduce kernel).  Which wave sums which chunk
   // only changes the fp32 partial-sum grouping, i.e. the last bits of the fp64 totals.
   const uint32_t lane_id = threadIdx.x & 63u;
-  for (;;) {
-    uint32_t ticket = 0;
-    if (lane_id == 0) ticket = atomicAdd(work_counter, 1u);
-    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket) * 64u;
+  const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+  for (uint32_t chunk = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);; chunk += n_waves) {
+    const uint32_t base = chunk * 64u;
     if (base >= src.n_valid) break;
     const uint32_t i = base + lane_id;
     const bool active = i < src.n_valid;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 
     if (MODE == 0) {
       NearestVisitor v{active ? INFINITY : -INFINITY, kNoPos, 0};
       // start at the leaf that held this query's nearest neighbour one iteration ago (0 = none yet)
-      if (active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, hint[i]);
+      if (active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, hint[i], s_top);
       if (active) hint[i] = v.leaf;
       const bool found = active && v.pos != kNoPos;
       ok = found && !((double)v.best > max_d2);
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 
       float *ld = reinterpret_cast<float *>(s_dyn) + threadIdx.x;
       uint32_t *lp = reinterpret_cast<uint32_t *>(s_dyn + sizeof(float) * BLOCK * kKnnMaxK) + threadIdx.x;
       KnnVisitor v{ld, lp, BLOCK, kk, 0, active ? INFINITY : -INFINITY};
-      bvh_traverse(tgt, x, y, z, v, stk, BLOCK);
+      bvh_traverse(tgt, x, y, z, v, stk, BLOCK, 0, s_top);
       // among the k nearest, the one with the smallest squared distance to the line (s, n)
       // (…normal_shooting_weighted.hpp:115-135; cross product in double)
       double min_dist = 1.79769313486231570815e308;
@@ -730,5 +732,78 @@ extern "C" int ope_debug_visit_counts(ope_ctx *ctx, const ope_cloud *q, const op
   OPE_HIP(ctx, hipMemcpy(hp.data(), d_p, 4 * n, hipMemcpyDeviceToHost));
   for (size_t i = 0; i < n; ++i) { nodes[q->perm[i]] = hn[i]; points[q->perm[i]] = hp[i]; }
   (void)hipFree(d_n); (void)hipFree(d_p); (void)hipFree(d_T);
+  return OPE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Developer instrumentation (tools/chunk_profile.py): one wave per 64-query chunk, start hints taken
+// from the last ICP run; per chunk the elapsed shader cycles and the lane-maximum step counts.
+namespace ope {
+struct StepVisitor {
+  float best;
+  uint32_t pos, leaf;
+  int nodes, points;
+  __device__ __forceinline__ bool prune(float bound) const { return !(bound < best); }
+  __device__ __forceinline__ void point(float d, const v4f &, uint32_t i, uint32_t lf) {
+    ++points;
+    if (d < best) { best = d; pos = i; leaf = lf; }
+  }
+  __device__ __forceinline__ void on_node() { ++nodes; }
+};
+
+__global__ __launch_bounds__(kAccBlock, 8) void debug_chunk_kernel(CloudView src, BvhView tgt, const float *__restrict__ T,
+                                                                     const uint32_t *__restrict__ hint, int use_hint,
+                                                                     long long *__restrict__ out) {
+  __shared__ float s_stk[kMaxDepth + 1][kAccBlock];
+  __shared__ v4f s_top[3 * kTopNodes];
+  fill_top_nodes(tgt, s_top);
+  __syncthreads();
+  const uint32_t lane_id = threadIdx.x & 63u;
+  const uint32_t chunk = blockIdx.x * (kAccBlock / 64) + (threadIdx.x >> 6);
+  const uint32_t base = chunk * 64u;
+  if (base >= src.n_valid) return;
+  const uint32_t i = base + lane_id;
+  const bool active = i < src.n_valid;
+  const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+  const float4 s = src.xyzw[active ? i : base];
+  const float x = xform_row(T + 0, s.x, s.y, s.z), y = xform_row(T + 4, s.x, s.y, s.z), z = xform_row(T + 8, s.x, s.y, s.z);
+  StepVisitor v{active ? INFINITY : -INFINITY, kNoPos, 0, 0, 0};
+  if (active) bvh_traverse(tgt, x, y, z, v, &s_stk[0][threadIdx.x], kAccBlock, use_hint ? hint[i] : 0u, s_top);
+  const long long t1 = (long long)__builtin_amdgcn_s_memtime();
+  int mn = v.nodes, mp = v.points, sn = v.nodes, sp = v.points;
+  for (int off = 32; off >= 1; off >>= 1) {
+    mn = max(mn, __shfl_xor(mn, off, 64)); mp = max(mp, __shfl_xor(mp, off, 64));
+    sn += __shfl_xor(sn, off, 64); sp += __shfl_xor(sp, off, 64);
+  }
+  if (lane_id == 0) {
+    out[6 * (size_t)chunk + 0] = t1 - t0;
+    out[6 * (size_t)chunk + 1] = mn;
+    out[6 * (size_t)chunk + 2] = mp;
+    out[6 * (size_t)chunk + 3] = sn;
+    out[6 * (size_t)chunk + 4] = sp;
+    out[6 * (size_t)chunk + 5] = t0;
+  }
+}
+}  // namespace ope
+
+extern "C" int ope_debug_chunk_profile(ope_ctx *ctx, const ope_cloud *q, const ope_index *ix, const float *T_colmajor,
+                                       int use_hint, long long *out /* n_chunks * 6 */) {
+  using namespace ope;
+  const size_t nch = (q->n_valid + 63) / 64;
+  float rows[12];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) rows[4 * r + c] = T_colmajor[4 * c + r];
+  float *d_T;
+  long long *d_out;
+  OPE_HIP(ctx, hipMalloc((void **)&d_T, sizeof rows));
+  OPE_HIP(ctx, hipMalloc((void **)&d_out, sizeof(long long) * 6 * nch));
+  OPE_HIP(ctx, hipMemset(d_out, 0, sizeof(long long) * 6 * nch));
+  OPE_HIP(ctx, hipMemcpy(d_T, rows, sizeof rows, hipMemcpyHostToDevice));
+  const unsigned nb = (unsigned)((nch + kAccBlock / 64 - 1) / (kAccBlock / 64));
+  hipLaunchKernelGGL(debug_chunk_kernel, dim3(nb), dim3(kAccBlock), 0, ctx->stream, q->view(), ix->view(), d_T, ctx->d_hint,
+                     (use_hint && ctx->d_hint) ? 1 : 0, d_out);
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  OPE_HIP(ctx, hipMemcpy(out, d_out, sizeof(long long) * 6 * nch, hipMemcpyDeviceToHost));
+  (void)hipFree(d_T); (void)hipFree(d_out);
   return OPE_OK;
 }
