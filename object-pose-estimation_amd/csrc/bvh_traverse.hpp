@@ -57,33 +57,20 @@ __device__ __forceinline__ float obb_dist2(const v4f n0, const v4f n1, const v4f
 // LDS-only and the D dependent round trips of a level-by-level check collapse into D/4.  Only
 // siblings that beat the current best are expanded.  Same exact result as the top-down walk.
 //
-// `top` (optional) is an LDS copy of nodes [0, kTopNodes): the boxes of the first levels are shared by
-// every query of the block and are read from LDS instead of through the texture path.
-constexpr int kTopLevels = 6;                  // levels 0..5
-constexpr int kTopNodes = 1 << kTopLevels;     // heap ids 0..63 (3 KiB)
-
-__device__ __forceinline__ void load_node(const BvhView &t, const v4f *top, uint32_t node, v4f &a, v4f &b, v4f &c) {
-  if (top != nullptr && node < (uint32_t)kTopNodes) {
-    a = top[3 * node]; b = top[3 * node + 1]; c = top[3 * node + 2];
-  } else {
-    const float4 *o = t.nodes + 3 * (size_t)node;
-    a = ld16(o); b = ld16(o + 1); c = ld16(o + 2);
-  }
-}
-
-// Block-cooperative fill of the LDS copy (call before the first traversal, then __syncthreads()).
-__device__ __forceinline__ void fill_top_nodes(const BvhView &t, v4f *top) {
-  const uint32_t have = min((uint32_t)kTopNodes, 2u << t.depth);
-  for (uint32_t i = threadIdx.x; i < 3u * kTopNodes; i += blockDim.x)
-    top[i] = (i < 3u * have) ? ld16(t.nodes + i) : ld16(t.nodes + 3);
+// (An LDS copy of the first tree levels was tried: selecting between an LDS and a global pointer per
+// lane turns every node fetch into a flat_load, which waits on both counters and was slower.)
+__device__ __forceinline__ void load_node(const BvhView &t, uint32_t node, v4f &a, v4f &b, v4f &c) {
+  const float4 *o = t.nodes + 3 * (size_t)node;
+  a = ld16(o); b = ld16(o + 1); c = ld16(o + 2);
 }
 
 template <class Visitor>
 __device__ __forceinline__ void bvh_traverse(const BvhView &t, float qx, float qy, float qz, Visitor &v, float *stk,
-                                             int stk_stride, uint32_t start_leaf = 0, const v4f *top = nullptr) {
+                                             int stk_stride, uint32_t start_leaf = 0) {
   const uint32_t leaf0 = 1u << t.depth;
   uint32_t node = 1;
   uint32_t trail = 0;  // bit k: the sibling of the k-th ancestor (bit 0: of `node` itself) is pending
+  float minb = INFINITY;  // never above the smallest parked bound: if it cannot beat the best, nothing pending can
   if (start_leaf != 0) {
     node = start_leaf;
     trail = leaf0 - 1u;
@@ -95,18 +82,21 @@ __device__ __forceinline__ void bvh_traverse(const BvhView &t, float qx, float q
       const uint32_t s1 = (k + 1 < D) ? ((start_leaf >> (k + 1)) ^ 1u) : s0;
       const uint32_t s2 = (k + 2 < D) ? ((start_leaf >> (k + 2)) ^ 1u) : s0;
       const uint32_t s3 = (k + 3 < D) ? ((start_leaf >> (k + 3)) ^ 1u) : s0;
-      load_node(t, top, s0, a0, b0, c0);
-      load_node(t, top, s1, a1, b1, c1);
-      load_node(t, top, s2, a2, b2, c2);
-      load_node(t, top, s3, a3, b3, c3);
-      stk[(D - k) * stk_stride] = obb_dist2(a0, b0, c0, qx, qy, qz);
-      if (k + 1 < D) stk[(D - k - 1) * stk_stride] = obb_dist2(a1, b1, c1, qx, qy, qz);
-      if (k + 2 < D) stk[(D - k - 2) * stk_stride] = obb_dist2(a2, b2, c2, qx, qy, qz);
-      if (k + 3 < D) stk[(D - k - 3) * stk_stride] = obb_dist2(a3, b3, c3, qx, qy, qz);
+      load_node(t, s0, a0, b0, c0);
+      load_node(t, s1, a1, b1, c1);
+      load_node(t, s2, a2, b2, c2);
+      load_node(t, s3, a3, b3, c3);
+      const float e0 = obb_dist2(a0, b0, c0, qx, qy, qz), e1 = obb_dist2(a1, b1, c1, qx, qy, qz),
+                  e2 = obb_dist2(a2, b2, c2, qx, qy, qz), e3 = obb_dist2(a3, b3, c3, qx, qy, qz);
+      stk[(D - k) * stk_stride] = e0;
+      if (k + 1 < D) stk[(D - k - 1) * stk_stride] = e1;
+      if (k + 2 < D) stk[(D - k - 2) * stk_stride] = e2;
+      if (k + 3 < D) stk[(D - k - 3) * stk_stride] = e3;
+      minb = fminf(minb, fminf(fminf(e0, e1), fminf(e2, e3)));  // duplicates of e0 in the tail are harmless
     }
   } else {
     v4f a, b, c;
-    load_node(t, top, 1, a, b, c);
+    load_node(t, 1, a, b, c);
     if (v.prune(obb_dist2(a, b, c, qx, qy, qz))) return;
   }
   // Flat loop: each trip advances every lane by one unit of work (an inner-node step OR a whole leaf
@@ -117,8 +107,8 @@ __device__ __forceinline__ void bvh_traverse(const BvhView &t, float qx, float q
     if (node < leaf0) {
       v.on_node();
       v4f c0, c1, c2, c3, c4, c5;
-      load_node(t, top, 2 * node, c0, c1, c2);
-      load_node(t, top, 2 * node + 1, c3, c4, c5);
+      load_node(t, 2 * node, c0, c1, c2);
+      load_node(t, 2 * node + 1, c3, c4, c5);
       const float d0 = obb_dist2(c0, c1, c2, qx, qy, qz);
       const float d1 = obb_dist2(c3, c4, c5, qx, qy, qz);
       const bool right = d1 < d0;
@@ -128,25 +118,36 @@ __device__ __forceinline__ void bvh_traverse(const BvhView &t, float qx, float q
         node = 2 * node + (right ? 1u : 0u);
         const bool pend = !v.prune(df);
         trail = (trail << 1) | (pend ? 1u : 0u);
-        if (pend) stk[(31 - __clz(node)) * stk_stride] = df;
+        if (pend) { stk[(31 - __clz(node)) * stk_stride] = df; minb = fminf(minb, df); }
         continue;
       }
     } else {
       const uint32_t j = node - leaf0;
       const uint32_t s = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
       const uint32_t e = (uint32_t)(((unsigned long long)(j + 1) * t.n) >> t.depth);
-      // four independent 16-byte loads in flight per batch (load indices clamped to the leaf, visitor
-      // calls guarded, so every point is presented exactly once)
-      for (uint32_t i = s; i < e; i += 4) {
-        const uint32_t i1 = min(i + 1, e - 1), i2 = min(i + 2, e - 1), i3 = min(i + 3, e - 1);
-        const v4f p0 = ld16(t.pts + i), p1 = ld16(t.pts + i1), p2 = ld16(t.pts + i2), p3 = ld16(t.pts + i3);
-        v.point(sq_dist3(__fsub_rn(qx, p0.x), __fsub_rn(qy, p0.y), __fsub_rn(qz, p0.z)), p0, i, node);
-        if (i + 1 < e) v.point(sq_dist3(__fsub_rn(qx, p1.x), __fsub_rn(qy, p1.y), __fsub_rn(qz, p1.z)), p1, i1, node);
-        if (i + 2 < e) v.point(sq_dist3(__fsub_rn(qx, p2.x), __fsub_rn(qy, p2.y), __fsub_rn(qz, p2.z)), p2, i2, node);
-        if (i + 3 < e) v.point(sq_dist3(__fsub_rn(qx, p3.x), __fsub_rn(qy, p3.y), __fsub_rn(qz, p3.z)), p3, i3, node);
+      // eight independent 16-byte loads in flight per batch (load indices clamped to the leaf, visitor
+      // calls guarded, so every point is presented exactly once): a default 8-point bucket is ONE trip
+#define OPE_LEAF_POINT(P, IDX) \
+  v.point(sq_dist3(__fsub_rn(qx, P.x), __fsub_rn(qy, P.y), __fsub_rn(qz, P.z)), P, IDX, node)
+      for (uint32_t i = s; i < e; i += 8) {
+        const uint32_t m = e - 1;
+        const v4f p0 = ld16(t.pts + i), p1 = ld16(t.pts + min(i + 1, m)), p2 = ld16(t.pts + min(i + 2, m)),
+                  p3 = ld16(t.pts + min(i + 3, m)), p4 = ld16(t.pts + min(i + 4, m)), p5 = ld16(t.pts + min(i + 5, m)),
+                  p6 = ld16(t.pts + min(i + 6, m)), p7 = ld16(t.pts + min(i + 7, m));
+        OPE_LEAF_POINT(p0, i);
+        if (i + 1 < e) OPE_LEAF_POINT(p1, i + 1);
+        if (i + 2 < e) OPE_LEAF_POINT(p2, i + 2);
+        if (i + 3 < e) OPE_LEAF_POINT(p3, i + 3);
+        if (i + 4 < e) OPE_LEAF_POINT(p4, i + 4);
+        if (i + 5 < e) OPE_LEAF_POINT(p5, i + 5);
+        if (i + 6 < e) OPE_LEAF_POINT(p6, i + 6);
+        if (i + 7 < e) OPE_LEAF_POINT(p7, i + 7);
       }
+#undef OPE_LEAF_POINT
     }
-    // back up to the deepest pending sibling whose parked bound still beats the current best (LDS only)
+    // back up to the deepest pending sibling whose parked bound still beats the current best (LDS only);
+    // most queries end here without touching LDS: no parked bound is below `minb`
+    if (v.prune(minb)) return;
     for (;;) {
       if (trail == 0) return;
       const int k = __builtin_ctz(trail);

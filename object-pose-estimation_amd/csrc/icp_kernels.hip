@@ -32,10 +32,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   __shared__ double s_red[BLOCK / 64][kNumSums];
   __shared__ float s_stk[kMaxDepth + 1][BLOCK];  // pending-sibling bounds of the traversal
-  __shared__ v4f s_top[3 * kTopNodes];           // boxes of the first tree levels
   float *stk = &s_stk[0][threadIdx.x];
-  fill_top_nodes(tgt, s_top);
-  __syncthreads();
   extern __shared__ unsigned char s_dyn[];  // MODE 1: k-NN lists
 
   float F[12];
@@ -83,7 +80,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 
     if (MODE == 0) {
       NearestVisitor v{active ? INFINITY : -INFINITY, kNoPos, 0};
       // start at the leaf that held this query's nearest neighbour one iteration ago (0 = none yet)
-      if (active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, hint[i], s_top);
+      if (active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, hint[i]);
       if (active) hint[i] = v.leaf;
       const bool found = active && v.pos != kNoPos;
       ok = found && !((double)v.best > max_d2);
@@ -94,7 +91,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 
       float *ld = reinterpret_cast<float *>(s_dyn) + threadIdx.x;
       uint32_t *lp = reinterpret_cast<uint32_t *>(s_dyn + sizeof(float) * BLOCK * kKnnMaxK) + threadIdx.x;
       KnnVisitor v{ld, lp, BLOCK, kk, 0, active ? INFINITY : -INFINITY};
-      bvh_traverse(tgt, x, y, z, v, stk, BLOCK, 0, s_top);
+      bvh_traverse(tgt, x, y, z, v, stk, BLOCK);
       // among the k nearest, the one with the smallest squared distance to the line (s, n)
       // (…normal_shooting_weighted.hpp:115-135; cross product in double)
       double min_dist = 1.79769313486231570815e308;
@@ -751,37 +748,120 @@ struct StepVisitor {
   __device__ __forceinline__ void on_node() { ++nodes; }
 };
 
+#define OPE_STAMP(var)                                                                    \
+  do {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+  } while (0)
+
 __global__ __launch_bounds__(kAccBlock, 8) void debug_chunk_kernel(CloudView src, BvhView tgt, const float *__restrict__ T,
                                                                      const uint32_t *__restrict__ hint, int use_hint,
                                                                      long long *__restrict__ out) {
   __shared__ float s_stk[kMaxDepth + 1][kAccBlock];
-  __shared__ v4f s_top[3 * kTopNodes];
-  fill_top_nodes(tgt, s_top);
-  __syncthreads();
   const uint32_t lane_id = threadIdx.x & 63u;
   const uint32_t chunk = blockIdx.x * (kAccBlock / 64) + (threadIdx.x >> 6);
   const uint32_t base = chunk * 64u;
   if (base >= src.n_valid) return;
   const uint32_t i = base + lane_id;
   const bool active = i < src.n_valid;
-  const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-  const float4 s = src.xyzw[active ? i : base];
-  const float x = xform_row(T + 0, s.x, s.y, s.z), y = xform_row(T + 4, s.x, s.y, s.z), z = xform_row(T + 8, s.x, s.y, s.z);
+  unsigned long long t0, t1, ta, tb;
+  unsigned long long c_node = 0, c_leaf = 0, c_pop = 0, c_eager = 0, n_node = 0, n_leaf = 0, n_pop = 0;
+  OPE_STAMP(t0);
+  const float4 s4 = src.xyzw[active ? i : base];
+  const float qx = xform_row(T + 0, s4.x, s4.y, s4.z), qy = xform_row(T + 4, s4.x, s4.y, s4.z), qz = xform_row(T + 8, s4.x, s4.y, s4.z);
   StepVisitor v{active ? INFINITY : -INFINITY, kNoPos, 0, 0, 0};
-  if (active) bvh_traverse(tgt, x, y, z, v, &s_stk[0][threadIdx.x], kAccBlock, use_hint ? hint[i] : 0u, s_top);
-  const long long t1 = (long long)__builtin_amdgcn_s_memtime();
-  int mn = v.nodes, mp = v.points, sn = v.nodes, sp = v.points;
-  for (int off = 32; off >= 1; off >>= 1) {
-    mn = max(mn, __shfl_xor(mn, off, 64)); mp = max(mp, __shfl_xor(mp, off, 64));
-    sn += __shfl_xor(sn, off, 64); sp += __shfl_xor(sp, off, 64);
+  // ---- instrumented copy of bvh_traverse's flat loop (no LDS top copy) ----
+  const BvhView &t = tgt;
+  float *stk = &s_stk[0][threadIdx.x];
+  const int stk_stride = kAccBlock;
+  const uint32_t leaf0 = 1u << t.depth;
+  uint32_t node = 1, trail = 0;
+  const uint32_t start_leaf = (active && use_hint) ? hint[i] : 0u;
+  bool alive = active;
+  OPE_STAMP(ta);
+  if (alive && start_leaf != 0) {
+    node = start_leaf;
+    trail = leaf0 - 1u;
+    const int D = t.depth;
+    for (int k = 0; k < D; k += 4) {
+      v4f a0, b0, c0, a1, b1, c1, a2, b2, c2, a3, b3, c3;
+      const uint32_t s0 = (start_leaf >> k) ^ 1u;
+      const uint32_t s1 = (k + 1 < D) ? ((start_leaf >> (k + 1)) ^ 1u) : s0;
+      const uint32_t s2 = (k + 2 < D) ? ((start_leaf >> (k + 2)) ^ 1u) : s0;
+      const uint32_t s3 = (k + 3 < D) ? ((start_leaf >> (k + 3)) ^ 1u) : s0;
+      load_node(t, s0, a0, b0, c0); load_node(t, s1, a1, b1, c1);
+      load_node(t, s2, a2, b2, c2); load_node(t, s3, a3, b3, c3);
+      stk[(D - k) * stk_stride] = obb_dist2(a0, b0, c0, qx, qy, qz);
+      if (k + 1 < D) stk[(D - k - 1) * stk_stride] = obb_dist2(a1, b1, c1, qx, qy, qz);
+      if (k + 2 < D) stk[(D - k - 2) * stk_stride] = obb_dist2(a2, b2, c2, qx, qy, qz);
+      if (k + 3 < D) stk[(D - k - 3) * stk_stride] = obb_dist2(a3, b3, c3, qx, qy, qz);
+    }
   }
+  OPE_STAMP(tb);
+  c_eager += tb - ta;
+  while (__ballot(alive) != 0ull) {
+    bool do_pop = false;
+    OPE_STAMP(ta);
+    if (alive && node < leaf0) {
+      v.on_node();
+      v4f c0, c1, c2, c3, c4, c5;
+      load_node(t, 2 * node, c0, c1, c2);
+      load_node(t, 2 * node + 1, c3, c4, c5);
+      const float d0 = obb_dist2(c0, c1, c2, qx, qy, qz);
+      const float d1 = obb_dist2(c3, c4, c5, qx, qy, qz);
+      const bool right = d1 < d0;
+      const float dn = right ? d1 : d0, df = right ? d0 : d1;
+      if (!v.prune(dn)) {
+        node = 2 * node + (right ? 1u : 0u);
+        const bool pend = !v.prune(df);
+        trail = (trail << 1) | (pend ? 1u : 0u);
+        if (pend) stk[(31 - __clz(node)) * stk_stride] = df;
+      } else {
+        do_pop = true;
+      }
+    }
+    OPE_STAMP(tb);
+    c_node += tb - ta; n_node += 1;
+    const bool leaf_now = alive && !do_pop && node >= leaf0 && false;
+    (void)leaf_now;
+    OPE_STAMP(ta);
+    if (alive && !do_pop && node >= leaf0) {
+      const uint32_t j = node - leaf0;
+      const uint32_t sb = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
+      const uint32_t e = (uint32_t)(((unsigned long long)(j + 1) * t.n) >> t.depth);
+      for (uint32_t q = sb; q < e; q += 4) {
+        const uint32_t i1 = min(q + 1, e - 1), i2 = min(q + 2, e - 1), i3 = min(q + 3, e - 1);
+        const v4f p0 = ld16(t.pts + q), p1 = ld16(t.pts + i1), p2 = ld16(t.pts + i2), p3 = ld16(t.pts + i3);
+        v.point(sq_dist3(__fsub_rn(qx, p0.x), __fsub_rn(qy, p0.y), __fsub_rn(qz, p0.z)), p0, q, node);
+        if (q + 1 < e) v.point(sq_dist3(__fsub_rn(qx, p1.x), __fsub_rn(qy, p1.y), __fsub_rn(qz, p1.z)), p1, i1, node);
+        if (q + 2 < e) v.point(sq_dist3(__fsub_rn(qx, p2.x), __fsub_rn(qy, p2.y), __fsub_rn(qz, p2.z)), p2, i2, node);
+        if (q + 3 < e) v.point(sq_dist3(__fsub_rn(qx, p3.x), __fsub_rn(qy, p3.y), __fsub_rn(qz, p3.z)), p3, i3, node);
+      }
+      do_pop = true;
+    }
+    OPE_STAMP(tb);
+    c_leaf += tb - ta; n_leaf += 1;
+    OPE_STAMP(ta);
+    if (alive && do_pop) {
+      for (;;) {
+        if (trail == 0) { alive = false; break; }
+        const int k = __builtin_ctz(trail);
+        node = (node >> k) ^ 1u;
+        trail = (trail >> k) & ~1u;
+        if (!v.prune(stk[(31 - __clz(node)) * stk_stride])) break;
+      }
+    }
+    OPE_STAMP(tb);
+    c_pop += tb - ta; n_pop += 1;
+  }
+  OPE_STAMP(t1);
+  int mn = v.nodes, mp = v.points;
+  for (int off = 32; off >= 1; off >>= 1) { mn = max(mn, __shfl_xor(mn, off, 64)); mp = max(mp, __shfl_xor(mp, off, 64)); }
   if (lane_id == 0) {
-    out[6 * (size_t)chunk + 0] = t1 - t0;
-    out[6 * (size_t)chunk + 1] = mn;
-    out[6 * (size_t)chunk + 2] = mp;
-    out[6 * (size_t)chunk + 3] = sn;
-    out[6 * (size_t)chunk + 4] = sp;
-    out[6 * (size_t)chunk + 5] = t0;
+    long long *o = out + 10 * (size_t)chunk;
+    o[0] = (long long)(t1 - t0); o[1] = mn; o[2] = mp; o[3] = (long long)c_eager; o[4] = (long long)c_node;
+    o[5] = (long long)c_leaf; o[6] = (long long)c_pop; o[7] = (long long)n_node; o[8] = 0; o[9] = 0;
   }
 }
 }  // namespace ope
@@ -796,14 +876,14 @@ extern "C" int ope_debug_chunk_profile(ope_ctx *ctx, const ope_cloud *q, const o
   float *d_T;
   long long *d_out;
   OPE_HIP(ctx, hipMalloc((void **)&d_T, sizeof rows));
-  OPE_HIP(ctx, hipMalloc((void **)&d_out, sizeof(long long) * 6 * nch));
-  OPE_HIP(ctx, hipMemset(d_out, 0, sizeof(long long) * 6 * nch));
+  OPE_HIP(ctx, hipMalloc((void **)&d_out, sizeof(long long) * 10 * nch));
+  OPE_HIP(ctx, hipMemset(d_out, 0, sizeof(long long) * 10 * nch));
   OPE_HIP(ctx, hipMemcpy(d_T, rows, sizeof rows, hipMemcpyHostToDevice));
   const unsigned nb = (unsigned)((nch + kAccBlock / 64 - 1) / (kAccBlock / 64));
   hipLaunchKernelGGL(debug_chunk_kernel, dim3(nb), dim3(kAccBlock), 0, ctx->stream, q->view(), ix->view(), d_T, ctx->d_hint,
                      (use_hint && ctx->d_hint) ? 1 : 0, d_out);
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  OPE_HIP(ctx, hipMemcpy(out, d_out, sizeof(long long) * 6 * nch, hipMemcpyDeviceToHost));
+  OPE_HIP(ctx, hipMemcpy(out, d_out, sizeof(long long) * 10 * nch, hipMemcpyDeviceToHost));
   (void)hipFree(d_T); (void)hipFree(d_out);
   return OPE_OK;
 }
