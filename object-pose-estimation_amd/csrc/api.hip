@@ -12,7 +12,9 @@ namespace ope {
 
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, const CloudView &, const BvhView &, const IcpState *, double *,
-                           int32_t *, float *, uint32_t *, uint32_t *);
+                           int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *);
+int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t, void *, size_t &);
+void fill_iota(hipStream_t, uint32_t *, uint32_t);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
 void launch_icp_update(hipStream_t, IcpState *, const double *);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
@@ -63,12 +65,24 @@ static double *sums_ptr(ope_ctx *ctx) {
 
 // One accumulate launch, optionally bracketed by HIP events on the launch stream (bench.py's roofline leg).
 static int enqueue_accumulate(ope_ctx *ctx) {
+  // re-sort the chunks by the cost they measured: after launches 1, 2, 4, ..., 32 and then every 32
+  static const bool no_plan = getenv("OPE_NO_PLAN") != nullptr;  // developer A/B switch
+  const int it_done = ctx->acc_launches++;
+  const uint32_t nch = (uint32_t)((ctx->run_src->n_valid + 63) / 64);
+  if (!no_plan && nch > 1 && it_done >= 1 && (((it_done & (it_done - 1)) == 0 && it_done <= 32) || it_done % 32 == 0)) {
+    size_t tb = ctx->plan_tmp_bytes;
+    if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
+                   ctx->d_plan_tmp, tb) != 0)
+      return set_err(ctx, OPE_EHIP, "chunk plan sort failed");
+    ctx->plan_valid = true;
+  }
   const ope_icp_params &p = ctx->run_params;
   const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
   const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
   if (timed) OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], ctx->stream));
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, ctx->run_src->view(), ctx->run_tgt->view(),
-                        ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint);
+                        ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
+                        ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost);
   if (timed) {
     OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
     ++ctx->prof_used;
@@ -126,6 +140,9 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
   if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
   if (ctx->d_hint) (void)hipFree(ctx->d_hint);
+  for (void *p : {(void *)ctx->d_chunk_cost, (void *)ctx->d_chunk_cost_sorted, (void *)ctx->d_chunk_ids,
+                  (void *)ctx->d_chunk_order, ctx->d_plan_tmp})
+    if (p) (void)hipFree(p);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->h_state) (void)hipHostFree(ctx->h_state);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -439,6 +456,32 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   }
   // every slot starts as "no correspondence" (non-finite points never get written)
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_corr_match, 0xff, sizeof(int32_t) * std::max<size_t>(src->n, 1), ctx->stream));
+  {
+    const size_t nch = (src->n_valid + 63) / 64 + 1;
+    if (ctx->chunk_cap < nch) {
+      for (void *p : {(void *)ctx->d_chunk_cost, (void *)ctx->d_chunk_cost_sorted, (void *)ctx->d_chunk_ids,
+                      (void *)ctx->d_chunk_order, ctx->d_plan_tmp})
+        if (p) (void)hipFree(p);
+      ctx->d_chunk_cost = ctx->d_chunk_cost_sorted = ctx->d_chunk_ids = ctx->d_chunk_order = nullptr;
+      ctx->d_plan_tmp = nullptr;
+      ctx->chunk_cap = 0;
+      OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_cost, 4 * nch));
+      OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_cost_sorted, 4 * nch));
+      OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_ids, 4 * nch));
+      OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_order, 4 * nch));
+      size_t tb = 0;
+      if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order,
+                     (uint32_t)nch, nullptr, tb) != 0)
+        return set_err(ctx, OPE_EHIP, "ope_icp_begin: rocprim temp-storage query failed");
+      OPE_HIP(ctx, hipMalloc(&ctx->d_plan_tmp, std::max<size_t>(tb, 16)));
+      ctx->plan_tmp_bytes = tb;
+      ctx->chunk_cap = nch;
+    }
+    fill_iota(ctx->stream, ctx->d_chunk_ids, (uint32_t)nch);
+    OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * nch, ctx->stream));
+    ctx->plan_valid = false;
+    ctx->acc_launches = 0;
+  }
   // no start hints yet: the first iteration walks top-down (hints belong to one (src, tgt) pairing)
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_hint, 0, sizeof(uint32_t) * std::max<size_t>(src->n, 1), ctx->stream));
 

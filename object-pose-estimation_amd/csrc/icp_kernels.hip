@@ -27,7 +27,7 @@ template <int MODE, bool NRM>
 __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 4) void icp_accumulate_kernel(
     CloudView src, BvhView tgt, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
-    uint32_t *__restrict__ hint) {
+    uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost) {
   if (st->done) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   __shared__ double s_red[BLOCK / 64][kNumSums];
@@ -56,10 +56,22 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 
   // order from a device-wide ticket counter (reset by the reduce kernel).  Which wave sums which chunk
   // only changes the fp32 partial-sum grouping, i.e. the last bits of the fp64 totals.
   const uint32_t lane_id = threadIdx.x & 63u;
+  // Static, cost-aware work distribution.  Query cost is very uneven (a clutter point far from the model
+  // walks 10-40x more nodes than a surface point) and the kernel ends with its slowest wave, so the
+  // 64-query chunks of the Morton order are dealt to the waves in "snake" order over a list sorted by
+  // the cost each chunk measured in an earlier iteration (heaviest chunks first, each wave's later
+  // chunks progressively lighter): longest-processing-time-first scheduling with no atomics.  (A
+  // device-wide ticket counter was tried first: ~24 k returning atomics on one word cost 130 us.)
   const uint32_t n_waves = gridDim.x * (BLOCK / 64);
-  for (uint32_t chunk = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);; chunk += n_waves) {
+  const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  const uint32_t n_chunks = (src.n_valid + 63u) / 64u;
+  for (uint32_t round = 0;; ++round) {
+    const uint32_t slot = round * n_waves + ((round & 1u) ? (n_waves - 1u - wave_id) : wave_id);
+    if (round * n_waves >= n_chunks) break;
+    if (slot >= n_chunks) continue;
+    const uint32_t chunk = chunk_order ? chunk_order[slot] : slot;
     const uint32_t base = chunk * 64u;
-    if (base >= src.n_valid) break;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const uint32_t i = base + lane_id;
     const bool active = i < src.n_valid;
     const float4 s = src.xyzw[active ? i : base];
@@ -144,6 +156,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 
         if (lane_id == (uint32_t)k) tot += (double)r;
       }
     }
+    if (lane_id == 0) chunk_cost[chunk] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
   }
 
   // wave -> block reduction in fp64, fixed order
@@ -632,18 +645,19 @@ __global__ __launch_bounds__(256) void fitness_kernel(CloudView q, BvhView tgt, 
 // host launchers (called from api.hip)
 void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, const CloudView &src,
                            const BvhView &tgt, const IcpState *st, double *partials, int32_t *corr_match,
-                           float *corr_d2, uint32_t *work_counter, uint32_t *hint) {
+                           float *corr_d2, uint32_t *work_counter, uint32_t *hint, const uint32_t *chunk_order,
+                           uint32_t *chunk_cost) {
   if (mode == 0) {
     if (nrm)
       hipLaunchKernelGGL((icp_accumulate_kernel<0, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, st,
-                         partials, corr_match, corr_d2, work_counter, hint);
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost);
     else
       hipLaunchKernelGGL((icp_accumulate_kernel<0, false>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, st,
-                         partials, corr_match, corr_d2, work_counter, hint);
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost);
   } else {
     const size_t lds = kKnnLdsBytes;
     hipLaunchKernelGGL((icp_accumulate_kernel<1, true>), dim3(nblocks), dim3(kKnnBlock), lds, stream, src, tgt, st,
-                       partials, corr_match, corr_d2, work_counter, hint);
+                       partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost);
   }
 }
 

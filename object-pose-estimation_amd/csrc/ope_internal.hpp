@@ -77,6 +77,12 @@ struct ope_ctx {
   uint32_t *d_work_counter = nullptr;  // ticket counter of the accumulate kernel's dynamic work queue
   int32_t *d_corr_match = nullptr;  // per sorted query: ORIGINAL target index or -1
   float *d_corr_d2 = nullptr;
+  // cost-aware chunk schedule of the accumulate kernel
+  uint32_t *d_chunk_cost = nullptr, *d_chunk_cost_sorted = nullptr, *d_chunk_ids = nullptr, *d_chunk_order = nullptr;
+  void *d_plan_tmp = nullptr;
+  size_t plan_tmp_bytes = 0, chunk_cap = 0;
+  bool plan_valid = false;
+  int acc_launches = 0;
   uint32_t *d_hint = nullptr;       // per sorted query: leaf (heap id) of the previous iteration's match, 0 = none
   size_t corr_cap = 0;
   ope::IcpState *h_state = nullptr;  // pinned

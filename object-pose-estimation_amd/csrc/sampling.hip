@@ -64,6 +64,27 @@ __global__ __launch_bounds__(256) void voxel_winner_kernel(CloudView c, float in
 
 }  // namespace ope
 
+namespace ope {
+
+__global__ void iota_kernel(uint32_t *v, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+
+// Chunk plan of the ICP accumulate kernel: chunk ids sorted by DESCENDING measured cost.
+// tmp/tmp_bytes: caller-provided scratch (call once with tmp == nullptr to size it).
+int chunk_plan(hipStream_t stream, const uint32_t *cost, uint32_t *cost_sorted, const uint32_t *ids, uint32_t *order,
+               uint32_t n, void *tmp, size_t &tmp_bytes) {
+  hipError_t e = rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, cost, cost_sorted, ids, order, n, 0, 32, stream);
+  return e == hipSuccess ? 0 : -1;
+}
+
+void fill_iota(hipStream_t stream, uint32_t *v, uint32_t n) {
+  hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, v, n);
+}
+
+}  // namespace ope
+
 using namespace ope;
 
 extern "C" int ope_uniform_sampling(ope_ctx *ctx, const ope_cloud *cloud, float leaf, int32_t *out_idx, size_t *n_out) {
