@@ -43,8 +43,9 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
-    ap.add_argument("--comm", default="torch", choices=["torch", "native"],
-                    help="N>1: all-reduce through torch.distributed (RCCL) or the library's own RCCL communicator")
+    ap.add_argument("--comm", default="native", choices=["torch", "native"],
+                    help="under torch.distributed.run: all-reduce through the library's own RCCL communicator (whole loop in "
+                         "C++, default) or through torch.distributed; 'native' falls back to 'torch' if RCCL init fails")
     ap.add_argument("--leaf", type=int, default=0, help="index leaf size override (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-coarse", action="store_true", help="skip the FPFH + SAC-IA initial alignment (identity start)")
@@ -97,9 +98,24 @@ def main() -> int:
         sums = torch.zeros(17, dtype=torch.float64, device="cuda")
         ctx.icp_set_sums_buffer(sums.data_ptr())
     elif launched:
-        ids = [ope.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(ids[0], world, rank)
+        ok = torch.ones(1, device="cuda")
+        try:
+            ids = [ope.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            ctx.comm_init(ids[0], world, rank)
+        except Exception as e:  # pragma: no cover - depends on the node's RCCL
+            print(f"[rank {rank}] native RCCL init failed ({e}); using torch.distributed", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # every rank must agree on the transport
+        if float(ok) == 0.0:
+            try:
+                ctx.comm_destroy()
+            except Exception:
+                pass
+            args.comm = "torch"
+            use_torch_comm = True
+            sums = torch.zeros(17, dtype=torch.float64, device="cuda")
+            ctx.icp_set_sums_buffer(sums.data_ptr())
 
     # ---- coarse stage (the "FPFH init" of config C3), as estimateCoarsePose runs it (poseestimator.cpp:16-73):
     # uniform keypoints (leaf 0.01) -> normals (k=30) -> FPFH (r=0.03) on both clouds -> SAC-IA (400 x 5 x 5).
