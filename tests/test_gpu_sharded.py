@@ -1,0 +1,81 @@
+"""Two ranks sharing the one GPU of the test box (gloo for the 17-double exchange, staged through the host
+because two ranks cannot form an RCCL communicator on one device): the sharded HIP path must give the same
+transform as the single-rank HIP path and as the oracle.  The 8-GPU RCCL run itself is the driver's."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, ns, nt, max_it, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ope = importlib.import_module("object-pose-estimation_amd")
+    sharded = importlib.import_module("object-pose-estimation_amd.sharded")
+    synth = importlib.import_module("object-pose-estimation_amd.synth")
+    torch.cuda.set_device(0)
+    src = synth.scene_cloud(ns); tgt = synth.model_surface(nt, 1)
+    lo, hi = sharded.shard_range(ns, world, rank)
+    ctx = ope.Context(0)
+    cs = ctx.upload(src[lo:hi]); ix = ctx.build_index(ctx.upload(tgt))
+    params = ope.default_icp_params(max_iterations=max_it, transformation_epsilon=1e-10, euclidean_fitness_epsilon=1e-10)
+
+    class HostStaged(sharded.GpuEngine):
+        """GpuEngine whose `sums` is exchanged through a host tensor (gloo)."""
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.dev_sums = self.sums
+            self.sums = torch.zeros(17, dtype=torch.float64)
+        def accumulate(self):
+            super().accumulate()
+            torch.cuda.synchronize()
+            self.sums.copy_(self.dev_sums.cpu())
+        def update(self):
+            self.dev_sums.copy_(self.sums)
+            super().update()
+
+    eng = HostStaged(ope, ctx, cs, ix, params, None, ns, nt)
+    res = sharded.run_sharded_icp(eng, max_it, check_every=5)
+    if rank == 0:
+        np.save(os.path.join(out_dir, f"T_w{world}.npy"), res.T)
+        np.save(os.path.join(out_dir, f"meta_w{world}.npy"), np.array([res.iterations, res.n_corr, res.state, res.align_strength]))
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_match_single_rank_and_oracle(tmp_path):
+    import oracle
+    synth = importlib.import_module("object-pose-estimation_amd.synth")
+    ns, nt, max_it = 40000, 8000, 25
+    for world in (1, 2):
+        mp.spawn(_worker, args=(world, _free_port(), ns, nt, max_it, str(tmp_path)), nprocs=world, join=True)
+    T1 = np.load(tmp_path / "T_w1.npy"); T2 = np.load(tmp_path / "T_w2.npy")
+    m1 = np.load(tmp_path / "meta_w1.npy"); m2 = np.load(tmp_path / "meta_w2.npy")
+    assert np.linalg.norm(T1.astype(np.float64) - T2.astype(np.float64)) < 1e-6
+    assert m1[0] == m2[0] and m1[1] == m2[1] == ns and m1[2] == m2[2]
+    assert m2[3] == pytest.approx(ns / (ns + nt))            # align strength uses the GLOBAL sizes
+    p = oracle.default_icp_params()
+    p.max_iterations = max_it; p.transformation_epsilon = 1e-10; p.euclidean_fitness_epsilon = 1e-10
+    p.acc_mode = 1; p.transform_mode = 1
+    ref = oracle.icp(synth.scene_cloud(ns), synth.model_surface(nt, 1), p)
+    assert np.linalg.norm(T2.astype(np.float64) - ref.T.astype(np.float64)) < 1e-4   # north_star tolerance
+    assert m2[0] == ref.iterations
