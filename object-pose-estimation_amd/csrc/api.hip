@@ -11,8 +11,9 @@
 namespace ope {
 
 // launchers defined in icp_kernels.hip
-void launch_icp_accumulate(hipStream_t, int, int, bool, const CloudView &, const BvhView &, const IcpState *, double *,
-                           int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *, uint32_t *);
+void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
+                           const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
+                           uint32_t *);
 int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t, void *, size_t &);
 void fill_iota(hipStream_t, uint32_t *, uint32_t);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
@@ -80,8 +81,9 @@ static int enqueue_accumulate(ope_ctx *ctx) {
   const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
   const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
   if (timed) OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], ctx->stream));
-  launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, ctx->run_src->view(), ctx->run_tgt->view(),
-                        ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
+  const bool recip = p.use_reciprocal != 0;
+  launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
+                        recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
                         ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost);
   if (timed) {
     OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
@@ -133,6 +135,7 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   ope_comm_destroy(ctx);
+  if (ctx->run_src_index) ope_index_free(ctx->run_src_index);
   for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
@@ -436,7 +439,8 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   ope_icp_params p;
   ope_icp_default_params(&p);
   if (params) p = *params;
-  if (p.use_reciprocal) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: reciprocal correspondences not implemented yet");
+  if (p.use_reciprocal && p.corr_mode != OPE_CORR_NEAREST)
+    return set_err(ctx, OPE_EINVAL, "ope_icp_begin: reciprocal correspondences are defined for 1-NN estimation only");
   const bool need_src_nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
   if (need_src_nrm && !src->d_nrm) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: source normals required but absent");
   if (p.use_surface_normal_rej && !tgt->d_nrm)
@@ -509,6 +513,25 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   h->k_normal_shooting = p.k_normal_shooting;
   h->use_surface_normal_rej = p.use_surface_normal_rej;
   h->use_self_occluded_rej = p.use_self_occluded_rej;
+  h->use_reciprocal = p.use_reciprocal;
+  {
+    // inverse of the guess (adjugate), rows layout
+    const double a = g[0], b = g[4], c = g[8], d = g[1], e = g[5], f = g[9], gg = g[2], hh = g[6], ii = g[10];
+    const double det = a * (e * ii - f * hh) - b * (d * ii - f * gg) + c * (d * hh - e * gg);
+    const double id = det != 0 ? 1.0 / det : 0.0;
+    const double M[9] = {(e * ii - f * hh) * id, (c * hh - b * ii) * id, (b * f - c * e) * id,
+                         (f * gg - d * ii) * id, (a * ii - c * gg) * id, (c * d - a * f) * id,
+                         (d * hh - e * gg) * id, (b * gg - a * hh) * id, (a * e - b * d) * id};
+    for (int r = 0; r < 3; ++r) {
+      h->Finv[4 * r + 0] = (float)M[3 * r]; h->Finv[4 * r + 1] = (float)M[3 * r + 1]; h->Finv[4 * r + 2] = (float)M[3 * r + 2];
+      h->Finv[4 * r + 3] = (float)(-(M[3 * r] * g[12] + M[3 * r + 1] * g[13] + M[3 * r + 2] * g[14]));
+    }
+  }
+  if (ctx->run_src_index) { ope_index_free(ctx->run_src_index); ctx->run_src_index = nullptr; }
+  if (p.use_reciprocal) {
+    int rc = ope_index_build(ctx, src, nullptr, &ctx->run_src_index);
+    if (rc != OPE_OK) return rc;
+  }
   OPE_HIP(ctx, hipMemcpyAsync(ctx->d_state, h, sizeof *h, hipMemcpyHostToDevice, ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 256, ctx->stream));
   // partial-sum rows of blocks that do not exist in this run must read as zero
@@ -521,7 +544,7 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   ctx->run_params = p;
   ctx->run_active = true;
   ctx->iters_enqueued = 0;
-  const int block = (p.corr_mode == OPE_CORR_NEAREST) ? kAccBlock : 256;
+  const int block = (p.corr_mode == OPE_CORR_NEAREST && !p.use_reciprocal) ? kAccBlock : ((p.corr_mode == OPE_CORR_NEAREST) ? kAccBlock : 256);
   ctx->acc_blocks = (int)std::min<size_t>(std::max<size_t>((src->n_valid + block - 1) / block, 1), kAccMaxBlocks);
   if (const char *e = getenv("OPE_ACC_BLOCKS")) ctx->acc_blocks = std::max(1, std::min(atoi(e), (int)kAccMaxBlocks));
   if (ctx->n_src_total <= 0) ctx->n_src_total = (int64_t)src->n;

@@ -23,9 +23,13 @@ namespace ope {
 
 // MODE 0: 1-NN correspondences.  MODE 1: normal shooting over the k nearest.
 // NRM: source/target normals present (rejectors and/or normal shooting).
-template <int MODE, bool NRM>
-__global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 4) void icp_accumulate_kernel(
-    CloudView src, BvhView tgt, const IcpState *__restrict__ st, double *__restrict__ partials,
+// RECIP: reciprocal correspondences (vPCL impl/correspondence_estimation_mod.hpp:216-303): keep (i, j) only
+// if the nearest SOURCE point of target point j is i again.  The reference searches a kd-tree rebuilt
+// over the transformed source every iteration; here the source index is built once in the source's own
+// frame and queried with F^-1 * t_j (a rigid map preserves the ranking up to fp32 rounding).
+template <int MODE, bool NRM, bool RECIP = false>
+__global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !RECIP) ? 8 : 4) void icp_accumulate_kernel(
+    CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost) {
   if (st->done) return;
@@ -99,6 +103,17 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, MODE == 0 ? 8 : 
       d2 = v.best;
       pos = found ? v.pos : 0;
       match = found ? __float_as_int(tgt.pts[pos].w) : -1;
+      if (RECIP) {
+        float G[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) G[k] = st->Finv[k];
+        const float4 t = tgt.pts[pos];
+        const float bx = xform_row(G + 0, t.x, t.y, t.z), by = xform_row(G + 4, t.x, t.y, t.z), bz = xform_row(G + 8, t.x, t.y, t.z);
+        NearestVisitor r{ok ? INFINITY : -INFINITY, kNoPos, 0};
+        if (ok) bvh_traverse(srcix, bx, by, bz, r, stk, BLOCK);
+        ok = ok && r.pos != kNoPos && !((double)r.best > max_d2) &&
+             __float_as_int(srcix.pts[r.pos].w) == __float_as_int(s.w);
+      }
     } else {
       float *ld = reinterpret_cast<float *>(s_dyn) + threadIdx.x;
       uint32_t *lp = reinterpret_cast<uint32_t *>(s_dyn + sizeof(float) * BLOCK * kKnnMaxK) + threadIdx.x;
@@ -388,6 +403,20 @@ __device__ __forceinline__ void icp_update_lane(IcpState *st, const double *S) {
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) st->Ff[4 * r + c] = (float)Fn[4 * c + r];
+  if (st->use_reciprocal) {
+    // inverse of the affine part by the adjugate (F is rigid unless the caller's guess was not)
+    const double a = Fn[0], b = Fn[4], c = Fn[8], d = Fn[1], e = Fn[5], f = Fn[9], g = Fn[2], h = Fn[6], i = Fn[10];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    const double id = 1.0 / det;
+    const double M[9] = {(e * i - f * h) * id, (c * h - b * i) * id, (b * f - c * e) * id,
+                         (f * g - d * i) * id, (a * i - c * g) * id, (c * d - a * f) * id,
+                         (d * h - e * g) * id, (b * g - a * h) * id, (a * e - b * d) * id};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      st->Finv[4 * r + 0] = (float)M[3 * r]; st->Finv[4 * r + 1] = (float)M[3 * r + 1]; st->Finv[4 * r + 2] = (float)M[3 * r + 2];
+      st->Finv[4 * r + 3] = (float)(-(M[3 * r] * Fn[12] + M[3 * r + 1] * Fn[13] + M[3 * r + 2] * Fn[14]));
+    }
+  }
   const int iterations = ++st->iterations;
 
   // DefaultConvergenceCriteria::hasConverged (uPCL) with the thresholds wired at icp_mod.hpp:164-168
@@ -643,22 +672,20 @@ __global__ __launch_bounds__(256) void fitness_kernel(CloudView q, BvhView tgt, 
 
 // ------------------------------------------------------------------------------------------
 // host launchers (called from api.hip)
-void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, const CloudView &src,
-                           const BvhView &tgt, const IcpState *st, double *partials, int32_t *corr_match,
-                           float *corr_d2, uint32_t *work_counter, uint32_t *hint, const uint32_t *chunk_order,
-                           uint32_t *chunk_cost) {
+void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, bool recip, const CloudView &src,
+                           const BvhView &tgt, const BvhView &srcix, const IcpState *st, double *partials,
+                           int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
+                           const uint32_t *chunk_order, uint32_t *chunk_cost) {
+#define OPE_LAUNCH_ACC(M, N, R, BLK, LDS)                                                                       \
+  hipLaunchKernelGGL((icp_accumulate_kernel<M, N, R>), dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, \
+                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost)
   if (mode == 0) {
-    if (nrm)
-      hipLaunchKernelGGL((icp_accumulate_kernel<0, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost);
-    else
-      hipLaunchKernelGGL((icp_accumulate_kernel<0, false>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost);
+    if (recip) { if (nrm) OPE_LAUNCH_ACC(0, true, true, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, true, kAccBlock, 0); }
+    else       { if (nrm) OPE_LAUNCH_ACC(0, true, false, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, false, kAccBlock, 0); }
   } else {
-    const size_t lds = kKnnLdsBytes;
-    hipLaunchKernelGGL((icp_accumulate_kernel<1, true>), dim3(nblocks), dim3(kKnnBlock), lds, stream, src, tgt, st,
-                       partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost);
+    OPE_LAUNCH_ACC(1, true, false, kKnnBlock, kKnnLdsBytes);
   }
+#undef OPE_LAUNCH_ACC
 }
 
 void launch_icp_reduce_update(hipStream_t stream, IcpState *st, const double *partials, double *S, int nblocks,

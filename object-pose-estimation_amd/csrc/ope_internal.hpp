@@ -45,6 +45,7 @@ struct IcpState {
   double F[16];        // final_transformation_, column-major, fp64
   double Tk[16];       // last incremental transformation_
   float Ff[12];        // F rounded to fp32: rows of the 3x4 [R|t] (r00 r01 r02 tx, …)
+  float Finv[12];      // inverse of F, same layout (reciprocal correspondences query the SOURCE index with it)
   double S[17];        // reduced sums of the current iteration
   double pivot[3];
   double prev_mse, cur_mse;
@@ -56,7 +57,7 @@ struct IcpState {
   long long n_corr;
   int max_iterations, failure_after_max_iter, min_correspondences;
   int iterations, converged, state, done;
-  int corr_mode, k_normal_shooting, use_surface_normal_rej, use_self_occluded_rej;
+  int corr_mode, k_normal_shooting, use_surface_normal_rej, use_self_occluded_rej, use_reciprocal;
 };
 
 constexpr int kNumSums = 17;
@@ -88,6 +89,7 @@ struct ope_ctx {
   ope::IcpState *h_state = nullptr;  // pinned
   const ope_cloud *run_src = nullptr;
   const ope_index *run_tgt = nullptr;
+  ope_index *run_src_index = nullptr;  // index over the source (reciprocal correspondences only)
   ope_icp_params run_params{};
   bool run_active = false;
   int acc_blocks = 0;

@@ -272,3 +272,19 @@ def test_stepwise_api_equals_run(ctx):
     b = ctx.icp_end()
     np.testing.assert_array_equal(a.T, b.T)
     assert a.iterations == b.iterations == 8
+
+
+def test_icp_reciprocal_correspondences_match_oracle(ctx):
+    """determineReciprocalCorrespondences (correspondence_estimation_mod.hpp:216-303)."""
+    P = synth.bumpy_torus(3000)
+    Q = apply(rigid(3, -2, 4, [0.004, -0.002, 0.003]), P)[::2]          # target = half of the moved cloud
+    kw = dict(max_iterations=12, use_reciprocal=1, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0)
+    out, cs, ix = gpu_icp(ctx, P, Q, mse_threshold_absolute=-1.0, **kw)
+    ref = oracle.icp(P, Q, orc_params(acc_mode=1, transform_mode=1, mse_threshold_absolute=-1.0, **kw))
+    assert out.iterations == ref.iterations == 12
+    assert abs(out.n_corr - ref.n_corr) <= 2 and 0 < out.n_corr <= len(Q)
+    assert frob(out.T, ref.T) < 1e-4
+    q, m, d = ctx.icp_correspondences(len(P))
+    assert len(set(m.tolist())) == len(m)                                  # reciprocal => one-to-one
+    common, ia, ib = np.intersect1d(q, ref.corr_q, return_indices=True)
+    assert len(common) >= ref.n_corr - 2 and (m[ia] == ref.corr_m[ib]).mean() > 0.999
