@@ -13,7 +13,8 @@ namespace ope {
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
-                           uint32_t *);
+                           uint32_t *, const uint32_t *);
+void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, uint32_t *);
 int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t, void *, size_t &);
 void fill_iota(hipStream_t, uint32_t *, uint32_t);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
@@ -75,6 +76,13 @@ static int enqueue_accumulate(ope_ctx *ctx) {
     if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
                    ctx->d_plan_tmp, tb) != 0)
       return set_err(ctx, OPE_EHIP, "chunk plan sort failed");
+    // chunks costlier than `factor` x the median chunk are walked by 8-lane groups.  Measured: with spare wave
+    // slots (fewer chunks than resident waves, e.g. a 1/8 shard) 2x is best (C2: 115 -> 79 us); on a saturated
+    // GPU the 8x lane cost must be reserved for the real tail, 4-6x (C3: 251 -> 225 us).
+    static const float heavy_env = [] { const char *e = getenv("OPE_HEAVY_FACTOR"); return e ? (float)atof(e) : -1.0f; }();
+    const uint32_t resident_waves = (uint32_t)ctx->acc_blocks * (kAccBlock / 64);
+    const float heavy_factor = heavy_env >= 0.f ? heavy_env : (nch <= resident_waves ? 2.0f : 5.0f);
+    plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch, heavy_factor, ctx->d_work_counter + 8);
     ctx->plan_valid = true;
   }
   const ope_icp_params &p = ctx->run_params;
@@ -84,7 +92,7 @@ static int enqueue_accumulate(ope_ctx *ctx) {
   const bool recip = p.use_reciprocal != 0;
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
                         recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
-                        ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost);
+                        ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8);
   if (timed) {
     OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
     ++ctx->prof_used;

@@ -31,9 +31,11 @@ template <int MODE, bool NRM, bool RECIP = false>
 __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !RECIP) ? 8 : 4) void icp_accumulate_kernel(
     CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
-    uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost) {
+    uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
+    const uint32_t *__restrict__ plan_info) {
   if (st->done) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
+  constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
   __shared__ double s_red[BLOCK / 64][kNumSums];
   __shared__ float s_stk[kMaxDepth + 1][BLOCK];  // pending-sibling bounds of the traversal
   float *stk = &s_stk[0][threadIdx.x];
@@ -50,10 +52,9 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   const double max_dist_unsq = st->max_corr_dist;
   const int kk = st->k_normal_shooting;
 
-  // Running sums: lane k (k < 17) of each wave owns component k of {n, Σs, Σt, Σ t sᵀ, Σd²}.  The 17
-  // per-lane terms of a chunk are wave-reduced right away (fp32 butterflies, fixed order), so only
-  // this one fp64 register stays live across the traversal instead of 17 accumulators.
-  double tot = 0.0;
+  // Running sums {n, Σs, Σt, Σ t sᵀ, Σd²}: one set of 17 fp64 LDS slots per wave (s_red), so no
+  // accumulator register stays live across the traversal.
+  if ((threadIdx.x & 63u) < (uint32_t)kNumSums) s_red[threadIdx.x >> 6][threadIdx.x & 63u] = 0.0;
 
   // Dynamic work distribution: query cost is very uneven (a clutter point far from the model walks
   // 10-40x more nodes than a surface point), so each WAVE pulls the next 64-query chunk of the Morton
@@ -66,18 +67,25 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   // the cost each chunk measured in an earlier iteration (heaviest chunks first, each wave's later
   // chunks progressively lighter): longest-processing-time-first scheduling with no atomics.  (A
   // device-wide ticket counter was tried first: ~24 k returning atomics on one word cost 130 us.)
+  // The n_heavy costliest chunks (clutter: long private walks) are split into eight slots each and walked
+  // by 8-lane groups (bvh_traverse_oct); all other chunks take one slot and one lane per query.
   const uint32_t n_waves = gridDim.x * (BLOCK / 64);
   const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
   const uint32_t n_chunks = (src.n_valid + 63u) / 64u;
+  const uint32_t n_heavy = (OCT_OK && chunk_order) ? min(plan_info[0], n_chunks) : 0u;
+  const uint32_t n_slots = n_chunks + 7u * n_heavy;
   for (uint32_t round = 0;; ++round) {
+    if (round * n_waves >= n_slots) break;
     const uint32_t slot = round * n_waves + ((round & 1u) ? (n_waves - 1u - wave_id) : wave_id);
-    if (round * n_waves >= n_chunks) break;
-    if (slot >= n_chunks) continue;
-    const uint32_t chunk = chunk_order ? chunk_order[slot] : slot;
+    if (slot >= n_slots) continue;
+    const bool oct = slot < 8u * n_heavy;
+    const uint32_t ord = oct ? (slot >> 3) : (slot - 7u * n_heavy);
+    const uint32_t chunk = chunk_order ? chunk_order[ord] : ord;
     const uint32_t base = chunk * 64u;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-    const uint32_t i = base + lane_id;
+    const uint32_t i = oct ? (base + (slot & 7u) * 8u + (lane_id >> 3)) : (base + lane_id);
     const bool active = i < src.n_valid;
+    const bool owner = active && (!oct || (lane_id & 7u) == 0u);  // the one lane that reports a query
     const float4 s = src.xyzw[active ? i : base];
     const float x = xform_row(F + 0, s.x, s.y, s.z);
     const float y = xform_row(F + 4, s.x, s.y, s.z);
@@ -96,8 +104,12 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     if (MODE == 0) {
       NearestVisitor v{active ? INFINITY : -INFINITY, kNoPos, 0};
       // start at the leaf that held this query's nearest neighbour one iteration ago (0 = none yet)
-      if (active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, hint[i]);
-      if (active) hint[i] = v.leaf;
+      if (OCT_OK && oct) {
+        if (active) bvh_traverse_oct(tgt, x, y, z, v, &s_stk[0][threadIdx.x & ~7u], BLOCK, hint[i]);
+      } else {
+        if (active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, hint[i]);
+      }
+      if (owner) hint[i] = v.leaf;
       const bool found = active && v.pos != kNoPos;
       ok = found && !((double)v.best > max_d2);
       d2 = v.best;
@@ -148,35 +160,39 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       const double score = (double)nx * (-(double)x / sl) + (double)ny * (-(double)y / sl) + (double)nz * (-(double)z / sl);
       ok = score > thr_so;
     }
-    if (active) {
+    ok = ok && owner;
+    if (owner) {
       corr_match[i] = ok ? match : -1;
       corr_d2[i] = d2;
     }
     {
+      // fp64 terms: differences and products of fp32 values are exact in fp64, so the 17 sums do not
+      // depend (beyond 1e-16) on how queries are grouped into lanes, chunks, waves or ranks
       const float4 t = tgt.pts[ok ? pos : 0];
-      const float w = ok ? 1.f : 0.f;
-      const float sx = w * (x - psx), sy = w * (y - psy), sz = w * (z - psz);
-      const float tx = w * (t.x - psx), ty = w * (t.y - psy), tz = w * (t.z - psz);
-      float term[kNumSums];
+      const double sx = (double)x - (double)psx, sy = (double)y - (double)psy, sz = (double)z - (double)psz;
+      const double tx = (double)t.x - (double)psx, ty = (double)t.y - (double)psy, tz = (double)t.z - (double)psz;
+      // 16-lane row sums by DPP (pure VALU), then one ds_add_f64 per row and component into the wave's
+      // 17 LDS slots (a full 64-lane fp64 butterfly cost ~200 dependent ds_bpermutes per chunk)
+      const double w = ok ? 1.0 : 0.0;
+      double term[kNumSums];
       term[0] = w;
-      term[1] = sx; term[2] = sy; term[3] = sz;
-      term[4] = tx; term[5] = ty; term[6] = tz;
-      term[7] = tx * sx; term[8] = tx * sy; term[9] = tx * sz;
-      term[10] = ty * sx; term[11] = ty * sy; term[12] = ty * sz;
-      term[13] = tz * sx; term[14] = tz * sy; term[15] = tz * sz;
-      term[16] = ok ? d2 : 0.f;
+      term[1] = w * sx; term[2] = w * sy; term[3] = w * sz;
+      term[4] = w * tx; term[5] = w * ty; term[6] = w * tz;
+      term[7] = w * (tx * sx); term[8] = w * (tx * sy); term[9] = w * (tx * sz);
+      term[10] = w * (ty * sx); term[11] = w * (ty * sy); term[12] = w * (ty * sz);
+      term[13] = w * (tz * sx); term[14] = w * (tz * sy); term[15] = w * (tz * sz);
+      term[16] = ok ? (double)d2 : 0.0;
+      double *acc = s_red[threadIdx.x >> 6];
 #pragma unroll
       for (int k = 0; k < kNumSums; ++k) {
-        const float r = wave_sum_f32(term[k]);
-        if (lane_id == (uint32_t)k) tot += (double)r;
+        const double r = row16_sum(term[k]);
+        if ((lane_id & 15u) == 0u) unsafeAtomicAdd(acc + k, r);
       }
     }
-    if (lane_id == 0) chunk_cost[chunk] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
+    if (lane_id == 0 && !oct) chunk_cost[chunk] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
   }
 
-  // wave -> block reduction in fp64, fixed order
-  const int wave = threadIdx.x >> 6;
-  if (lane_id < (uint32_t)kNumSums) s_red[wave][lane_id] = tot;
+  // wave slots -> block partial, fixed order
   __syncthreads();
   if (threadIdx.x < kNumSums) {
     double v = 0.0;
@@ -675,10 +691,10 @@ __global__ __launch_bounds__(256) void fitness_kernel(CloudView q, BvhView tgt, 
 void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, bool recip, const CloudView &src,
                            const BvhView &tgt, const BvhView &srcix, const IcpState *st, double *partials,
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
-                           const uint32_t *chunk_order, uint32_t *chunk_cost) {
+                           const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info) {
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS)                                                                       \
   hipLaunchKernelGGL((icp_accumulate_kernel<M, N, R>), dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, \
-                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost)
+                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info)
   if (mode == 0) {
     if (recip) { if (nrm) OPE_LAUNCH_ACC(0, true, true, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, true, kAccBlock, 0); }
     else       { if (nrm) OPE_LAUNCH_ACC(0, true, false, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, false, kAccBlock, 0); }

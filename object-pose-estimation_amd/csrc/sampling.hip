@@ -79,6 +79,26 @@ int chunk_plan(hipStream_t stream, const uint32_t *cost, uint32_t *cost_sorted, 
   return e == hipSuccess ? 0 : -1;
 }
 
+// plan_info[0] = number of "heavy" chunks: those costlier than factor x the median chunk (capped at n/4)
+__global__ void plan_heavy_kernel(const uint32_t *cost_sorted_desc, uint32_t n, float factor, uint32_t *plan_info) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t nh = 0;
+  if (factor > 0.f && n >= 8) {
+    const float thr = factor * (float)cost_sorted_desc[n / 2];
+    uint32_t lo = 0, hi = n / 4;  // first index whose cost <= thr
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) / 2;
+      if ((float)cost_sorted_desc[mid] > thr) lo = mid + 1; else hi = mid;
+    }
+    nh = lo;
+  }
+  plan_info[0] = nh;
+}
+
+void plan_heavy(hipStream_t stream, const uint32_t *cost_sorted_desc, uint32_t n, float factor, uint32_t *plan_info) {
+  hipLaunchKernelGGL(plan_heavy_kernel, dim3(1), dim3(64), 0, stream, cost_sorted_desc, n, factor, plan_info);
+}
+
 void fill_iota(hipStream_t stream, uint32_t *v, uint32_t n) {
   hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, v, n);
 }

@@ -270,7 +270,8 @@ def test_stepwise_api_equals_run(ctx):
         ctx.icp_accumulate()
         ctx.icp_update()
     b = ctx.icp_end()
-    np.testing.assert_array_equal(a.T, b.T)
+    # the cost-aware chunk schedule follows measured cycles, so fp64 partial sums may group differently
+    np.testing.assert_allclose(a.T, b.T, atol=1e-6)
     assert a.iterations == b.iterations == 8
 
 
