@@ -111,6 +111,12 @@ enum { /* DefaultConvergenceCriteria::ConvergenceState, default_convergence_crit
 };
 
 enum { OPE_CORR_NEAREST = 0, OPE_CORR_NORMAL_SHOOTING = 1 };
+/* transformation estimation: SVD/Umeyama (poseestimator.cpp:306,341), or the linearised point-to-plane
+ * estimator that IterativeClosestPointWithNormals defaults to (icp_mod.h:352-357; needs TARGET normals).
+ * BuildModel selects the LM point-to-plane estimator (regmeshpcd.cpp:162,193): same cost, non-linear solve. */
+enum { OPE_EST_SVD = 0, OPE_EST_POINT_TO_PLANE_LLS = 1 };
+#define OPE_NUM_SUMS 17     /* {n, Σs, Σt, Σ t sᵀ, Σd²} */
+#define OPE_NUM_SUMS_MAX 44 /* + upper triangle of AᵀA (21) and Aᵀb (6) for point-to-plane */
 
 typedef struct {
   /* Registration defaults, registration_mod.h:106-118 */
@@ -134,6 +140,7 @@ typedef struct {
   int failure_after_max_iter;    /* 0 */
   /* host polling period for the on-device convergence flag (iterations); 0 = only at the end */
   int check_every;
+  int estimator; /* OPE_EST_* */
 } ope_icp_params;
 
 typedef struct {
@@ -162,10 +169,11 @@ int ope_icp_run(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const 
 int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float *guess,
                   const ope_icp_params *params);
 int ope_icp_accumulate(ope_ctx *ctx);
-/* Device pointer to the 17 fp64 sums {n, Σs[3], Σt[3], Σ t sᵀ[9], Σd²} (about the index pivot). */
+/* Device pointer to the fp64 sums {n, Σs[3], Σt[3], Σ t sᵀ[9], Σd²} (about the index pivot), followed for the
+ * point-to-plane estimator by 21 + 6 normal-equation sums: all-reduce OPE_NUM_SUMS (or OPE_NUM_SUMS_MAX) doubles. */
 void *ope_icp_sums_device(ope_ctx *ctx);
 int ope_icp_update(ope_ctx *ctx);
-/* Use a caller-owned device buffer of 17 doubles for the sums (e.g. a torch tensor that
+/* Use a caller-owned device buffer of OPE_NUM_SUMS_MAX doubles for the sums (e.g. a torch tensor that
  * torch.distributed all-reduces); NULL restores the internal buffer. */
 int ope_icp_set_sums_buffer(ope_ctx *ctx, void *device_ptr);
 /* Enqueue n whole iterations (accumulate -> reduce -> [RCCL all-reduce if ope_comm_init_rank was

@@ -23,6 +23,8 @@ LIB_PATH = os.path.join(_HERE, "libope_hip.so")
 OPE_OK, OPE_EINVAL, OPE_ENODEV, OPE_EHIP, OPE_ENOMEM, OPE_ESTATE, OPE_ECOMM, OPE_EEMPTY = 0, -1, -2, -3, -4, -5, -6, -7
 CONV_NAMES = ["NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE", "NO_CORRESPONDENCES"]
 CORR_NEAREST, CORR_NORMAL_SHOOTING = 0, 1
+EST_SVD, EST_POINT_TO_PLANE_LLS = 0, 1
+NUM_SUMS, NUM_SUMS_MAX = 17, 44
 COMM_ID_BYTES = 128
 
 
@@ -62,6 +64,7 @@ class IcpParams(C.Structure):
         ("mse_threshold_absolute", C.c_double),
         ("failure_after_max_iter", C.c_int),
         ("check_every", C.c_int),
+        ("estimator", C.c_int),
     ]
 
 

@@ -86,7 +86,8 @@ static int enqueue_accumulate(ope_ctx *ctx) {
     ctx->plan_valid = true;
   }
   const ope_icp_params &p = ctx->run_params;
-  const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
+  const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej ||
+                   p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
   const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
   if (timed) OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], ctx->stream));
   const bool recip = p.use_reciprocal != 0;
@@ -129,7 +130,7 @@ int ope_ctx_create(ope_ctx **out, int device_ordinal) {
   }
   ctx->stream = ctx->own_stream;
   if (hipMalloc(&ctx->d_state, sizeof(IcpState)) != hipSuccess ||
-      hipMalloc(&ctx->d_partials, sizeof(double) * kNumSums * kAccMaxBlocks) != hipSuccess ||
+      hipMalloc(&ctx->d_partials, sizeof(double) * kNumSumsMax * kAccMaxBlocks) != hipSuccess ||
       hipMalloc((void **)&ctx->d_work_counter, 256) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState)) != hipSuccess) {
     ope_ctx_destroy(ctx);
@@ -430,6 +431,7 @@ void ope_icp_default_params(ope_icp_params *p) {
   p->mse_threshold_absolute = 1e-12;
   p->failure_after_max_iter = 0;
   p->check_every = 10;
+  p->estimator = OPE_EST_SVD;
 }
 
 int ope_icp_set_global_sizes(ope_ctx *ctx, int64_t n_src_total, int64_t n_tgt_total) {
@@ -451,6 +453,8 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: reciprocal correspondences are defined for 1-NN estimation only");
   const bool need_src_nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
   if (need_src_nrm && !src->d_nrm) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: source normals required but absent");
+  if (p.estimator == OPE_EST_POINT_TO_PLANE_LLS && !tgt->d_nrm)
+    return set_err(ctx, OPE_EINVAL, "ope_icp_begin: the point-to-plane estimator needs target normals (build the index from a cloud with normals)");
   if (p.use_surface_normal_rej && !tgt->d_nrm)
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: target normals required (build the index from a cloud with normals)");
   if (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && (p.k_normal_shooting < 1 || p.k_normal_shooting > 32))
@@ -522,6 +526,7 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   h->use_surface_normal_rej = p.use_surface_normal_rej;
   h->use_self_occluded_rej = p.use_self_occluded_rej;
   h->use_reciprocal = p.use_reciprocal;
+  h->estimator = p.estimator;
   {
     // inverse of the guess (adjugate), rows layout
     const double a = g[0], b = g[4], c = g[8], d = g[1], e = g[5], f = g[9], gg = g[2], hh = g[6], ii = g[10];
@@ -543,7 +548,7 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   OPE_HIP(ctx, hipMemcpyAsync(ctx->d_state, h, sizeof *h, hipMemcpyHostToDevice, ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 256, ctx->stream));
   // partial-sum rows of blocks that do not exist in this run must read as zero
-  OPE_HIP(ctx, hipMemsetAsync(ctx->d_partials, 0, sizeof(double) * kNumSums * kAccMaxBlocks, ctx->stream));
+  OPE_HIP(ctx, hipMemsetAsync(ctx->d_partials, 0, sizeof(double) * kNumSumsMax * kAccMaxBlocks, ctx->stream));
   // the pinned block is reused for read-back: make sure the upload is finished with it first
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
@@ -589,7 +594,7 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
     if (rc != OPE_OK) return rc;
     if (sharded) {
       launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
-      rc = comm_allreduce_sums(ctx, sums_ptr(ctx), kNumSums);
+      rc = comm_allreduce_sums(ctx, sums_ptr(ctx), ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LLS ? kNumSumsMax : kNumSums);
       if (rc != OPE_OK) return rc;
       launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx));
     } else if (split_update) {

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   if (st->done) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
-  __shared__ double s_red[BLOCK / 64][kNumSums];
+  __shared__ double s_red[BLOCK / 64][kNumSumsMax];
   __shared__ float s_stk[kMaxDepth + 1][BLOCK];  // pending-sibling bounds of the traversal
   float *stk = &s_stk[0][threadIdx.x];
   extern __shared__ unsigned char s_dyn[];  // MODE 1: k-NN lists
@@ -54,7 +54,8 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
 
   // Running sums {n, Σs, Σt, Σ t sᵀ, Σd²}: one set of 17 fp64 LDS slots per wave (s_red), so no
   // accumulator register stays live across the traversal.
-  if ((threadIdx.x & 63u) < (uint32_t)kNumSums) s_red[threadIdx.x >> 6][threadIdx.x & 63u] = 0.0;
+  if ((threadIdx.x & 63u) < (uint32_t)kNumSumsMax) s_red[threadIdx.x >> 6][threadIdx.x & 63u] = 0.0;
+  const bool p2p = NRM && st->estimator == OPE_EST_POINT_TO_PLANE_LLS;
 
   // Dynamic work distribution: query cost is very uneven (a clutter point far from the model walks
   // 10-40x more nodes than a surface point), so each WAVE pulls the next 64-query chunk of the Morton
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     const float y = xform_row(F + 4, s.x, s.y, s.z);
     const float z = xform_row(F + 8, s.x, s.y, s.z);
     float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (NRM) {
+    if (NRM && src.nrm != nullptr) {
       const float4 n4 = src.nrm[active ? i : base];
       nx = rot_row(F + 0, n4.x, n4.y, n4.z);
       ny = rot_row(F + 4, n4.x, n4.y, n4.z);
@@ -188,13 +189,39 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
         const double r = row16_sum(term[k]);
         if ((lane_id & 15u) == 0u) unsafeAtomicAdd(acc + k, r);
       }
+      if (NRM && p2p) {
+        // TransformationEstimationPointToPlaneLLS: row v = (s x n, n), right-hand side d = n . (t - s);
+        // the reference forms these products in float (operands are const float&), sums in double
+        const float4 tn = tgt.nrm[ok ? pos : 0];
+        const float v0 = __fsub_rn(__fmul_rn(tn.z, y), __fmul_rn(tn.y, z));
+        const float v1 = __fsub_rn(__fmul_rn(tn.x, z), __fmul_rn(tn.z, x));
+        const float v2 = __fsub_rn(__fmul_rn(tn.y, x), __fmul_rn(tn.x, y));
+        const float dd = __fsub_rn(__fsub_rn(__fsub_rn(__fadd_rn(__fadd_rn(__fmul_rn(tn.x, t.x), __fmul_rn(tn.y, t.y)), __fmul_rn(tn.z, t.z)),
+                                                         __fmul_rn(tn.x, x)), __fmul_rn(tn.y, y)), __fmul_rn(tn.z, z));
+        const double v[6] = {w * (double)v0, w * (double)v1, w * (double)v2, w * (double)tn.x, w * (double)tn.y, w * (double)tn.z};
+        int slot = kNumSums;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = r; c < 6; ++c) {
+            const double sum = row16_sum(v[r] * v[c]);
+            if ((lane_id & 15u) == 0u) unsafeAtomicAdd(acc + slot, sum);
+            ++slot;
+          }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const double sum = row16_sum(v[r] * (double)dd);
+          if ((lane_id & 15u) == 0u) unsafeAtomicAdd(acc + slot, sum);
+          ++slot;
+        }
+      }
     }
     if (lane_id == 0 && !oct) chunk_cost[chunk] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
   }
 
   // wave slots -> block partial, fixed order
   __syncthreads();
-  if (threadIdx.x < kNumSums) {
+  if (threadIdx.x < (p2p ? kNumSumsMax : kNumSums)) {
     double v = 0.0;
 #pragma unroll
     for (int w = 0; w < BLOCK / 64; ++w) v += s_red[w][threadIdx.x];
@@ -386,6 +413,62 @@ __device__ __forceinline__ void umeyama_from_sums(const double *S, const double 
   T[15] = 1.0;
 }
 
+// x = (AᵀA)^-1 Aᵀb by Cholesky (static indices: registers only), then PCL's constructTransformationMatrix.
+// N holds the upper triangle of AᵀA row by row (21 values) followed by Aᵀb (6).
+__device__ __forceinline__ bool point_to_plane_from_sums(const double *N, double (&T)[16]) {
+  double A[6][6], b[6];
+  {
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = r; c < 6; ++c) { A[r][c] = N[k]; A[c][r] = N[k]; ++k; }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) b[r] = N[21 + r];
+  }
+  double L[6][6];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    ok = ok && (d > 0.0);
+    const double inv = ok ? fast_rsqrt(d) : 0.0;
+    L[j][j] = d * inv;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double v = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+      L[i][j] = v * inv;
+    }
+  }
+  if (!ok) return false;
+  double yv[6], x[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double v = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= L[i][k] * yv[k];
+    yv[i] = v * fast_rcp(L[i][i]);
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double v = yv[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k];
+    x[i] = v * fast_rcp(L[i][i]);
+  }
+  const double sa = sin(x[0]), ca = cos(x[0]), sb = sin(x[1]), cb = cos(x[1]), sg = sin(x[2]), cg = cos(x[2]);
+  // column-major
+  T[0] = cg * cb;                 T[4] = -sg * ca + cg * sb * sa;  T[8] = sg * sa + cg * sb * ca;   T[12] = x[3];
+  T[1] = sg * cb;                 T[5] = cg * ca + sg * sb * sa;   T[9] = -cg * sa + sg * sb * ca;  T[13] = x[4];
+  T[2] = -sb;                     T[6] = cb * sa;                  T[10] = cb * ca;                 T[14] = x[5];
+  T[3] = 0.0; T[7] = 0.0; T[11] = 0.0; T[15] = 1.0;
+  return true;
+}
+
 __device__ __forceinline__ void icp_update_lane(IcpState *st, const double *S) {
   const double n = S[0];
   st->n_corr = (long long)n;
@@ -397,7 +480,17 @@ __device__ __forceinline__ void icp_update_lane(IcpState *st, const double *S) {
     return;
   }
   double Tk[16];
-  umeyama_from_sums(S, st->pivot, Tk);
+  if (st->estimator == OPE_EST_POINT_TO_PLANE_LLS) {
+    if (!point_to_plane_from_sums(S + kNumSums, Tk)) {
+      // singular normal equations: no usable step (PCL would propagate NaNs); stop with what we have
+      st->state = OPE_CONV_NO_CORRESPONDENCES;
+      st->converged = 0;
+      st->done = 1;
+      return;
+    }
+  } else {
+    umeyama_from_sums(S, st->pivot, Tk);
+  }
   // transformation_ is a Matrix4f in the reference
   float Tf[16];
 #pragma unroll
@@ -481,36 +574,41 @@ __global__ __launch_bounds__(kRedBlock) void icp_reduce_update_kernel(IcpState *
   // ds_bpermutes and took 15 us): rows -> 256 per-thread sums -> 8 group sums -> total.
   __shared__ double s_part[kNumSums][kRedBlock];
   __shared__ double s_grp[kNumSums][8];
-  __shared__ double s_S[kNumSums];
+  __shared__ double s_S[kNumSumsMax];
   __shared__ IcpState s_st;
   if (do_update) state_to_lds(&s_st, st);
+  const int nsums = (st->estimator == OPE_EST_POINT_TO_PLANE_LLS) ? kNumSumsMax : kNumSums;
+  for (int base = 0; base < nsums; base += kNumSums) {   // 17 components per pass through the LDS tree
 #pragma unroll
-  for (int k = 0; k < kNumSums; ++k) {
-    double v = 0.0;
+    for (int k = 0; k < kNumSums; ++k) {
+      double v = 0.0;
+      if (base + k < nsums) {
 #pragma unroll
-    for (int j = 0; j < kAccMaxBlocks / kRedBlock; ++j) {
-      // unconditional, independent loads: rows >= nblocks were zero-filled by ope_icp_begin
-      v += partials[k * kAccMaxBlocks + (int)threadIdx.x + j * kRedBlock];
+        for (int j = 0; j < kAccMaxBlocks / kRedBlock; ++j)
+          // unconditional, independent loads: rows >= nblocks were zero-filled by ope_icp_begin
+          v += partials[(base + k) * kAccMaxBlocks + (int)threadIdx.x + j * kRedBlock];
+      }
+      s_part[k][threadIdx.x] = v;
     }
-    s_part[k][threadIdx.x] = v;
-  }
-  __syncthreads();
-  {
-    const int k = threadIdx.x >> 3, g = threadIdx.x & 7;
-    if (k < kNumSums) {
+    __syncthreads();
+    {
+      const int k = threadIdx.x >> 3, g = threadIdx.x & 7;
+      if (k < kNumSums) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < kRedBlock / 8; ++j) v += s_part[k][g * (kRedBlock / 8) + j];
+        s_grp[k][g] = v;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumSums && base + (int)threadIdx.x < nsums) {
       double v = 0.0;
 #pragma unroll
-      for (int j = 0; j < kRedBlock / 8; ++j) v += s_part[k][g * (kRedBlock / 8) + j];
-      s_grp[k][g] = v;
+      for (int g = 0; g < 8; ++g) v += s_grp[threadIdx.x][g];
+      S[base + threadIdx.x] = v;
+      s_S[base + threadIdx.x] = v;
     }
-  }
-  __syncthreads();
-  if (threadIdx.x < kNumSums) {
-    double v = 0.0;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) v += s_grp[threadIdx.x][g];
-    S[threadIdx.x] = v;
-    s_S[threadIdx.x] = v;
+    __syncthreads();
   }
   if (do_update) {
     __syncthreads();
@@ -522,10 +620,10 @@ __global__ __launch_bounds__(kRedBlock) void icp_reduce_update_kernel(IcpState *
 
 __global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, const double *S) {
   if (st->done) return;
-  __shared__ double s_S[kNumSums];
+  __shared__ double s_S[kNumSumsMax];
   __shared__ IcpState s_st;
   state_to_lds(&s_st, st);
-  if (threadIdx.x < kNumSums) s_S[threadIdx.x] = S[threadIdx.x];
+  if (threadIdx.x < kNumSumsMax) s_S[threadIdx.x] = S[threadIdx.x];
   __syncthreads();
   if (threadIdx.x == 0) icp_update_lane(&s_st, s_S);
   __syncthreads();

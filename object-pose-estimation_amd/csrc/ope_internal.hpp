@@ -46,7 +46,7 @@ struct IcpState {
   double Tk[16];       // last incremental transformation_
   float Ff[12];        // F rounded to fp32: rows of the 3x4 [R|t] (r00 r01 r02 tx, …)
   float Finv[12];      // inverse of F, same layout (reciprocal correspondences query the SOURCE index with it)
-  double S[17];        // reduced sums of the current iteration
+  double S[44];        // reduced sums of the current iteration (17, or 44 with point-to-plane)
   double pivot[3];
   double prev_mse, cur_mse;
   double rotation_threshold, translation_threshold;
@@ -57,10 +57,11 @@ struct IcpState {
   long long n_corr;
   int max_iterations, failure_after_max_iter, min_correspondences;
   int iterations, converged, state, done;
-  int corr_mode, k_normal_shooting, use_surface_normal_rej, use_self_occluded_rej, use_reciprocal;
+  int corr_mode, k_normal_shooting, use_surface_normal_rej, use_self_occluded_rej, use_reciprocal, estimator;
 };
 
 constexpr int kNumSums = 17;
+constexpr int kNumSumsMax = 44;  // + 21 (upper triangle of AᵀA) + 6 (Aᵀb) for the point-to-plane estimator
 constexpr int kAccBlock = 512;       // threads per block of the accumulate kernel
 constexpr int kAccMaxBlocks = 1024;  // partials rows; the update kernel reduces them with 1024 threads
 
@@ -74,7 +75,7 @@ struct ope_ctx {
 
   // ICP run state
   ope::IcpState *d_state = nullptr;
-  double *d_partials = nullptr;   // [kNumSums][kAccMaxBlocks]
+  double *d_partials = nullptr;   // [kNumSumsMax][kAccMaxBlocks]
   uint32_t *d_work_counter = nullptr;  // ticket counter of the accumulate kernel's dynamic work queue
   int32_t *d_corr_match = nullptr;  // per sorted query: ORIGINAL target index or -1
   float *d_corr_d2 = nullptr;

@@ -43,7 +43,7 @@ class GpuEngine:
         self.ope, self.ctx = ope, ctx
         self.src, self.tgt, self.params, self.guess = src_cloud, tgt_index, params, guess
         self.n_src_total, self.n_tgt_total = n_src_total, n_tgt_total
-        self.sums = torch.zeros(17, dtype=torch.float64, device=f"cuda:{ctx.device}")
+        self.sums = torch.zeros(ope.NUM_SUMS_MAX, dtype=torch.float64, device=f"cuda:{ctx.device}")
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.icp_set_sums_buffer(self.sums.data_ptr())
 

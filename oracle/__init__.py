@@ -58,6 +58,7 @@ class IcpParams(C.Structure):
         ("mse_threshold_absolute", C.c_double),
         ("failure_after_max_iter", C.c_int),
         ("acc_mode", C.c_int),
+        ("estimator", C.c_int),
         ("transform_mode", C.c_int),
     ]
 
@@ -111,6 +112,8 @@ def _declare(L):
     L.orc_umeyama_from_sums.restype = C.c_int
     L.orc_umeyama_from_sums.argtypes = [_dp, _dp, _fp]
     L.orc_svd3.argtypes = [_dp, _dp, _dp, _dp]
+    L.orc_point_to_plane_lls.restype = C.c_int
+    L.orc_point_to_plane_lls.argtypes = [_fp, _fp, _fp, C.c_int, _fp]
     L.orc_convergence_init.argtypes = [C.POINTER(Convergence)]
     L.orc_convergence_step.restype = C.c_int
     L.orc_convergence_step.argtypes = [C.POINTER(Convergence), C.c_int, _fp, C.c_double]
@@ -192,6 +195,14 @@ def umeyama(src, tgt, acc_mode: int = 0) -> np.ndarray:
     src, tgt = _f32(src, 3), _f32(tgt, 3)
     T = np.empty(16, np.float32)
     rc = lib().orc_umeyama(_p(src, _fp), _p(tgt, _fp), len(src), acc_mode, _p(T, _fp))
+    assert rc == 0
+    return T.reshape(4, 4).T.copy()
+
+
+def point_to_plane_lls(src, tgt, tgt_nrm) -> np.ndarray:
+    src, tgt, tn = _f32(src, 3), _f32(tgt, 3), _f32(tgt_nrm, 3)
+    T = np.empty(16, np.float32)
+    rc = lib().orc_point_to_plane_lls(_p(src, _fp), _p(tgt, _fp), _p(tn, _fp), len(src), _p(T, _fp))
     assert rc == 0
     return T.reshape(4, 4).T.copy()
 

@@ -207,6 +207,72 @@ int orc_umeyama_from_sums(const double S[17], const double pivot[3], float T[16]
 }
 
 /* ------------------------------------------------------------------ */
+/* uPCL transformation_estimation_point_to_plane_lls.hpp (published algorithm, Low 2004):
+ * products a,b,c,d are formed in float (the operands are `const float&`), accumulated in double;
+ * x = ATA^-1 ATb; rotation rebuilt from the three angles with full sin/cos. */
+static int solve6(double A[36], double b[6], double x[6]) {
+  int perm[6] = {0, 1, 2, 3, 4, 5};
+  for (int k = 0; k < 6; ++k) {
+    int piv = k;
+    for (int r = k + 1; r < 6; ++r)
+      if (fabs(A[6 * perm[r] + k]) > fabs(A[6 * perm[piv] + k])) piv = r;
+    int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    double d = A[6 * perm[k] + k];
+    if (fabs(d) < 1e-300) return -1;
+    for (int r = k + 1; r < 6; ++r) {
+      double f = A[6 * perm[r] + k] / d;
+      for (int c = k; c < 6; ++c) A[6 * perm[r] + c] -= f * A[6 * perm[k] + c];
+      b[perm[r]] -= f * b[perm[k]];
+    }
+  }
+  for (int k = 5; k >= 0; --k) {
+    double v = b[perm[k]];
+    for (int c = k + 1; c < 6; ++c) v -= A[6 * perm[k] + c] * x[c];
+    x[k] = v / A[6 * perm[k] + k];
+  }
+  return 0;
+}
+
+int orc_point_to_plane_lls(const float *src, const float *tgt, const float *tgt_nrm, int n, float T[16]) {
+  static const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  memcpy(T, I4, sizeof I4);
+  double ATA[36] = {0}, ATb[6] = {0};
+  for (int i = 0; i < n; ++i) {
+    const float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+    const float dx = tgt[3 * i], dy = tgt[3 * i + 1], dz = tgt[3 * i + 2];
+    const float nx = tgt_nrm[3 * i], ny = tgt_nrm[3 * i + 1], nz = tgt_nrm[3 * i + 2];
+    if (!isfinite(sx) || !isfinite(sy) || !isfinite(sz) || !isfinite(dx) || !isfinite(dy) || !isfinite(dz) ||
+        !isfinite(nx) || !isfinite(ny) || !isfinite(nz)) continue;
+    const double v[6] = {(double)(nz * sy - ny * sz), (double)(nx * sz - nz * sx), (double)(ny * sx - nx * sy),
+                         (double)nx, (double)ny, (double)nz};
+    const double d = (double)(nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz);
+    for (int r = 0; r < 6; ++r) {
+      for (int c = r; c < 6; ++c) ATA[6 * r + c] += v[r] * v[c];
+      ATb[r] += v[r] * d;
+    }
+  }
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < r; ++c) ATA[6 * r + c] = ATA[6 * c + r];
+  double x[6];
+  if (solve6(ATA, ATb, x) != 0) return -1;
+  const double al = x[0], be = x[1], ga = x[2];
+  double R[9];
+  R[0] = cos(ga) * cos(be);
+  R[1] = -sin(ga) * cos(al) + cos(ga) * sin(be) * sin(al);
+  R[2] = sin(ga) * sin(al) + cos(ga) * sin(be) * cos(al);
+  R[3] = sin(ga) * cos(be);
+  R[4] = cos(ga) * cos(al) + sin(ga) * sin(be) * sin(al);
+  R[5] = -cos(ga) * sin(al) + sin(ga) * sin(be) * cos(al);
+  R[6] = -sin(be);
+  R[7] = cos(be) * sin(al);
+  R[8] = cos(be) * cos(al);
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) T[4 * c + r] = (float)R[3 * r + c];
+  T[12] = (float)x[3]; T[13] = (float)x[4]; T[14] = (float)x[5];
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
 void orc_convergence_init(orc_convergence *c) {
   c->max_iterations = 100;
   c->failure_after_max_iter = 0;
@@ -388,7 +454,7 @@ int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt
   if (ns <= 0 || !src_xyz) return -2;
   if (!guess) guess = I4;
   int need_src_nrm = (p->corr_mode == 1) || p->use_surface_normal_rej || p->use_self_occluded_rej;
-  int need_tgt_nrm = p->use_surface_normal_rej;
+  int need_tgt_nrm = p->use_surface_normal_rej || p->estimator == 1;
   if ((need_src_nrm && !src_nrm) || (need_tgt_nrm && !tgt_nrm)) return -3;
 
   orc_kdtree *tree = orc_kdtree_build(tgt_xyz, nt, 15);
@@ -401,6 +467,7 @@ int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt
   float *cd = (float *)malloc(sizeof(float) * (size_t)ns);
   float *ps = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
   float *pt = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
+  float *pn = (p->estimator == 1) ? (float *)malloc(sizeof(float) * 3 * (size_t)ns) : NULL;
   int kk = p->k_normal_shooting > 0 ? p->k_normal_shooting : 1;
   int32_t *nn_i = (int32_t *)malloc(sizeof(int32_t) * (size_t)kk);
   float *nn_d = (float *)malloc(sizeof(float) * (size_t)kk);
@@ -497,8 +564,10 @@ int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt
     for (int c = 0; c < ncorr; ++c) {
       memcpy(ps + 3 * c, work + 3 * cq[c], 3 * sizeof(float));
       memcpy(pt + 3 * c, tgt_xyz + 3 * cm[c], 3 * sizeof(float));
+      if (pn) memcpy(pn + 3 * c, tgt_nrm + 3 * cm[c], 3 * sizeof(float));
     }
-    orc_umeyama(ps, pt, ncorr, p->acc_mode, Tk);
+    if (p->estimator == 1) orc_point_to_plane_lls(ps, pt, pn, ncorr, Tk);
+    else orc_umeyama(ps, pt, ncorr, p->acc_mode, Tk);
     if (p->transform_mode == 0) {
       orc_transform_points(work, ns, Tk, work);
       if (wnrm) orc_transform_normals(wnrm, ns, Tk, wnrm);
@@ -531,7 +600,7 @@ int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt
   if (corr_m_out) memcpy(corr_m_out, cm, sizeof(int32_t) * (size_t)ncorr);
   if (corr_d2_out) memcpy(corr_d2_out, cd, sizeof(float) * (size_t)ncorr);
 
-  free(work); free(wnrm); free(cq); free(cm); free(cd); free(ps); free(pt); free(nn_i); free(nn_d);
+  free(work); free(wnrm); free(cq); free(cm); free(cd); free(ps); free(pt); free(pn); free(nn_i); free(nn_d);
   orc_kdtree_free(tree);
   if (rtree) orc_kdtree_free(rtree);
   return 0;

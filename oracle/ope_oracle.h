@@ -71,6 +71,10 @@ int orc_umeyama(const float *src, const float *tgt, int n, int acc_mode, float T
  * Sums are taken about `pivot` (subtracted from both s and t). */
 int orc_umeyama_from_sums(const double S[17], const double pivot[3], float T[16]);
 
+/* uPCL TransformationEstimationPointToPlaneLLS::estimateRigidTransformation on n paired points
+ * (tgt_nrm = normals of the matched target points).  Returns 0, or -1 if the 6x6 system is singular. */
+int orc_point_to_plane_lls(const float *src, const float *tgt, const float *tgt_nrm, int n, float T[16]);
+
 /* 3x3 SVD (two-sided Jacobi via A^T A eigen-decomposition refinement),
  * A = U diag(s) V^T, s descending, row-major 3x3 arrays. */
 void orc_svd3(const double A[9], double U[9], double s[3], double V[9]);
@@ -131,6 +135,12 @@ typedef struct {
   double mse_threshold_absolute;   /* 1e-12; <0 disables (throughput runs) */
   int failure_after_max_iter;      /* 0 */
   int acc_mode;                    /* umeyama accumulation, see orc_umeyama */
+  int estimator;                   /* 0: TransformationEstimationSVD (poseestimator.cpp:306,341)
+                                      1: TransformationEstimationPointToPlaneLLS — the default estimator of
+                                         IterativeClosestPointWithNormals (icp_mod.h:352-357), linearised
+                                         point-to-plane; needs target normals.  (BuildModel selects the
+                                         LM-based point-to-plane estimator, regmeshpcd.cpp:162,193: same cost
+                                         function, non-linear solve — not restated.) */
   int transform_mode;              /* 0: incremental float transform of the working cloud
                                          each iteration (reference, icp_mod.hpp:246);
                                       1: final_T (composed in double) applied to the

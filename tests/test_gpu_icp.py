@@ -289,3 +289,34 @@ def test_icp_reciprocal_correspondences_match_oracle(ctx):
     assert len(set(m.tolist())) == len(m)                                  # reciprocal => one-to-one
     common, ia, ib = np.intersect1d(q, ref.corr_q, return_indices=True)
     assert len(common) >= ref.n_corr - 2 and (m[ia] == ref.corr_m[ib]).mean() > 0.999
+
+
+def test_icp_point_to_plane_lls_matches_oracle(ctx):
+    """TransformationEstimationPointToPlaneLLS — IterativeClosestPointWithNormals' default estimator (icp_mod.h:352-357)."""
+    ope = load_pkg()
+    P, nP = synth.model_surface(6000, 5, return_normals=True)
+    P = P + np.array([0, 0, 0.6], np.float32)
+    Tgt = rigid(2.0, -1.5, 3.0, [0.004, -0.003, 0.002])
+    Q = apply(Tgt, synth.model_surface(6000, 6) + np.array([0, 0, 0.6], np.float32))
+    _, nQ0 = synth.model_surface(6000, 6, return_normals=True)
+    nQ = (nQ0.astype(np.float64) @ Tgt[:3, :3].T).astype(np.float32)
+    kw = dict(max_iterations=25, transformation_epsilon=1e-10, euclidean_fitness_epsilon=1e-12, max_corr_dist=0.01)
+    cs = ctx.upload(P); ct = ctx.upload(Q, nQ); ix = ctx.build_index(ct)
+    out = ctx.icp(cs, ix, ope.default_icp_params(estimator=ope.EST_POINT_TO_PLANE_LLS, **kw))
+    ref = oracle.icp(P, Q, orc_params(acc_mode=1, transform_mode=1, estimator=1, **kw), tgt_nrm=nQ)
+    assert frob(out.T, ref.T) < 1e-4
+    assert abs(out.iterations - ref.iterations) <= 1 and out.converged == ref.converged
+    assert abs(out.n_corr - ref.n_corr) <= 3
+    assert frob(out.T, Tgt) < 5e-3                                   # two samplings of the same surface
+    # point-to-plane converges in fewer iterations than point-to-point on the same data
+    svd = ctx.icp(cs, ix, ope.default_icp_params(**kw))
+    assert out.iterations <= svd.iterations
+
+
+def test_point_to_plane_needs_target_normals(ctx):
+    ope = load_pkg()
+    P = synth.bumpy_torus(500)
+    cs = ctx.upload(P); ix = ctx.build_index(ctx.upload(P))
+    with pytest.raises(ope.OpeError) as e:
+        ctx.icp(cs, ix, ope.default_icp_params(estimator=ope.EST_POINT_TO_PLANE_LLS))
+    assert e.value.code == ope.OPE_EINVAL

@@ -43,7 +43,7 @@ def _worker(rank, world, port, ns, nt, max_it, out_dir):
         def __init__(self, *a, **k):
             super().__init__(*a, **k)
             self.dev_sums = self.sums
-            self.sums = torch.zeros(17, dtype=torch.float64)
+            self.sums = torch.zeros_like(self.dev_sums, device="cpu")
         def accumulate(self):
             super().accumulate()
             torch.cuda.synchronize()

@@ -411,3 +411,22 @@ def test_sacia_error_metric_and_forced_samples():
     T2, err2, it2 = oracle.sacia(P, feat, Q, feat, n_iter=3, nr_samples=5, k_corr=1, forced_samples=forced)
     np.testing.assert_allclose(T2, Tgt, atol=1e-4)
     assert it2 == 0
+
+
+# ---------------------------------------------------------------- point-to-plane LLS
+def test_point_to_plane_lls_small_motion_and_icp():
+    P, N = synth.model_surface(3000, 5, return_normals=True)
+    Tgt = rigid(1.0, -0.8, 1.5, [0.002, -0.001, 0.0015])
+    Q = apply(Tgt, P); NQ = (N.astype(np.float64) @ Tgt[:3, :3].T).astype(np.float32)
+    T1 = oracle.point_to_plane_lls(P, Q, NQ)
+    assert np.abs(T1 - Tgt).max() < 1e-3                            # one linearised step
+    R = T1[:3, :3].astype(np.float64)
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)       # rebuilt from angles: a proper rotation
+    # independent check of the normal equations with numpy
+    s = P.astype(np.float64); d = Q.astype(np.float64); n = NQ.astype(np.float64)
+    A = np.c_[np.cross(s, n), n]; b = ((d - s) * n).sum(1)
+    x = np.linalg.lstsq(A, b, rcond=None)[0]
+    np.testing.assert_allclose(T1[:3, 3], x[3:], atol=2e-6)
+    p = oracle.default_icp_params(); p.max_iterations = 30; p.estimator = 1; p.acc_mode = 1
+    out = oracle.icp(P, Q, p, tgt_nrm=NQ)
+    assert out.converged and np.abs(out.T - Tgt).max() < 1e-6
