@@ -10,6 +10,7 @@
 //   registration::CorrespondenceRejectorSurfaceNormal    poseestimator.cpp:264-272
 //   registration::CorrespondenceRejectorSelfOccludedNormal vPCL correspondence_rejection_self_occluded_normal.h
 //   registration::TransformationEstimationSVD            poseestimator.cpp:306,435
+//   registration::TransformationEstimationPointToPlane[LLS] BuildModel regmeshpcd.cpp:162,193; vPCL icp_mod.h:355
 //   NormalEstimation / FPFHEstimation / UniformSampling  poseestimator.cpp:121-125,141-156
 //   SampleConsensusInitialAlignment                      poseestimator.cpp:50-64
 // Point types are layout-compatible PODs (x@0,y@4,z@8; normal@16 in PointXYZRGBNormal; 16-byte aligned).
@@ -172,6 +173,7 @@ struct CorrespondenceRejectorSelfOccludedNormal : CorrespondenceRejector {
 
 template <class S, class T, class Scalar = float> struct TransformationEstimationSVD {
   typedef std::shared_ptr<TransformationEstimationSVD> Ptr;
+  static constexpr int ope_estimator = OPE_EST_SVD;
   void estimateRigidTransformation(const PointCloud<S> &src, const PointCloud<T> &tgt, const Correspondences &corrs,
                                    Matrix4f &out) const {
     out = Matrix4f::Identity();
@@ -186,6 +188,19 @@ template <class S, class T, class Scalar = float> struct TransformationEstimatio
     }
     if (ope_rigid_transform_svd(ctx, a.data(), b.data(), corrs.size(), out.m) != OPE_OK) log_error("TransformationEstimationSVD", ctx);
   }
+};
+
+// Selected by type in setTransformationEstimation: the 6x6 normal equations of the linearised point-to-plane
+// error (the IterativeClosestPointWithNormals default, vPCL icp_mod.h:355).
+template <class S, class T, class Scalar = float> struct TransformationEstimationPointToPlaneLLS {
+  typedef std::shared_ptr<TransformationEstimationPointToPlaneLLS> Ptr;
+  static constexpr int ope_estimator = OPE_EST_POINT_TO_PLANE_LLS;
+};
+// PCL's class of this name minimises the same error with Levenberg-Marquardt (regmeshpcd.cpp:162,193); here it
+// maps to the LLS solve, which has the same fixed points ("BuildModel loop").
+template <class S, class T, class Scalar = float> struct TransformationEstimationPointToPlane {
+  typedef std::shared_ptr<TransformationEstimationPointToPlane> Ptr;
+  static constexpr int ope_estimator = OPE_EST_POINT_TO_PLANE_LLS;
 };
 
 // DefaultConvergenceCriteria knobs the reference can reach through getConvergeCriteria()
@@ -233,7 +248,7 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
   void setUseReciprocalCorrespondences(bool b) { params_.use_reciprocal = b ? 1 : 0; }
   void setCorrespondenceEstimation(const std::shared_ptr<registration::CorrespondenceEstimationBase> &ce) { corr_est_ = ce; }
   void addCorrespondenceRejector(const registration::CorrespondenceRejector::Ptr &r) { rejectors_.push_back(r); }
-  template <class TE> void setTransformationEstimation(const std::shared_ptr<TE> &) {}  // SVD is the built-in estimator
+  template <class TE> void setTransformationEstimation(const std::shared_ptr<TE> &) { params_.estimator = TE::ope_estimator; }
   std::shared_ptr<registration::DefaultConvergenceCriteria> getConvergeCriteria() { return criteria_; }
 
   void align(PointCloudSource &output) { align(output, Matrix4f::Identity()); }
@@ -256,7 +271,8 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
     for (auto &r : rejectors_) r->apply(p);
     p.mse_threshold_absolute = criteria_->mse_threshold_absolute_;
     p.failure_after_max_iter = criteria_->failure_after_max_iter_ ? 1 : 0;
-    const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
+    const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej ||
+                     p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
     if (!src_dev_) src_dev_ = upload(*input_, nrm);
     if (!tgt_index_) {
       tgt_dev_ = upload(*target_, nrm);
@@ -323,8 +339,11 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
   int64_t n_corr_ = 0;
 };
 
-// Differs from the base only in transforming the normals too, which the kernels always do.
-template <class S, class T, class Scalar = float> class IterativeClosestPointWithNormals : public IterativeClosestPoint<S, T, Scalar> {};
+// Transforms the normals too (the kernels always do) and starts from the point-to-plane LLS estimator (icp_mod.h:355).
+template <class S, class T, class Scalar = float> class IterativeClosestPointWithNormals : public IterativeClosestPoint<S, T, Scalar> {
+ public:
+  IterativeClosestPointWithNormals() { this->params_.estimator = OPE_EST_POINT_TO_PLANE_LLS; }
+};
 
 // ------------------------------------------------------------------------------------------ features
 namespace search { template <class P> struct KdTree { typedef std::shared_ptr<KdTree> Ptr; explicit KdTree(bool = true) {} }; }

@@ -1,0 +1,100 @@
+"""BuildModel's registration loop on the HIP path (SURVEY.md §8f row "C5").
+
+Host-side mirror of `RegMeshPcd::getIcpNormal` (BuildModel/src/regmeshpcd.cpp:63-206) and
+`RegMeshPcd::registerPointClouds` (:210-271): the sequence and parameters are the reference's, every
+stage is a C-ABI call into libope_hip.so (normals, index build, ICP loop, transform).  Meshing
+(`generateMesh`, :273-343) is out of scope.
+
+Differences a maintainer must know about, all recorded in DESIGN.md:
+  * the reference installs `TransformationEstimationPointToPlane` (Levenberg-Marquardt, :162,:193);
+    this path solves the same point-to-plane objective with the linear least-squares estimator
+    (`OPE_EST_POINT_TO_PLANE_LLS`, the `IterativeClosestPointWithNormals` default).  The two share
+    their fixed points; per-iteration increments differ, so parity for this row is against the oracle
+    run with the LLS estimator, not against the LM trajectory.
+  * `p_maxCorrDist` only reaches the stand-alone `determineCorrespondences` call (:145) whose result
+    the reference discards; the ICP object itself keeps PCL's default correspondence distance
+    (sqrt(DBL_MAX)).  `use_max_corr_dist_in_icp=False` reproduces that.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+@dataclass
+class PairResult:
+    T: np.ndarray
+    iterations: int
+    converged: bool
+    fitness: float
+    n_source: int
+    n_target: int
+
+
+@dataclass
+class RegistrationResult:
+    cloud: np.ndarray                      # accumulated, registered cloud (frame of the last input)
+    pairs: list = field(default_factory=list)
+
+
+def icp_params_with_normals(ope, corr_rej_thresh: float, max_iterations: int, max_corr_dist: float | None = None):
+    """The parameter block of getIcpNormal (regmeshpcd.cpp:142-194)."""
+    kw = dict(max_iterations=int(max_iterations),            # :179
+              transformation_epsilon=1e-8,                  # :182
+              euclidean_fitness_epsilon=1e-8,               # :184
+              corr_mode=ope.CORR_NORMAL_SHOOTING,           # :139-145,:187
+              k_normal_shooting=20,                         # :144
+              use_surface_normal_rej=1,                     # :148-158,:190
+              surface_normal_thr=float(corr_rej_thresh),    # :158
+              estimator=ope.EST_POINT_TO_PLANE_LLS)         # :162,:193 (LLS in place of LM, see module doc)
+    if max_corr_dist is not None:
+        kw["max_corr_dist"] = float(max_corr_dist)
+    return ope.default_icp_params(**kw)
+
+
+def get_icp_normal(ope, ctx, source_xyz, target_xyz, corr_rej_thresh: float = 0.7, max_iterations: int = 500,
+                   max_corr_dist: float = 0.005, use_max_corr_dist_in_icp: bool = False, k_normals: int = 12):
+    """One frame pair: normals(k=12) on both clouds -> ICP with normals -> aligned source.
+
+    Returns (aligned_xyz, PairResult).  regmeshpcd.cpp:63-206.
+    """
+    src = ctx.upload(source_xyz)
+    tgt = ctx.upload(target_xyz)
+    try:
+        ns, _ = ctx.normals(src, k_normals)     # :72-84
+        nt, _ = ctx.normals(tgt, k_normals)     # :86-90
+        src.set_normals(ns)
+        tgt.set_normals(nt)
+        index = ctx.build_index(tgt)
+        try:
+            p = icp_params_with_normals(ope, corr_rej_thresh, max_iterations,
+                                        max_corr_dist if use_max_corr_dist_in_icp else None)
+            out = ctx.icp(src, index, p)        # :196
+            fit, _, _ = ctx.fitness(src, index, out.T)   # :198
+            aligned = ctx.transform_cloud(src, out.T)    # :203
+        finally:
+            index.free()
+    finally:
+        src.free()
+        tgt.free()
+    return aligned, PairResult(out.T, out.iterations, out.converged, fit, len(source_xyz), len(target_xyz))
+
+
+def register_point_clouds(ope, ctx, frames, max_corr_dist: float = 0.005, corr_rej_thresh: float = 0.7,
+                          max_iterations: int = 500, **kw) -> RegistrationResult:
+    """Sequential accumulate-and-register over N frames (regmeshpcd.cpp:210-271).
+
+    cloudTemp = frame 0; for every next frame: align cloudTemp to it, then cloudTemp = aligned + frame.
+    """
+    if len(frames) == 0:
+        raise ValueError("register_point_clouds: no frames")
+    acc = np.ascontiguousarray(frames[0], np.float32)
+    res = RegistrationResult(acc)
+    for i in range(len(frames) - 1):
+        target = np.ascontiguousarray(frames[i + 1], np.float32)
+        aligned, pr = get_icp_normal(ope, ctx, acc, target, corr_rej_thresh, max_iterations, max_corr_dist, **kw)
+        acc = np.concatenate([aligned, target], axis=0)   # :254-258
+        res.pairs.append(pr)
+    res.cloud = acc
+    return res
