@@ -135,12 +135,20 @@ def main() -> int:
                            "fpfh_ms": (t4 - t3) * 1e3}
             kclouds.append(kc)
         t5 = time.perf_counter()
-        kix = ctx.build_index(kclouds[1])
-        guess, sac_err, sac_it = ctx.sacia(kclouds[0], feats[0], kclouds[1], kix, feats[1], ope.default_sacia_params(seed=1))
+        # SAC-IA in the reference's direction: source = the model, target = the scene (rosinterface.cpp:250 hands
+        # estimateFinalPose the loaded model as source); the ICP below runs scene -> model, so it starts from the inverse
+        kix = ctx.build_index(kclouds[0])
+        m2s, sac_err, sac_it = ctx.sacia(kclouds[1], feats[1], kclouds[0], kix, feats[0], ope.default_sacia_params(seed=1))
+        guess = np.linalg.inv(np.asarray(m2s, np.float64)).astype(np.float32)
         t6 = time.perf_counter()
+        gt = np.linalg.inv(synth.ground_truth_pose())
         coarse = {"total_ms": (t6 - t_c) * 1e3, "sacia_ms": (t6 - t5) * 1e3, "sacia_hypotheses": 400,
-                  "sacia_best_iteration": int(sac_it), "stages": stage,
-                  "note": "host wall-clock incl. uploads and host-side index builds; not part of value"}
+                  "sacia_best_iteration": int(sac_it), "sacia_error": float(sac_err),
+                  "pose_error_vs_ground_truth_frobenius": float(np.linalg.norm(guess.astype(np.float64) - gt)),
+                  "stages": stage,
+                  "note": "host wall-clock incl. uploads and host-side index builds; not part of value. The synthetic "
+                          "model is nearly symmetric under a half turn: SAC-IA may land on the mirrored fit "
+                          "(Frobenius 2.83 from the generator's pose, same residual to 1%)"}
 
     params = ope.default_icp_params(max_iterations=W + K + 1, transformation_epsilon=0.0,
                                     euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0, check_every=0)

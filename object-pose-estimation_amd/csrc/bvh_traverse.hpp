@@ -33,14 +33,16 @@ __device__ __forceinline__ float sq_dist3(float dx, float dy, float dz) {
 
 // squared distance lower bound from q to the oriented box {n0, n1, n2} (see BvhView)
 __device__ __forceinline__ float obb_dist2(const v4f n0, const v4f n1, const v4f n2, float qx, float qy, float qz) {
+  // Bounds need not match the oracle bit for bit (only point distances do): FMAs here, the build's margin
+  // and the final 0.999996 cover the rounding.
   const float dx = qx - n0.x, dy = qy - n0.y, dz = qz - n0.z;
-  const float a2x = n1.y * n2.z - n1.z * n2.y;
-  const float a2y = n1.z * n2.x - n1.x * n2.z;
-  const float a2z = n1.x * n2.y - n1.y * n2.x;
-  const float t0 = fmaxf(fabsf(dx * n1.x + dy * n1.y + dz * n1.z) - n0.w, 0.f);
-  const float t1 = fmaxf(fabsf(dx * n2.x + dy * n2.y + dz * n2.z) - n1.w, 0.f);
-  const float t2 = fmaxf(fabsf(dx * a2x + dy * a2y + dz * a2z) - n2.w, 0.f);
-  return (t0 * t0 + t1 * t1 + t2 * t2) * 0.999996f;
+  const float a2x = __fmaf_rn(n1.y, n2.z, -(n1.z * n2.y));
+  const float a2y = __fmaf_rn(n1.z, n2.x, -(n1.x * n2.z));
+  const float a2z = __fmaf_rn(n1.x, n2.y, -(n1.y * n2.x));
+  const float t0 = fmaxf(fabsf(__fmaf_rn(dz, n1.z, __fmaf_rn(dy, n1.y, dx * n1.x))) - n0.w, 0.f);
+  const float t1 = fmaxf(fabsf(__fmaf_rn(dz, n2.z, __fmaf_rn(dy, n2.y, dx * n2.x))) - n1.w, 0.f);
+  const float t2 = fmaxf(fabsf(__fmaf_rn(dz, a2z, __fmaf_rn(dy, a2y, dx * a2x))) - n2.w, 0.f);
+  return __fmaf_rn(t2, t2, __fmaf_rn(t1, t1, t0 * t0)) * 0.999996f;
 }
 
 // Visitor concept:

@@ -28,7 +28,7 @@ namespace ope {
 // over the transformed source every iteration; here the source index is built once in the source's own
 // frame and queried with F^-1 * t_j (a rigid map preserves the ranking up to fp32 rounding).
 template <int MODE, bool NRM, bool RECIP = false>
-__global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !RECIP) ? 8 : 4) void icp_accumulate_kernel(
+__global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !RECIP) ? kAccWavesPerSimd : 4) void icp_accumulate_kernel(
     CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,

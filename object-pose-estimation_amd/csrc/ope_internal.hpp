@@ -63,6 +63,10 @@ struct IcpState {
 constexpr int kNumSums = 17;
 constexpr int kNumSumsMax = 44;  // + 21 (upper triangle of AᵀA) + 6 (Aᵀb) for the point-to-plane estimator
 constexpr int kAccBlock = 512;       // threads per block of the accumulate kernel
+// Launch bound of the plain 1-NN accumulate kernel, in waves per SIMD.  At 8 (64 VGPRs) the kernel spilled ~20
+// VGPRs to scratch (~25 MB of scratch writes per C3 launch); 6 (80 VGPRs) has no spills and is faster although
+// only 768 of the 1024 blocks are resident at a time (C3: 230 -> 197 us, C2: 78 -> 68 us).
+constexpr int kAccWavesPerSimd = 6;
 constexpr int kAccMaxBlocks = 1024;  // partials rows; the update kernel reduces them with 1024 threads
 
 }  // namespace ope

@@ -1,5 +1,25 @@
-import importlib, os, sys, time, subprocess
-for f in ("0", "1.2", "1.5", "2", "3", "4"):
-    env = dict(os.environ, OPE_HEAVY_FACTOR=f)
-    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "quick_bench.py")], env=env, capture_output=True, text=True).stdout.splitlines()
-    print("factor", f, "|", [l.split("->")[1].split("mse")[0].strip() for l in out if "leaf=16" in l])
+"""Developer probe: C2-sized (shard-sized) runs under different OPE_HEAVY_FACTOR values (set in the environment)."""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ope = importlib.import_module("object-pose-estimation_amd")
+synth = importlib.import_module("object-pose-estimation_amd.synth")
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 125000
+    scene, model = synth.config_clouds("C3")
+    scene = scene[:n]
+    ctx = ope.Context(0)
+    cs = ctx.upload(scene); ix = ctx.build_index(ctx.upload(model))
+    p = ope.default_icp_params(max_iterations=200, mse_threshold_absolute=-1.0, check_every=0)
+    ctx.icp_begin(cs, ix, p, None)
+    ctx.icp_iterate(40); ctx.sync()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter(); ctx.icp_iterate(20); ctx.sync(); ts.append((time.perf_counter() - t0) / 20 * 1e6)
+    ctx.icp_end()
+    print(f"n={n} heavy={os.environ.get('OPE_HEAVY_FACTOR','default')}: us/it " + " ".join(f"{t:.1f}" for t in ts), flush=True)
+    ctx.close()
+
+if __name__ == "__main__":
+    main()
