@@ -40,7 +40,8 @@ enum {
   OPE_ENOMEM = -4,
   OPE_ESTATE = -5,  /* call out of sequence (e.g. ope_icp_step without begin) */
   OPE_ECOMM = -6,   /* RCCL failure */
-  OPE_EEMPTY = -7   /* empty target cloud (registration_mod.hpp:60-64) */
+  OPE_EEMPTY = -7,  /* empty target cloud (registration_mod.hpp:60-64) */
+  OPE_ERANGE = -8   /* voxel index would overflow 32 bits: PCL warns "leaf size is too small" and returns its input */
 };
 
 typedef struct ope_ctx ope_ctx;
@@ -225,6 +226,22 @@ int ope_fpfh(ope_ctx *ctx, const ope_cloud *cloud, float radius, float *out33);
 /* pcl::UniformSampling::compute(PointCloud<int>&) with setRadiusSearch(leaf)
  * (poseestimator.cpp:141-145); survivors in ascending voxel-key order. */
 int ope_uniform_sampling(ope_ctx *ctx, const ope_cloud *cloud, float leaf, int32_t *out_idx, size_t *n_out);
+
+
+/* ---------------- filters either side of the path ---------------- */
+/* pcl::removeNaNFromPointCloud (poseestimator.cpp:192-194): ORIGINAL indices of the finite points, ascending.
+ * out_idx has room for every point of the cloud. */
+int ope_remove_nan(ope_ctx *ctx, const ope_cloud *cloud, int32_t *out_idx, size_t *n_out);
+/* pcl::PassThrough::filter on "z", then "y", then "x" with setFilterLimits(lo, hi) each
+ * (BuildModel processingpcd.cpp:8-36): a finite point survives iff lo[d] <= p[d] <= hi[d] for d = x, y, z
+ * (limits inclusive; use -/+FLT_MAX for an unfiltered field).  ORIGINAL indices, ascending. */
+int ope_pass_through(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], int32_t *out_idx,
+                     size_t *n_out);
+/* pcl::VoxelGrid::filter with setLeafSize(leaf[0], leaf[1], leaf[2]) (BuildModel processingpcd.cpp:39-52):
+ * one centroid per occupied voxel, in ascending voxel index (PCL's output order); xyz only (colours are
+ * not carried).  out_xyz has room for 3 floats per finite input point.  OPE_ERANGE where PCL would warn
+ * "Leaf size is too small for the input dataset" and return the input unchanged. */
+int ope_voxel_grid(ope_ctx *ctx, const ope_cloud *cloud, const float leaf[3], float *out_xyz, size_t *n_out);
 
 typedef struct {
   int max_iterations;      /* 400  (poseestimator.cpp:55) */

@@ -87,6 +87,11 @@ int main() {
   pcl::transformPointCloud(*model, *aligned, coarse);
 
   // ---- estimateFinePose
+  {  // remove NaN points (poseestimator.cpp:192-194)
+    std::vector<int> index;
+    pcl::removeNaNFromPointCloud(*aligned, *aligned, index);
+    pcl::removeNaNFromPointCloud(*scene, *scene, index);
+  }
   pcl::PointCloud<PointT>::Ptr s8, t8;
   pcl::PointCloud<pcl::Normal>::Ptr s8n, t8n;
   subSampleAndCalculateNormals(aligned, s8, s8n, 0.008);

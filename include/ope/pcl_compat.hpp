@@ -12,6 +12,7 @@
 //   registration::TransformationEstimationSVD            poseestimator.cpp:306,435
 //   registration::TransformationEstimationPointToPlane[LLS] BuildModel regmeshpcd.cpp:162,193; vPCL icp_mod.h:355
 //   NormalEstimation / FPFHEstimation / UniformSampling  poseestimator.cpp:121-125,141-156
+//   removeNaNFromPointCloud / PassThrough / VoxelGrid    poseestimator.cpp:192-194; BuildModel processingpcd.cpp:8-52
 //   SampleConsensusInitialAlignment                      poseestimator.cpp:50-64
 // Point types are layout-compatible PODs (x@0,y@4,z@8; normal@16 in PointXYZRGBNormal; 16-byte aligned).
 // Errors never throw on the hot path: like PCL, a failed call logs to stderr and leaves
@@ -434,6 +435,86 @@ template <class P> inline void copyPointCloud(const PointCloud<P> &in, const std
   for (int i : indices) out.points.push_back(in.points[i]);
   out.width = (uint32_t)out.points.size();
 }
+
+// ------------------------------------------------------------------------------------------ filters
+// pcl::removeNaNFromPointCloud (poseestimator.cpp:192-194); `index` maps output positions to input positions.
+template <class P> inline void removeNaNFromPointCloud(const PointCloud<P> &in, PointCloud<P> &out, std::vector<int> &index) {
+  index.clear();
+  ope_ctx *ctx = default_context();
+  auto dev = ctx ? upload(in, false) : std::shared_ptr<CloudHandle>();
+  std::vector<int32_t> idx(in.size() + 1);
+  size_t n = 0;
+  if (!dev || !dev->h || ope_remove_nan(ctx, dev->h, idx.data(), &n) != OPE_OK) {
+    if (ctx && dev && dev->h) log_error("removeNaNFromPointCloud", ctx);
+    n = 0;
+  }
+  index.assign(idx.begin(), idx.begin() + n);
+  PointCloud<P> tmp;
+  tmp.points.reserve(n);
+  for (size_t i = 0; i < n; ++i) tmp.points.push_back(in.points[index[i]]);
+  tmp.width = (uint32_t)n;
+  out = std::move(tmp);  // `in` and `out` may be the same object, as at poseestimator.cpp:193
+  out.is_dense = true;
+}
+
+// pcl::PassThrough (processingpcd.cpp:13-33): one field per object, inclusive limits.
+template <class PointT> class PassThrough {
+ public:
+  void setInputCloud(const typename PointCloud<PointT>::ConstPtr &c) { input_ = c; }
+  void setFilterFieldName(const std::string &f) { field_ = f; }
+  void setFilterLimits(float lo, float hi) { lo_ = lo; hi_ = hi; }
+  void filter(PointCloud<PointT> &out) {
+    PointCloud<PointT> tmp;
+    ope_ctx *ctx = default_context();
+    if (ctx && input_ && !input_->empty()) {
+      float lo[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}, hi[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+      const int d = field_ == "x" ? 0 : field_ == "y" ? 1 : field_ == "z" ? 2 : -1;
+      if (d >= 0) { lo[d] = lo_; hi[d] = hi_; }   // an unknown / empty field name only drops non-finite points
+      auto dev = upload(*input_, false);
+      std::vector<int32_t> idx(input_->size());
+      size_t n = 0;
+      if (dev->h && ope_pass_through(ctx, dev->h, lo, hi, idx.data(), &n) != OPE_OK) { log_error("PassThrough", ctx); n = 0; }
+      tmp.points.reserve(n);
+      for (size_t i = 0; i < n; ++i) tmp.points.push_back(input_->points[idx[i]]);
+      tmp.width = (uint32_t)n;
+    }
+    out = std::move(tmp);
+  }
+ private:
+  typename PointCloud<PointT>::ConstPtr input_;
+  std::string field_;
+  float lo_ = -FLT_MAX, hi_ = FLT_MAX;
+};
+
+// pcl::VoxelGrid (processingpcd.cpp:44-49): xyz centroids, ascending voxel index; other fields default-initialised.
+template <class PointT> class VoxelGrid {
+ public:
+  void setInputCloud(const typename PointCloud<PointT>::ConstPtr &c) { input_ = c; }
+  void setLeafSize(float lx, float ly, float lz) { leaf_[0] = lx; leaf_[1] = ly; leaf_[2] = lz; }
+  void filter(PointCloud<PointT> &out) {
+    PointCloud<PointT> tmp;
+    ope_ctx *ctx = default_context();
+    if (ctx && input_ && !input_->empty()) {
+      auto dev = upload(*input_, false);
+      std::vector<float> xyz(3 * input_->size());
+      size_t n = 0;
+      const int rc = dev->h ? ope_voxel_grid(ctx, dev->h, leaf_, xyz.data(), &n) : OPE_EINVAL;
+      if (rc == OPE_ERANGE) {  // voxel_grid.hpp: warn and hand the input back
+        std::fprintf(stderr, "[ope::VoxelGrid::applyFilter] Leaf size is too small for the input dataset. Integer indices would overflow.\n");
+        out = *input_;
+        return;
+      }
+      if (rc != OPE_OK) { log_error("VoxelGrid", ctx); n = 0; }
+      tmp.points.resize(n);
+      for (size_t i = 0; i < n; ++i) { tmp.points[i].x = xyz[3 * i]; tmp.points[i].y = xyz[3 * i + 1]; tmp.points[i].z = xyz[3 * i + 2]; }
+      tmp.width = (uint32_t)n;
+    }
+    out = std::move(tmp);
+  }
+ private:
+  typename PointCloud<PointT>::ConstPtr input_;
+  float leaf_[3] = {0.01f, 0.01f, 0.01f};
+};
 
 template <class PointSource, class PointTarget, class FeatureT> class SampleConsensusInitialAlignment {
  public:

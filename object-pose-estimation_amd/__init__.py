@@ -20,7 +20,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libope_hip.so")
 
-OPE_OK, OPE_EINVAL, OPE_ENODEV, OPE_EHIP, OPE_ENOMEM, OPE_ESTATE, OPE_ECOMM, OPE_EEMPTY = 0, -1, -2, -3, -4, -5, -6, -7
+OPE_OK, OPE_EINVAL, OPE_ENODEV, OPE_EHIP, OPE_ENOMEM, OPE_ESTATE, OPE_ECOMM, OPE_EEMPTY, OPE_ERANGE = 0, -1, -2, -3, -4, -5, -6, -7, -8
 CONV_NAMES = ["NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE", "NO_CORRESPONDENCES"]
 CORR_NEAREST, CORR_NORMAL_SHOOTING = 0, 1
 EST_SVD, EST_POINT_TO_PLANE_LLS = 0, 1
@@ -141,6 +141,9 @@ ABI = [
     ("ope_normals", C.c_int, [_vp, _vp, C.c_int, _fp, _fp, _fp]),
     ("ope_fpfh", C.c_int, [_vp, _vp, C.c_float, _fp]),
     ("ope_uniform_sampling", C.c_int, [_vp, _vp, C.c_float, _ip, C.POINTER(C.c_size_t)]),
+    ("ope_remove_nan", C.c_int, [_vp, _vp, _ip, C.POINTER(C.c_size_t)]),
+    ("ope_pass_through", C.c_int, [_vp, _vp, _fp, _fp, _ip, C.POINTER(C.c_size_t)]),
+    ("ope_voxel_grid", C.c_int, [_vp, _vp, _fp, _fp, C.POINTER(C.c_size_t)]),
     ("ope_sacia_default_params", None, [C.POINTER(SaciaParams)]),
     ("ope_sacia", C.c_int, [_vp, _vp, _fp, _vp, _vp, _fp, C.POINTER(SaciaParams), _ip, _fp, _dp, _ip]),
 ]
@@ -398,6 +401,32 @@ class Context:
         out = np.empty(cloud.n, np.int32)
         n = C.c_size_t(0)
         self._chk(lib().ope_uniform_sampling(self.h, cloud.h, leaf, _p(out, _ip), C.byref(n)))
+        return out[: n.value].copy()
+
+    # ---- filters either side of the path
+    def remove_nan(self, cloud: "Cloud") -> np.ndarray:
+        """pcl::removeNaNFromPointCloud: original indices of the finite points, ascending."""
+        out = np.empty(max(cloud.n, 1), np.int32)
+        n = C.c_size_t(0)
+        self._chk(lib().ope_remove_nan(self.h, cloud.h, _p(out, _ip), C.byref(n)))
+        return out[: n.value].copy()
+
+    def pass_through(self, cloud: "Cloud", lo, hi) -> np.ndarray:
+        """pcl::PassThrough on x, y and z (inclusive limits): original indices of the survivors, ascending."""
+        lo = np.ascontiguousarray(lo, np.float32); hi = np.ascontiguousarray(hi, np.float32)
+        if lo.shape != (3,) or hi.shape != (3,):
+            raise ValueError("pass_through: lo and hi are 3-vectors")
+        out = np.empty(max(cloud.n, 1), np.int32)
+        n = C.c_size_t(0)
+        self._chk(lib().ope_pass_through(self.h, cloud.h, _p(lo, _fp), _p(hi, _fp), _p(out, _ip), C.byref(n)))
+        return out[: n.value].copy()
+
+    def voxel_grid(self, cloud: "Cloud", leaf) -> np.ndarray:
+        """pcl::VoxelGrid centroids (m,3) in ascending voxel index; OpeError(OPE_ERANGE) where PCL refuses the leaf."""
+        lf = np.ascontiguousarray(np.broadcast_to(np.asarray(leaf, np.float32), (3,)))
+        out = np.empty((max(cloud.n, 1), 3), np.float32)
+        n = C.c_size_t(0)
+        self._chk(lib().ope_voxel_grid(self.h, cloud.h, _p(lf, _fp), _p(out, _fp), C.byref(n)))
         return out[: n.value].copy()
 
     def sacia(self, src: "Cloud", src_feat, tgt: "Cloud", tgt_index: "Index", tgt_feat, params: SaciaParams | None = None,

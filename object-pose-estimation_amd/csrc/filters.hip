@@ -1,0 +1,187 @@
+// filters.hip — the point-cloud filters either side of the registration path, on the device
+// (SURVEY.md §8f row 3).  HBM-bound byte work: one pass over the cloud, a rocPRIM sort/scan/select.
+//
+//   pcl::removeNaNFromPointCloud   DetectAndLocalize/src/poseestimator.cpp:192-194
+//   pcl::PassThrough::filter       BuildModel/src/processingpcd.cpp:8-36 (z, then y, then x: an axis-aligned box)
+//   pcl::VoxelGrid::filter         BuildModel/src/processingpcd.cpp:39-52
+//
+// Index filters return ORIGINAL indices in ascending order (PCL keeps the input order).  The cloud on the
+// device is Morton-sorted, so the keep flag of each point is scattered to its original position and a
+// rocPRIM select over a counting iterator gathers the survivors.
+// VoxelGrid: key = (voxel index << 32 | original index) -> radix sort -> one lane per voxel sums its points
+// in ascending original index (PCL's std::sort leaves that order unspecified) and multiplies by 1/count
+// (Eigen 3.2's operator/= on float vectors) -> centroids in ascending voxel index, PCL's own output order.
+#include <cstring>
+#include <string>
+
+#include <rocprim/rocprim.hpp>
+
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+#include "ope_internal.hpp"
+
+namespace ope {
+
+__global__ __launch_bounds__(256) void box_flags_kernel(CloudView c, float lox, float loy, float loz, float hix, float hiy,
+                                                         float hiz, unsigned char *__restrict__ flags_orig) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c.n) return;
+  const float4 p = c.xyzw[i];
+  // passthrough.hpp: "if (value > max || value < min) -> removed"; non-finite points (sorted last) never pass
+  const bool keep = i < c.n_valid && !(p.x > hix || p.x < lox) && !(p.y > hiy || p.y < loy) && !(p.z > hiz || p.z < loz);
+  flags_orig[(uint32_t)__float_as_int(p.w)] = keep ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void grid_key_kernel(CloudView c, float invx, float invy, float invz, int min_bx, int min_by,
+                                                        int min_bz, unsigned div_x, unsigned long long div_xy,
+                                                        unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= c.n) return;
+  vals[i] = i;
+  if (i >= c.n_valid) { keys[i] = ~0ull; return; }
+  const float4 p = c.xyzw[i];
+  // voxel_grid.hpp: ijk = static_cast<int>(floor(x * inverse_leaf) - static_cast<float>(min_b))
+  const int ix = (int)(floorf(p.x * invx) - (float)min_bx), iy = (int)(floorf(p.y * invy) - (float)min_by),
+            iz = (int)(floorf(p.z * invz) - (float)min_bz);
+  const unsigned long long voxel = (unsigned long long)ix + (unsigned long long)iy * div_x + (unsigned long long)iz * div_xy;
+  keys[i] = (voxel << 32) | (unsigned long long)(uint32_t)__float_as_int(p.w);
+}
+
+__global__ __launch_bounds__(256) void run_start_kernel(const unsigned long long *__restrict__ keys, uint32_t n_valid, uint32_t n,
+                                                         uint32_t *__restrict__ flags /* n + 1 */) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p > n) return;
+  flags[p] = (p < n_valid && (p == 0 || (keys[p - 1] >> 32) != (keys[p] >> 32))) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void centroid_kernel(CloudView c, const unsigned long long *__restrict__ keys,
+                                                        const uint32_t *__restrict__ vals, const uint32_t *__restrict__ flags,
+                                                        const uint32_t *__restrict__ slot, uint32_t n_valid,
+                                                        float *__restrict__ out_xyz) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_valid || flags[p] == 0u) return;
+  const unsigned long long vox = keys[p] >> 32;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  uint32_t j = p;
+  for (; j < n_valid && (keys[j] >> 32) == vox; ++j) {
+    const float4 q = c.xyzw[vals[j]];
+    sx = __fadd_rn(sx, q.x); sy = __fadd_rn(sy, q.y); sz = __fadd_rn(sz, q.z);
+  }
+  const float r = __fdiv_rn(1.0f, (float)(j - p));
+  float *o = out_xyz + 3 * (size_t)slot[p];
+  o[0] = __fmul_rn(sx, r); o[1] = __fmul_rn(sy, r); o[2] = __fmul_rn(sz, r);
+}
+
+static int box_filter(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], int32_t *out_idx,
+                      size_t *n_out, const char *who) {
+  *n_out = 0;
+  const size_t n = cloud->n;
+  if (n == 0) return OPE_OK;
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned char *d_flags = nullptr;
+  int32_t *d_out = nullptr;
+  unsigned int *d_count = nullptr;
+  void *d_tmp = nullptr;
+  unsigned int count = 0;
+  hipError_t e = hipMalloc((void **)&d_flags, n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_out, 4 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_count, 4);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(box_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cloud->view(), lo[0], lo[1],
+                       lo[2], hi[0], hi[1], hi[2], d_flags);
+    rocprim::counting_iterator<int32_t> iota(0);
+    size_t tb = 0;
+    e = rocprim::select(nullptr, tb, iota, d_flags, d_out, d_count, n, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tb, 16));
+    if (e == hipSuccess) e = rocprim::select(d_tmp, tb, iota, d_flags, d_out, d_count, n, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && count) e = hipMemcpy(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost);
+  }
+  for (void *p : {(void *)d_flags, (void *)d_out, (void *)d_count, d_tmp})
+    if (p) (void)hipFree(p);
+  if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string(who) + ": " + hipGetErrorString(e));
+  *n_out = count;
+  return OPE_OK;
+}
+
+}  // namespace ope
+
+using namespace ope;
+
+extern "C" int ope_remove_nan(ope_ctx *ctx, const ope_cloud *cloud, int32_t *out_idx, size_t *n_out) {
+  if (!ctx || !cloud || !out_idx || !n_out) return set_err(ctx, OPE_EINVAL, "ope_remove_nan: bad argument");
+  const float lo[3] = {-INFINITY, -INFINITY, -INFINITY}, hi[3] = {INFINITY, INFINITY, INFINITY};
+  return box_filter(ctx, cloud, lo, hi, out_idx, n_out, "ope_remove_nan");
+}
+
+extern "C" int ope_pass_through(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], int32_t *out_idx,
+                                size_t *n_out) {
+  if (!ctx || !cloud || !lo || !hi || !out_idx || !n_out) return set_err(ctx, OPE_EINVAL, "ope_pass_through: bad argument");
+  return box_filter(ctx, cloud, lo, hi, out_idx, n_out, "ope_pass_through");
+}
+
+extern "C" int ope_voxel_grid(ope_ctx *ctx, const ope_cloud *cloud, const float leaf[3], float *out_xyz, size_t *n_out) {
+  if (!ctx || !cloud || !leaf || !out_xyz || !n_out || !(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0))
+    return set_err(ctx, OPE_EINVAL, "ope_voxel_grid: bad argument");
+  *n_out = 0;
+  const size_t n = cloud->n, nv = cloud->n_valid;
+  if (n == 0 || nv == 0) return OPE_OK;
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  float inv[3];
+  long long min_b[3], div_b[3], dxyz[3];
+  for (int d = 0; d < 3; ++d) {
+    inv[d] = 1.0f / leaf[d];
+    dxyz[d] = (long long)((cloud->bb_hi[d] - cloud->bb_lo[d]) * inv[d]) + 1;
+    min_b[d] = (long long)(int)std::floor(cloud->bb_lo[d] * inv[d]);
+    div_b[d] = (long long)(int)std::floor(cloud->bb_hi[d] * inv[d]) - min_b[d] + 1;
+  }
+  // voxel_grid.hpp: "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = input
+  if (dxyz[0] * dxyz[1] * dxyz[2] > 2147483647LL)
+    return set_err(ctx, OPE_ERANGE, "ope_voxel_grid: leaf size too small for the input dataset (voxel index overflows)");
+  unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+  uint32_t *d_vals = nullptr, *d_vals2 = nullptr, *d_flags = nullptr, *d_slot = nullptr;
+  float *d_out = nullptr;
+  void *d_tmp = nullptr;
+  uint32_t count = 0;
+  hipError_t e = hipMalloc((void **)&d_keys, 8 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_keys2, 8 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_vals, 4 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_vals2, 4 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_flags, 4 * (n + 1));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_slot, 4 * (n + 1));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_out, 12 * nv);
+  if (e == hipSuccess) {
+    const unsigned nb = (unsigned)((n + 256) / 256);
+    hipLaunchKernelGGL(grid_key_kernel, dim3(nb), dim3(256), 0, ctx->stream, cloud->view(), inv[0], inv[1], inv[2], (int)min_b[0],
+                       (int)min_b[1], (int)min_b[2], (unsigned)div_b[0], (unsigned long long)(div_b[0] * div_b[1]), d_keys, d_vals);
+    size_t tmp_sort = 0, tmp_scan = 0;
+    e = rocprim::radix_sort_pairs(nullptr, tmp_sort, d_keys, d_keys2, d_vals, d_vals2, n, 0, 64, ctx->stream);
+    if (e == hipSuccess)
+      e = rocprim::exclusive_scan(nullptr, tmp_scan, d_flags, d_slot, 0u, n + 1, rocprim::plus<uint32_t>(), ctx->stream);
+    const size_t tmp_bytes = std::max(tmp_sort, tmp_scan);
+    if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16));
+    size_t tb = tmp_bytes;
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 64, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(run_start_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_keys2, (uint32_t)nv, (uint32_t)n, d_flags);
+      tb = tmp_bytes;
+      e = rocprim::exclusive_scan(d_tmp, tb, d_flags, d_slot, 0u, n + 1, rocprim::plus<uint32_t>(), ctx->stream);
+    }
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(centroid_kernel, dim3(nb), dim3(256), 0, ctx->stream, cloud->view(), d_keys2, d_vals2, d_flags, d_slot,
+                         (uint32_t)nv, d_out);
+      e = hipMemcpyAsync(&count, d_slot + n, 4, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && count) e = hipMemcpy(out_xyz, d_out, 12 * (size_t)count, hipMemcpyDeviceToHost);
+  }
+  for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_vals, (void *)d_vals2, (void *)d_flags, (void *)d_slot, (void *)d_out,
+                  d_tmp})
+    if (p) (void)hipFree(p);
+  if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_voxel_grid: ") + hipGetErrorString(e));
+  *n_out = count;
+  return OPE_OK;
+}

@@ -15,7 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libope_oracle.so")
-_SRCS = ["kdtree.c", "icp.c", "features.c", "ope_oracle.h", "Makefile"]
+_SRCS = ["kdtree.c", "icp.c", "features.c", "filters.c", "ope_oracle.h", "Makefile"]
 
 
 def build(force: bool = False) -> str:
@@ -130,6 +130,12 @@ def _declare(L):
     L.orc_pair_features.restype = C.c_int
     L.orc_pair_features.argtypes = [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]
     L.orc_fpfh.argtypes = [_fp, _fp, C.c_int, C.c_float, _fp, _fp, _dp]
+    L.orc_remove_nan.restype = C.c_int
+    L.orc_remove_nan.argtypes = [_fp, C.c_int, _ip]
+    L.orc_pass_through.restype = C.c_int
+    L.orc_pass_through.argtypes = [_fp, C.c_int, _fp, _fp, _ip]
+    L.orc_voxel_grid.restype = C.c_int
+    L.orc_voxel_grid.argtypes = [_fp, C.c_int, _fp, _fp]
     L.orc_uniform_sampling.restype = C.c_int
     L.orc_uniform_sampling.argtypes = [_fp, C.c_int, C.c_float, _ip]
     L.orc_sacia_error.restype = C.c_double
@@ -326,6 +332,32 @@ def uniform_sampling(xyz, leaf: float) -> np.ndarray:
     out = np.empty(len(xyz), np.int32)
     n = lib().orc_uniform_sampling(_p(xyz, _fp), len(xyz), leaf, _p(out, _ip))
     return out[:n].copy()
+
+
+def remove_nan(xyz) -> np.ndarray:
+    """pcl::removeNaNFromPointCloud: indices of the finite points, input order."""
+    xyz = _f32(xyz, 3)
+    out = np.empty(max(len(xyz), 1), np.int32)
+    n = lib().orc_remove_nan(_p(xyz, _fp), len(xyz), _p(out, _ip))
+    return out[:n].copy()
+
+
+def pass_through(xyz, lo, hi) -> np.ndarray:
+    """pcl::PassThrough on x, y and z with inclusive limits: indices of the survivors, input order."""
+    xyz = _f32(xyz, 3)
+    lo = np.ascontiguousarray(lo, np.float32); hi = np.ascontiguousarray(hi, np.float32)
+    out = np.empty(max(len(xyz), 1), np.int32)
+    n = lib().orc_pass_through(_p(xyz, _fp), len(xyz), _p(lo, _fp), _p(hi, _fp), _p(out, _ip))
+    return out[:n].copy()
+
+
+def voxel_grid(xyz, leaf):
+    """pcl::VoxelGrid centroids in ascending voxel index; None when PCL would refuse the leaf size."""
+    xyz = _f32(xyz, 3)
+    lf = np.ascontiguousarray(np.broadcast_to(np.asarray(leaf, np.float32), (3,)))
+    out = np.empty((max(len(xyz), 1), 3), np.float32)
+    n = lib().orc_voxel_grid(_p(xyz, _fp), len(xyz), _p(lf, _fp), _p(out, _fp))
+    return None if n < 0 else out[:n].copy()
 
 
 def feature_knn(feat, q, k: int):

@@ -206,6 +206,14 @@ void orc_fpfh(const float *xyz, const float *nrm, int n, float radius, float *ou
  * boost::unordered_map order.  Returns count; out_idx capacity n. */
 int orc_uniform_sampling(const float *xyz, int n, float leaf, int32_t *out_idx);
 
+/* Filters either side of the path (filters.c): removeNaNFromPointCloud (poseestimator.cpp:192-194),
+ * PassThrough on x/y/z with inclusive limits (processingpcd.cpp:8-36), VoxelGrid centroids
+ * (processingpcd.cpp:39-52; -1 = "leaf size too small", PCL hands back the input).
+ * Index outputs have capacity n, out_xyz capacity n*3; the count is returned. */
+int orc_remove_nan(const float *xyz, int n, int32_t *out_idx);
+int orc_pass_through(const float *xyz, int n, const float lo[3], const float hi[3], int32_t *out_idx);
+int orc_voxel_grid(const float *xyz, int n, const float leaf[3], float *out_xyz);
+
 /* SAC-IA error metric for one hypothesis: sum of TruncatedError(1-NN d2). */
 double orc_sacia_error(const float *src_xyz, int ns, const orc_kdtree *tgt_tree,
                        const float T[16], double corr_dist_threshold);

@@ -209,3 +209,50 @@ def test_coarse_then_fine_pipeline_recovers_pose(ctx):
     assert np.linalg.norm(out.T.astype(np.float64) - Tgt) < 1.5e-2   # two independent samplings of the surface: ~0.3 deg
     score, _, _ = ctx.fitness(full_src, full_ix, out.T)
     assert score < 1e-5
+
+
+# ---------------------------------------------------------------- filters: bit-exact vs the oracle
+def _cloud_with_holes(n, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-0.3, 0.3, (n, 3)).astype(np.float32)
+    bad = rng.choice(n, max(n // 50, 1), replace=False)
+    x[bad[::3], 0] = np.nan
+    x[bad[1::3], 1] = np.inf
+    x[bad[2::3], 2] = -np.inf
+    return x
+
+
+@pytest.mark.parametrize("n", [1, 257, 100_000])
+def test_remove_nan_and_pass_through_equal_oracle(ctx, n):
+    x = _cloud_with_holes(n, n)
+    c = ctx.upload(x)
+    np.testing.assert_array_equal(ctx.remove_nan(c), oracle.remove_nan(x))
+    lo, hi = [-0.1, -0.25, 0.0], [0.2, 0.05, 0.3]
+    np.testing.assert_array_equal(ctx.pass_through(c, lo, hi), oracle.pass_through(x, lo, hi))
+    # limits are inclusive: a box that ends exactly on a point keeps it
+    fin = x[np.isfinite(x).all(1)]
+    if len(fin):
+        np.testing.assert_array_equal(ctx.pass_through(c, fin[0], fin[0]), oracle.pass_through(x, fin[0], fin[0]))
+        assert len(oracle.pass_through(x, fin[0], fin[0])) >= 1
+    assert len(ctx.pass_through(c, [1, 1, 1], [0, 0, 0])) == 0
+
+
+@pytest.mark.parametrize("n,leaf", [(1, 0.01), (5000, 0.05), (200_000, 0.01), (200_000, [0.02, 0.01, 0.04])])
+def test_voxel_grid_equals_oracle(ctx, n, leaf):
+    x = _cloud_with_holes(n, 7 * n)
+    got = ctx.voxel_grid(ctx.upload(x), leaf)
+    want = oracle.voxel_grid(x, leaf)
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got, want)      # same voxel order, same float additions in the same order
+
+
+def test_voxel_grid_on_model_surface_and_refused_leaf(ctx):
+    ope = load_pkg()
+    m = synth.model_surface(100_000, 1)
+    c = ctx.upload(m)
+    np.testing.assert_array_equal(ctx.voxel_grid(c, 0.001), oracle.voxel_grid(m, 0.001))   # processingpcd leaf (regmeshpcd.cpp:226)
+    with pytest.raises(ope.OpeError) as e:
+        ctx.voxel_grid(c, 1e-5)
+    assert e.value.code == ope.OPE_ERANGE and oracle.voxel_grid(m, 1e-5) is None
+    allnan = ctx.upload(np.full((10, 3), np.nan, np.float32))
+    assert len(ctx.voxel_grid(allnan, 0.1)) == 0 and len(ctx.remove_nan(allnan)) == 0

@@ -430,3 +430,39 @@ def test_point_to_plane_lls_small_motion_and_icp():
     p = oracle.default_icp_params(); p.max_iterations = 30; p.estimator = 1; p.acc_mode = 1
     out = oracle.icp(P, Q, p, tgt_nrm=NQ)
     assert out.converged and np.abs(out.T - Tgt).max() < 1e-6
+
+
+# ---------------------------------------------------------------- filters
+def test_remove_nan_and_pass_through_known_answers():
+    x = np.array([[0.1, 0.1, 0.1], [np.nan, 0.0, 0.0], [0.2, 0.5, 1.0], [0.0, np.inf, 0.0], [0.2, 0.5, 1.0000001],
+                  [-0.3, 0.5, 0.2], [0.2, 0.5, -1.0]], np.float32)
+    np.testing.assert_array_equal(oracle.remove_nan(x), [0, 2, 4, 5, 6])
+    # limits are inclusive (passthrough.hpp: removed iff value > max || value < min); z, y, x in sequence = a box
+    big = np.float32(np.finfo(np.float32).max)
+    np.testing.assert_array_equal(oracle.pass_through(x, [-big, -big, -1.0], [big, big, 1.0]), [0, 2, 5, 6])
+    np.testing.assert_array_equal(oracle.pass_through(x, [0.0, 0.1, -1.0], [0.2, 0.5, 1.0]), [0, 2, 6])
+    assert len(oracle.remove_nan(np.empty((0, 3), np.float32))) == 0
+    assert len(oracle.pass_through(x, [1, 1, 1], [0, 0, 0])) == 0          # empty interval keeps nothing
+
+
+def test_voxel_grid_known_answers():
+    # two voxels of edge 1: {p0, p1, p4} and {p2}; NaN dropped; output in ascending voxel index (x fastest)
+    x = np.array([[0.1, 0.1, 0.1], [0.2, 0.2, 0.2], [1.5, 0.1, 0.1], [np.nan, 0, 0], [0.3, 0.9, 0.1]], np.float32)
+    c = oracle.voxel_grid(x, 1.0)
+    assert c.shape == (2, 3)
+    s = (np.float32(0.1) + np.float32(0.2)) + np.float32(0.3)              # float sums in input order ...
+    np.testing.assert_array_equal(c[0, 0], s * (np.float32(1) / np.float32(3)))   # ... times the reciprocal (Eigen 3.2 operator/=)
+    np.testing.assert_array_equal(c[1], x[2])
+    # negative coordinates floor towards -inf; anisotropic leaves; a single point is its own centroid
+    y = np.array([[-0.05, 0.0, 0.0], [0.05, 0.0, 0.0], [-0.15, 0.0, 0.0]], np.float32)
+    c = oracle.voxel_grid(y, [0.1, 1.0, 1.0])
+    np.testing.assert_allclose(c[:, 0], [-0.15, -0.05, 0.05], rtol=1e-6)
+    # every input point lies in exactly one voxel: the count-weighted mean of the centroids is the cloud's mean
+    rng = np.random.default_rng(3)
+    z = rng.uniform(-0.2, 0.2, (5000, 3)).astype(np.float32)
+    c = oracle.voxel_grid(z, 0.05)
+    keys = np.floor(z / np.float32(0.05)).astype(np.int64)
+    assert len(c) == len(np.unique(keys, axis=0))
+    # PCL refuses leaves whose voxel index would overflow 32 bits and hands back its input
+    assert oracle.voxel_grid(z, 1e-5) is None
+    assert len(oracle.voxel_grid(np.full((4, 3), np.nan, np.float32), 0.1)) == 0
