@@ -17,6 +17,7 @@ void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &,
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, uint32_t *);
 int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t, void *, size_t &);
 void fill_iota(hipStream_t, uint32_t *, uint32_t);
+hipError_t morton_order_device(hipStream_t, const float *, size_t, const float[3], const float[3], float4 *, int32_t *);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
 void launch_icp_update(hipStream_t, IcpState *, const double *);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
@@ -35,14 +36,6 @@ int set_err(ope_ctx *ctx, int code, const std::string &msg) {
 }
 
 static inline bool finite3(const float *p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
-
-static inline uint32_t expand_bits10(uint32_t v) {
-  v = (v * 0x00010001u) & 0xFF0000FFu;
-  v = (v * 0x00000101u) & 0x0F00F00Fu;
-  v = (v * 0x00000011u) & 0xC30C30C3u;
-  v = (v * 0x00000005u) & 0x49249249u;
-  return v;
-}
 
 // column-major 4x4 -> 12 floats, rows of [R|t]
 static void colmajor_to_rows(const float *T, float rows[12]) {
@@ -201,34 +194,21 @@ int ope_cloud_upload(ope_ctx *ctx, const void *base, size_t n, size_t stride_byt
   if (nv == 0) { for (int d = 0; d < 3; ++d) lo[d] = hi[d] = 0.f; }
   std::memcpy(c->bb_lo, lo, sizeof lo);
   std::memcpy(c->bb_hi, hi, sizeof hi);
-  // Morton order (10 bits per axis over the cloud's own bbox); non-finite points go last
-  std::vector<uint64_t> keys(n);
+  // Morton order (10 bits per axis over the cloud's own bbox); non-finite points go last.  Keys, sort and the
+  // gather into float4 {x, y, z, input index} run on the device (a host std::sort of 1 M keys took ~50 ms).
   float inv[3];
   for (int d = 0; d < 3; ++d) inv[d] = (hi[d] > lo[d]) ? 1023.999f / (hi[d] - lo[d]) : 0.f;
-  for (size_t i = 0; i < n; ++i) {
-    const float *p = &c->h_xyz[3 * i];
-    uint64_t code;
-    if (!finite3(p)) code = (uint64_t)1 << 30;  // above every 30-bit Morton code
-    else {
-      uint32_t q[3];
-      for (int d = 0; d < 3; ++d) q[d] = std::min<uint32_t>(1023u, (uint32_t)std::max(0.f, (p[d] - lo[d]) * inv[d]));
-      code = expand_bits10(q[0]) | (expand_bits10(q[1]) << 1) | (expand_bits10(q[2]) << 2);
-    }
-    keys[i] = (code << 32) | (uint64_t)i;  // index in the low bits keeps the sort stable and unique
-  }
-  std::sort(keys.begin(), keys.end());
   c->perm.resize(n);
-  std::vector<float> packed(n * 4);
-  for (size_t i = 0; i < n; ++i) {
-    const int32_t o = (int32_t)(keys[i] & 0xffffffffu);
-    c->perm[i] = o;
-    packed[4 * i + 0] = c->h_xyz[3 * (size_t)o + 0];
-    packed[4 * i + 1] = c->h_xyz[3 * (size_t)o + 1];
-    packed[4 * i + 2] = c->h_xyz[3 * (size_t)o + 2];
-    std::memcpy(&packed[4 * i + 3], &o, 4);
-  }
+  float *d_raw = nullptr;
+  int32_t *d_perm = nullptr;
   hipError_t e = hipMalloc((void **)&c->d_xyzw, sizeof(float4) * std::max<size_t>(n, 1));
-  if (e == hipSuccess && n) e = hipMemcpy(c->d_xyzw, packed.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess && n) e = hipMalloc((void **)&d_raw, 12 * n);
+  if (e == hipSuccess && n) e = hipMalloc((void **)&d_perm, 4 * n);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(d_raw, c->h_xyz.data(), 12 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n) e = morton_order_device(ctx->stream, d_raw, n, lo, inv, c->d_xyzw, d_perm);
+  if (e == hipSuccess && n) e = hipMemcpy(c->perm.data(), d_perm, 4 * n, hipMemcpyDeviceToHost);
+  if (d_raw) (void)hipFree(d_raw);
+  if (d_perm) (void)hipFree(d_perm);
   if (e != hipSuccess) {
     ope_cloud_free(c);
     return set_err(ctx, OPE_EHIP, std::string("ope_cloud_upload: ") + hipGetErrorString(e));

@@ -46,6 +46,15 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   for (int i = 0; i < 12; ++i) F[i] = st->Ff[i];
   const float psx = (float)st->pivot[0], psy = (float)st->pivot[1], psz = (float)st->pivot[2];
   const double max_d2 = st->max_d2;
+  // With a finite setMaxCorrespondenceDistance the 1-NN search only has to see points that can survive the
+  // threshold test (correspondence_estimation_mod.hpp:171 rejects d2 > max_d2 afterwards anyway): start from the
+  // smallest float strictly above every admissible d2 instead of +inf, so far-off queries end at the first boxes.
+  float best0 = INFINITY;
+  if (max_d2 < 3.0e38) {
+    float f = (float)max_d2;
+    if ((double)f < max_d2) f = nextafterf(f, INFINITY);
+    best0 = nextafterf(f, INFINITY);
+  }
   const bool rej_sn = NRM && st->use_surface_normal_rej;
   const bool rej_so = NRM && st->use_self_occluded_rej;
   const double thr_sn = st->surface_normal_thr, thr_so = st->self_occluded_thr;
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     uint32_t pos = 0;
     int match = -1;
     if (MODE == 0) {
-      NearestVisitor v{active ? INFINITY : -INFINITY, kNoPos, 0};
+      NearestVisitor v{active ? best0 : -INFINITY, kNoPos, 0};
       // start at the leaf that held this query's nearest neighbour one iteration ago (0 = none yet)
       if (OCT_OK && oct) {
         if (active) bvh_traverse_oct(tgt, x, y, z, v, &s_stk[0][threadIdx.x & ~7u], BLOCK, hint[i]);
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       if (owner) hint[i] = v.leaf;
       const bool found = active && v.pos != kNoPos;
       ok = found && !((double)v.best > max_d2);
-      d2 = v.best;
+      d2 = found ? v.best : INFINITY;
       pos = found ? v.pos : 0;
       match = found ? __float_as_int(tgt.pts[pos].w) : -1;
       if (RECIP) {
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
         for (int k = 0; k < 12; ++k) G[k] = st->Finv[k];
         const float4 t = tgt.pts[pos];
         const float bx = xform_row(G + 0, t.x, t.y, t.z), by = xform_row(G + 4, t.x, t.y, t.z), bz = xform_row(G + 8, t.x, t.y, t.z);
-        NearestVisitor r{ok ? INFINITY : -INFINITY, kNoPos, 0};
+        NearestVisitor r{ok ? best0 : -INFINITY, kNoPos, 0};
         if (ok) bvh_traverse(srcix, bx, by, bz, r, stk, BLOCK);
         ok = ok && r.pos != kNoPos && !((double)r.best > max_d2) &&
              __float_as_int(srcix.pts[r.pos].w) == __float_as_int(s.w);

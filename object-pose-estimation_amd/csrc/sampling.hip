@@ -105,6 +105,73 @@ void fill_iota(hipStream_t stream, uint32_t *v, uint32_t n) {
 
 }  // namespace ope
 
+// ------------------------------------------------------------------------------------------
+// Morton ordering of an uploaded cloud (ope_cloud_upload): key = (30-bit Morton code over the cloud's own
+// bounding box, non-finite points above every code) << 32 | input index, rocPRIM radix sort, gather into
+// float4 {x, y, z, input index}.  Keys are unique, so the order equals a host std::sort of the same keys.
+namespace ope {
+
+__device__ __forceinline__ uint32_t expand_bits10_dev(uint32_t v) {
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void morton_key_kernel(const float *__restrict__ raw, uint32_t n, float lox, float loy, float loz,
+                                                          float ivx, float ivy, float ivz, unsigned long long *__restrict__ keys) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = raw[3 * (size_t)i], y = raw[3 * (size_t)i + 1], z = raw[3 * (size_t)i + 2];
+  unsigned long long code;
+  if (!(isfinite(x) && isfinite(y) && isfinite(z))) code = 1ull << 30;
+  else {
+    const uint32_t qx = min(1023u, (uint32_t)fmaxf(0.f, __fmul_rn(__fsub_rn(x, lox), ivx)));
+    const uint32_t qy = min(1023u, (uint32_t)fmaxf(0.f, __fmul_rn(__fsub_rn(y, loy), ivy)));
+    const uint32_t qz = min(1023u, (uint32_t)fmaxf(0.f, __fmul_rn(__fsub_rn(z, loz), ivz)));
+    code = expand_bits10_dev(qx) | (expand_bits10_dev(qy) << 1) | (expand_bits10_dev(qz) << 2);
+  }
+  keys[i] = (code << 32) | (unsigned long long)i;
+}
+
+__global__ __launch_bounds__(256) void morton_gather_kernel(const float *__restrict__ raw, const unsigned long long *__restrict__ keys,
+                                                             uint32_t n, float4 *__restrict__ xyzw, int32_t *__restrict__ perm) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t o = (uint32_t)(keys[i] & 0xffffffffull);
+  perm[i] = (int32_t)o;
+  xyzw[i] = make_float4(raw[3 * (size_t)o], raw[3 * (size_t)o + 1], raw[3 * (size_t)o + 2], __int_as_float((int)o));
+}
+
+// d_raw: n*3 floats in input order (device).  Outputs: d_xyzw (n float4, sorted), d_perm (n, sorted position -> input index).
+hipError_t morton_order_device(hipStream_t stream, const float *d_raw, size_t n, const float lo[3], const float inv[3],
+                               float4 *d_xyzw, int32_t *d_perm) {
+  if (n == 0) return hipSuccess;
+  unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+  void *d_tmp = nullptr;
+  hipError_t e = hipMalloc((void **)&d_keys, 8 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_keys2, 8 * n);
+  if (e == hipSuccess) {
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(morton_key_kernel, dim3(nb), dim3(256), 0, stream, d_raw, (uint32_t)n, lo[0], lo[1], lo[2], inv[0], inv[1],
+                       inv[2], d_keys);
+    size_t tb = 0;
+    e = rocprim::radix_sort_keys(nullptr, tb, d_keys, d_keys2, n, 0, 63, stream);
+    if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tb, 16));
+    if (e == hipSuccess) e = rocprim::radix_sort_keys(d_tmp, tb, d_keys, d_keys2, n, 0, 63, stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(morton_gather_kernel, dim3(nb), dim3(256), 0, stream, d_raw, d_keys2, (uint32_t)n, d_xyzw, d_perm);
+      e = hipStreamSynchronize(stream);
+    }
+  }
+  for (void *p : {(void *)d_keys, (void *)d_keys2, d_tmp})
+    if (p) (void)hipFree(p);
+  return e;
+}
+
+}  // namespace ope
+
 using namespace ope;
 
 extern "C" int ope_uniform_sampling(ope_ctx *ctx, const ope_cloud *cloud, float leaf, int32_t *out_idx, size_t *n_out) {
