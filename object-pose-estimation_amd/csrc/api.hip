@@ -18,6 +18,8 @@ void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, uint32_t *);
 int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t, void *, size_t &);
 void fill_iota(hipStream_t, uint32_t *, uint32_t);
 hipError_t morton_order_device(hipStream_t, const float *, size_t, const float[3], const float[3], float4 *, int32_t *);
+hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t, int, const float[3], const float[3], int *, float4 **,
+                            float4 **, float4 **);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
 void launch_icp_update(hipStream_t, IcpState *, const double *);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
@@ -265,6 +267,25 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
   ope_index_default_params(&dp);
   if (params) dp = *params;
   const size_t n = target->n_valid;
+  static const bool host_build = getenv("OPE_HOST_BUILD") != nullptr;  // developer A/B switch: the host reference builder
+  if (!host_build) {
+    // the finite points are the first n_valid records of the Morton-sorted device copy (w = original index)
+    ope_index *ix = new ope_index();
+    ix->ctx = ctx;
+    ix->n = n;
+    ix->n_total = target->n;
+    std::memcpy(ix->bb_lo, target->bb_lo, sizeof ix->bb_lo);
+    std::memcpy(ix->bb_hi, target->bb_hi, sizeof ix->bb_hi);
+    for (int d = 0; d < 3; ++d) ix->pivot[d] = 0.5 * ((double)target->bb_lo[d] + (double)target->bb_hi[d]);
+    const hipError_t e = build_bvh_device(ctx->stream, target->d_xyzw, target->d_nrm, n, dp.leaf_size, target->bb_lo, target->bb_hi,
+                                          &ix->depth, &ix->d_nodes, &ix->d_pts, &ix->d_nrm);
+    if (e != hipSuccess) {
+      ope_index_free(ix);
+      return set_err(ctx, OPE_EHIP, std::string("ope_index_build: ") + hipGetErrorString(e));
+    }
+    *out = ix;
+    return OPE_OK;
+  }
   std::vector<float> xyz(n * 3), nrm;
   std::vector<int32_t> ids(n);
   size_t m = 0;

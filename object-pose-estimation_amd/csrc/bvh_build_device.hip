@@ -1,0 +1,305 @@
+// bvh_build_device.hip — construction of the implicit balanced OBB tree on the device.
+//
+// Replaces the kd-tree build inside Registration::initCompute (vPCL impl/registration_mod.hpp:80-84:
+// tree_->setInputCloud(target_)).  Same structure and the same conservative box margins as the host builder
+// (bvh_build.cpp, kept as the A/B reference behind OPE_HOST_BUILD): a perfect binary tree whose node (l, j)
+// owns the contiguous point range [start(j << (D-l)), start((j+1) << (D-l))), start(k) = k*n >> D.
+//
+//   for every level l < D:   per-node bounding box (wave-reduced atomics on order-preserving integer images of
+//                            the floats) -> split axis = widest extent -> ONE rocPRIM radix sort of
+//                            (node << 32 | coordinate along the node's axis): every node's range is sorted in
+//                            place, so its lower half is its left child.  D sorts of n keys in total.
+//   then, level by level:    one block per node fits the oriented box: mean and covariance in fp64, cyclic
+//                            Jacobi, mid-range centre along the rounded axes, half extents about the ROUNDED
+//                            centre plus the margin that covers the traversal's fp32 evaluation.
+//
+// The tree differs from the host builder's only where equal coordinates straddle a median; the search is exact
+// for any tree whose boxes contain their points.
+#include <cstring>
+#include <string>
+
+#include <rocprim/rocprim.hpp>
+
+#include <cfloat>
+#include <cmath>
+
+#include "ope_internal.hpp"
+
+namespace ope {
+
+namespace {
+
+constexpr int kFitBlock = 256;
+
+__device__ __forceinline__ uint32_t enc_f32(float f) {
+  const uint32_t b = (uint32_t)__float_as_int(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f32(uint32_t u) {
+  const uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __int_as_float((int)b);
+}
+
+// leaf bucket that owns sorted position p: the largest j with (j*n >> D) <= p
+__device__ __forceinline__ uint32_t leaf_of(uint32_t p, uint32_t n, int D) {
+  return (uint32_t)(((((unsigned long long)p + 1ull) << D) - 1ull) / n);
+}
+__device__ __forceinline__ uint32_t leaf_start(unsigned long long j, uint32_t n, int D) { return (uint32_t)((j * n) >> D); }
+
+__global__ __launch_bounds__(256) void level_bbox_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, uint32_t n,
+                                                          int D, int level, uint32_t *__restrict__ mn, uint32_t *__restrict__ mx) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  const bool active = p < n;
+  const uint32_t node = active ? (leaf_of(p, n, D) >> (D - level)) : 0xffffffffu;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (active) { const float4 q = pts[order[p]]; x = q.x; y = q.y; z = q.z; }
+  // a wave usually lies inside one node: reduce there, one atomic per wave and component
+  const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
+  if (__ballot(node != first) == 0ull) {
+    float lx = x, ly = y, lz = z, hx = x, hy = y, hz = z;
+    for (int off = 32; off >= 1; off >>= 1) {
+      lx = fminf(lx, __shfl_xor(lx, off, 64)); ly = fminf(ly, __shfl_xor(ly, off, 64)); lz = fminf(lz, __shfl_xor(lz, off, 64));
+      hx = fmaxf(hx, __shfl_xor(hx, off, 64)); hy = fmaxf(hy, __shfl_xor(hy, off, 64)); hz = fmaxf(hz, __shfl_xor(hz, off, 64));
+    }
+    if ((threadIdx.x & 63u) == 0u && active) {
+      atomicMin(mn + 3 * node + 0, enc_f32(lx)); atomicMin(mn + 3 * node + 1, enc_f32(ly)); atomicMin(mn + 3 * node + 2, enc_f32(lz));
+      atomicMax(mx + 3 * node + 0, enc_f32(hx)); atomicMax(mx + 3 * node + 1, enc_f32(hy)); atomicMax(mx + 3 * node + 2, enc_f32(hz));
+    }
+  } else if (active) {
+    atomicMin(mn + 3 * node + 0, enc_f32(x)); atomicMin(mn + 3 * node + 1, enc_f32(y)); atomicMin(mn + 3 * node + 2, enc_f32(z));
+    atomicMax(mx + 3 * node + 0, enc_f32(x)); atomicMax(mx + 3 * node + 1, enc_f32(y)); atomicMax(mx + 3 * node + 2, enc_f32(z));
+  }
+}
+
+__global__ __launch_bounds__(256) void level_key_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, uint32_t n, int D,
+                                                         int level, const uint32_t *__restrict__ mn, const uint32_t *__restrict__ mx,
+                                                         unsigned long long *__restrict__ keys) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t node = leaf_of(p, n, D) >> (D - level);
+  const float ex = dec_f32(mx[3 * node + 0]) - dec_f32(mn[3 * node + 0]), ey = dec_f32(mx[3 * node + 1]) - dec_f32(mn[3 * node + 1]),
+              ez = dec_f32(mx[3 * node + 2]) - dec_f32(mn[3 * node + 2]);
+  int dim = 0;
+  float e = ex;
+  if (ey > e) { dim = 1; e = ey; }
+  if (ez > e) dim = 2;
+  const float4 q = pts[order[p]];
+  const float c = dim == 0 ? q.x : (dim == 1 ? q.y : q.z);
+  keys[p] = ((unsigned long long)node << 32) | (unsigned long long)enc_f32(c);
+}
+
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *v, uint32_t n, uint32_t value) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i] = value;
+}
+__global__ __launch_bounds__(256) void iota_u32_kernel(uint32_t *v, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+
+__global__ __launch_bounds__(256) void gather_points_kernel(const float4 *__restrict__ src, const float4 *__restrict__ src_nrm,
+                                                             const uint32_t *__restrict__ order, uint32_t n, float4 *__restrict__ dst,
+                                                             float4 *__restrict__ dst_nrm) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t o = order[p];
+  dst[p] = src[o];
+  if (dst_nrm) { float4 m = src_nrm[o]; m.w = 0.f; dst_nrm[p] = m; }
+}
+
+// ---- block-wide reductions of a few doubles
+template <class Op>
+__device__ __forceinline__ double block_reduce(double v, double *s_tmp /*[kFitBlock/64]*/, Op op) {
+  for (int off = 32; off >= 1; off >>= 1) v = op(v, __shfl_xor(v, off, 64));
+  __syncthreads();   // s_tmp may still be read from the previous call
+  if ((threadIdx.x & 63u) == 0u) s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = s_tmp[0];
+  for (int w = 1; w < kFitBlock / 64; ++w) r = op(r, s_tmp[w]);
+  return r;
+}
+struct OpAdd { __device__ double operator()(double a, double b) const { return a + b; } };
+struct OpMin { __device__ double operator()(double a, double b) const { return a < b ? a : b; } };
+struct OpMax { __device__ double operator()(double a, double b) const { return a > b ? a : b; } };
+
+// symmetric 3x3 eigen-decomposition (cyclic Jacobi, fp64); columns of V are eigenvectors
+__device__ void jacobi_eig3_dev(double S[9], double V[9]) {
+  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 50; ++sweep) {
+    const double off = fabs(S[1]) + fabs(S[2]) + fabs(S[5]);
+    const double diag = fabs(S[0]) + fabs(S[4]) + fabs(S[8]);
+    if (off <= 1e-300 || off <= 1e-16 * diag) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = S[3 * p + q];
+        if (apq == 0.0) continue;
+        const double theta = (S[3 * q + q] - S[3 * p + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 3; ++k) {
+          const double a = S[3 * k + p], b = S[3 * k + q];
+          S[3 * k + p] = c * a - s * b;
+          S[3 * k + q] = s * a + c * b;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double a = S[3 * p + k], b = S[3 * q + k];
+          S[3 * p + k] = c * a - s * b;
+          S[3 * q + k] = s * a + c * b;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double a = V[3 * k + p], b = V[3 * k + q];
+          V[3 * k + p] = c * a - s * b;
+          V[3 * k + q] = s * a + c * b;
+        }
+      }
+  }
+}
+
+// One block per node of `level`: oriented box of the node's points (final order), written in the 48-byte layout.
+__global__ __launch_bounds__(kFitBlock) void fit_obb_kernel(const float4 *__restrict__ pts, uint32_t n, int D, int level, double scale,
+                                                            float *__restrict__ nodes) {
+  __shared__ double s_tmp[kFitBlock / 64];
+  __shared__ double s_A[9];
+  __shared__ float s_cf[3];
+  const uint32_t j = blockIdx.x;
+  const uint32_t node = (1u << level) + j;
+  const uint32_t b = leaf_start((unsigned long long)j << (D - level), n, D), e = leaf_start((unsigned long long)(j + 1) << (D - level), n, D);
+  float *o = nodes + (size_t)kNodeFloats * node;
+  if (e <= b) {  // empty leaf (n < 2^D): a box nothing can be close to
+    if (threadIdx.x < kNodeFloats) {
+      float v = 0.f;
+      if (threadIdx.x < 3) v = 1e30f;
+      if (threadIdx.x == 4 || threadIdx.x == 9) v = 1.f;
+      o[threadIdx.x] = v;
+    }
+    return;
+  }
+  const double cnt = (double)(e - b);
+  double sx = 0, sy = 0, sz = 0;
+  for (uint32_t i = b + threadIdx.x; i < e; i += kFitBlock) { const float4 p = pts[i]; sx += p.x; sy += p.y; sz += p.z; }
+  const double mx = block_reduce(sx, s_tmp, OpAdd()) / cnt, my = block_reduce(sy, s_tmp, OpAdd()) / cnt, mz = block_reduce(sz, s_tmp, OpAdd()) / cnt;
+  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+  for (uint32_t i = b + threadIdx.x; i < e; i += kFitBlock) {
+    const float4 p = pts[i];
+    const double vx = p.x - mx, vy = p.y - my, vz = p.z - mz;
+    c00 += vx * vx; c01 += vx * vy; c02 += vx * vz; c11 += vy * vy; c12 += vy * vz; c22 += vz * vz;
+  }
+  c00 = block_reduce(c00, s_tmp, OpAdd()); c01 = block_reduce(c01, s_tmp, OpAdd()); c02 = block_reduce(c02, s_tmp, OpAdd());
+  c11 = block_reduce(c11, s_tmp, OpAdd()); c12 = block_reduce(c12, s_tmp, OpAdd()); c22 = block_reduce(c22, s_tmp, OpAdd());
+  if (threadIdx.x == 0) {
+    double C[9] = {c00, c01, c02, c01, c11, c12, c02, c12, c22}, V[9];
+    jacobi_eig3_dev(C, V);
+    // two axes as floats; the third is their cross product, as the traversal recomputes it
+    float a0[3], a1[3];
+    for (int d = 0; d < 3; ++d) { a0[d] = (float)V[3 * d + 0]; a1[d] = (float)V[3 * d + 1]; }
+    for (int d = 0; d < 3; ++d) { s_A[d] = a0[d]; s_A[3 + d] = a1[d]; }
+    s_A[6] = s_A[1] * s_A[5] - s_A[2] * s_A[4];
+    s_A[7] = s_A[2] * s_A[3] - s_A[0] * s_A[5];
+    s_A[8] = s_A[0] * s_A[4] - s_A[1] * s_A[3];
+    o[4] = a0[0]; o[5] = a0[1]; o[6] = a0[2];
+    o[8] = a1[0]; o[9] = a1[1]; o[10] = a1[2];
+  }
+  __syncthreads();
+  double A[9];
+  for (int k = 0; k < 9; ++k) A[k] = s_A[k];
+  double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+  for (uint32_t i = b + threadIdx.x; i < e; i += kFitBlock) {
+    const float4 p = pts[i];
+    for (int k = 0; k < 3; ++k) {
+      const double t = A[3 * k] * p.x + A[3 * k + 1] * p.y + A[3 * k + 2] * p.z;
+      lo[k] = t < lo[k] ? t : lo[k];
+      hi[k] = t > hi[k] ? t : hi[k];
+    }
+  }
+  double mid[3];
+  for (int k = 0; k < 3; ++k) mid[k] = 0.5 * (block_reduce(lo[k], s_tmp, OpMin()) + block_reduce(hi[k], s_tmp, OpMax()));
+  if (threadIdx.x == 0)
+    for (int d = 0; d < 3; ++d) s_cf[d] = (float)(mid[0] * A[d] + mid[1] * A[3 + d] + mid[2] * A[6 + d]);
+  __syncthreads();
+  const float cf0 = s_cf[0], cf1 = s_cf[1], cf2 = s_cf[2];
+  // half extents about the ROUNDED centre, measured with the rounded axes
+  double h[3] = {0, 0, 0}, far = 0;
+  for (uint32_t i = b + threadIdx.x; i < e; i += kFitBlock) {
+    const float4 p = pts[i];
+    const double vx = (double)p.x - cf0, vy = (double)p.y - cf1, vz = (double)p.z - cf2;
+    const double r = sqrt(vx * vx + vy * vy + vz * vz);
+    far = r > far ? r : far;
+    for (int k = 0; k < 3; ++k) {
+      const double t = fabs(A[3 * k] * vx + A[3 * k + 1] * vy + A[3 * k + 2] * vz);
+      h[k] = t > h[k] ? t : h[k];
+    }
+  }
+  far = block_reduce(far, s_tmp, OpMax());
+  for (int k = 0; k < 3; ++k) h[k] = block_reduce(h[k], s_tmp, OpMax());
+  if (threadIdx.x == 0) {
+    // margin covering the traversal's fp32 evaluation of the projections (relative 4e-6 of the offset, i.e.
+    // > 10 fp32 ulps, and an absolute floor), exactly as bvh_build.cpp
+    const double margin = 4e-6 * far + 1e-7 * scale;
+    o[0] = cf0; o[1] = cf1; o[2] = cf2;
+    for (int k = 0; k < 3; ++k) o[4 * k + 3] = nextafterf((float)(h[k] + margin), FLT_MAX);
+  }
+}
+
+}  // namespace
+
+// d_src: n finite points (float4, w = original index bits) in any order, d_src_nrm optional (same order).
+// Allocates *d_nodes ((2 << D) * 48 B), *d_pts and (if normals) *d_nrm.
+hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float4 *d_src_nrm, size_t n, int leaf_size,
+                            const float bb_lo[3], const float bb_hi[3], int *out_depth, float4 **d_nodes, float4 **d_pts,
+                            float4 **d_nrm) {
+  if (leaf_size < 1) leaf_size = 16;
+  int D = 0;
+  while (((n + ((size_t)1 << D) - 1) >> D) > (size_t)leaf_size) ++D;
+  if (D > kMaxDepth) D = kMaxDepth;
+  *out_depth = D;
+  const size_t n_nodes = (size_t)2 << D;
+  const double scale = std::max({(double)bb_hi[0] - bb_lo[0], (double)bb_hi[1] - bb_lo[1], (double)bb_hi[2] - bb_lo[2], 1e-3}) +
+                       std::max({std::fabs((double)bb_lo[0]), std::fabs((double)bb_hi[0]), std::fabs((double)bb_lo[1]),
+                                 std::fabs((double)bb_hi[1]), std::fabs((double)bb_lo[2]), std::fabs((double)bb_hi[2])});
+  unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+  uint32_t *d_order = nullptr, *d_order2 = nullptr, *d_mn = nullptr, *d_mx = nullptr;
+  void *d_tmp = nullptr;
+  const uint32_t nn = (uint32_t)n;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  hipError_t e = hipMalloc((void **)d_nodes, n_nodes * kNodeFloats * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void **)d_pts, sizeof(float4) * n);
+  if (e == hipSuccess && d_src_nrm) e = hipMalloc((void **)d_nrm, sizeof(float4) * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_keys, 8 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_keys2, 8 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_order, 4 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_order2, 4 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_mn, 12 * ((size_t)1 << D));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_mx, 12 * ((size_t)1 << D));
+  size_t tmp_bytes = 0;
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_order, d_order2, n, 0, 64, stream);
+  if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(iota_u32_kernel, dim3(nb), dim3(256), 0, stream, d_order, nn);
+    for (int level = 0; level < D && e == hipSuccess; ++level) {
+      const uint32_t cnt = 3u << level;
+      hipLaunchKernelGGL(fill_u32_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_mn, cnt, 0xffffffffu);
+      hipLaunchKernelGGL(fill_u32_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_mx, cnt, 0u);
+      hipLaunchKernelGGL(level_bbox_kernel, dim3(nb), dim3(256), 0, stream, d_src, d_order, nn, D, level, d_mn, d_mx);
+      hipLaunchKernelGGL(level_key_kernel, dim3(nb), dim3(256), 0, stream, d_src, d_order, nn, D, level, d_mn, d_mx, d_keys);
+      size_t tb = tmp_bytes;
+      e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_order, d_order2, n, 0, 32 + std::max(level, 1), stream);
+      std::swap(d_order, d_order2);
+    }
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(gather_points_kernel, dim3(nb), dim3(256), 0, stream, d_src, d_src_nrm, d_order, nn, *d_pts,
+                       d_src_nrm ? *d_nrm : nullptr);
+    for (int level = 0; level <= D; ++level)
+      hipLaunchKernelGGL(fit_obb_kernel, dim3(1u << level), dim3(kFitBlock), 0, stream, *d_pts, nn, D, level, scale,
+                         reinterpret_cast<float *>(*d_nodes));
+    // node 0 is unused: give it the root box so stray reads are harmless
+    e = hipMemcpyAsync(*d_nodes, reinterpret_cast<float *>(*d_nodes) + kNodeFloats, kNodeFloats * sizeof(float), hipMemcpyDeviceToDevice,
+                       stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  }
+  for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_order, (void *)d_order2, (void *)d_mn, (void *)d_mx, d_tmp})
+    if (p) (void)hipFree(p);
+  return e;
+}
+
+}  // namespace ope

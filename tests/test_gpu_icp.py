@@ -56,6 +56,33 @@ def test_nn_search_bit_exact_vs_oracle(ctx, nt, nq, leaf):
         assert len(bad) <= max(2, nq // 10000)
 
 
+@pytest.mark.parametrize("kind", ["duplicates", "collinear", "planar", "two_clusters"])
+def test_nn_search_degenerate_targets(ctx, kind):
+    """Index build corner cases (device PCA fit): zero-extent boxes, rank-deficient covariances, equal split keys."""
+    rng = np.random.default_rng(5)
+    if kind == "duplicates":
+        tgt = np.tile(np.array([[0.01, -0.02, 0.03]], np.float32), (3000, 1))
+        tgt[:7] += rng.uniform(-1e-3, 1e-3, (7, 3)).astype(np.float32)
+    elif kind == "collinear":
+        t = rng.uniform(-0.1, 0.1, 4000).astype(np.float32)
+        tgt = np.stack([t, 2 * t, -t], axis=1).astype(np.float32)
+    elif kind == "planar":
+        tgt = np.concatenate([rng.uniform(-0.1, 0.1, (5000, 2)), np.zeros((5000, 1))], axis=1).astype(np.float32)
+    else:
+        tgt = np.concatenate([rng.normal(0, 1e-4, (2500, 3)) + [0.1, 0, 0], rng.normal(0, 1e-4, (2500, 3)) - [0.1, 0, 0]]).astype(np.float32)
+    q = rng.uniform(-0.15, 0.15, (20000, 3)).astype(np.float32)
+    ct, cq = ctx.upload(tgt), ctx.upload(q)
+    ix = ctx.build_index(ct, leaf_size=8)
+    idx, d2 = ctx.nn(cq, ix)
+    oi, od, _ = oracle.KdTree(tgt).knn(q, 1)
+    np.testing.assert_array_equal(d2, od[:, 0])
+    same = idx == oi[:, 0]
+    if kind in ("planar", "two_clusters"):     # the other two are full of exact fp32 distance ties by construction
+        assert same.mean() > 0.999
+    alt = ((q[~same] - tgt[idx[~same]]) ** 2).astype(np.float32)
+    assert np.allclose(alt.sum(1), od[~same, 0], rtol=1e-6)      # only exact ties may pick another index
+
+
 def test_nn_search_with_transform_and_nan_queries(ctx):
     rng = np.random.default_rng(1)
     tgt = synth.model_surface(5000, 1)
