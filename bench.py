@@ -146,7 +146,7 @@ def main() -> int:
                   "sacia_best_iteration": int(sac_it), "sacia_error": float(sac_err),
                   "pose_error_vs_ground_truth_frobenius": float(np.linalg.norm(guess.astype(np.float64) - gt)),
                   "stages": stage,
-                  "note": "host wall-clock incl. uploads and host-side index builds; not part of value. The synthetic "
+                  "note": "host wall-clock incl. uploads, device index builds and read-backs; not part of value. The synthetic "
                           "model is nearly symmetric under a half turn: SAC-IA may land on the mirrored fit "
                           "(Frobenius 2.83 from the generator's pose, same residual to 1%)"}
 
