@@ -13,7 +13,7 @@ namespace ope {
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
-                           uint32_t *, const uint32_t *);
+                           uint32_t *, const uint32_t *, bool);
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, uint32_t *);
 int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t, void *, size_t &);
 void fill_iota(hipStream_t, uint32_t *, uint32_t);
@@ -86,9 +86,13 @@ static int enqueue_accumulate(ope_ctx *ctx) {
   const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
   if (timed) OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], ctx->stream));
   const bool recip = p.use_reciprocal != 0;
+  // packet walks for coherent chunks pay off when the launch fills the GPU (C3: 195 -> 184 us); on an underfilled
+  // one (a 1/8 shard, C2) the longer dependent chain of a packet costs more than its gathers save (77 -> 88 us)
+  static const bool no_packet = getenv("OPE_NO_PACKET") != nullptr;  // developer A/B switch
+  const bool packet = !no_packet && nch > (uint32_t)ctx->n_cu * 4u * (uint32_t)kAccWavesPerSimd;
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
                         recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
-                        ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8);
+                        ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet);
   if (timed) {
     OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
     ++ctx->prof_used;
@@ -119,6 +123,10 @@ int ope_ctx_create(ope_ctx **out, int device_ordinal) {
   if (device_ordinal < 0 || device_ordinal >= n) return set_err(nullptr, OPE_ENODEV, "bad device ordinal");
   ope_ctx *ctx = new ope_ctx();
   ctx->device = device_ordinal;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+  }
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
     delete ctx;
     return set_err(nullptr, OPE_EHIP, "hipSetDevice/hipStreamCreate failed");

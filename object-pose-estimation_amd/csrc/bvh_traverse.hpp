@@ -67,6 +67,10 @@ __device__ __forceinline__ void load_node(const BvhView &t, uint32_t node, v4f &
 }
 
 template <class Visitor>
+__device__ __forceinline__ void bvh_walk(const BvhView &t, float qx, float qy, float qz, Visitor &v, float *stk, int stk_stride,
+                                         uint32_t node, uint32_t trail, float minb, bool node_done);
+
+template <class Visitor>
 __device__ __forceinline__ void bvh_traverse(const BvhView &t, float qx, float qy, float qz, Visitor &v, float *stk,
                                              int stk_stride, uint32_t start_leaf = 0) {
   const uint32_t leaf0 = 1u << t.depth;
@@ -101,12 +105,22 @@ __device__ __forceinline__ void bvh_traverse(const BvhView &t, float qx, float q
     load_node(t, 1, a, b, c);
     if (v.prune(obb_dist2(a, b, c, qx, qy, qz))) return;
   }
-  // Flat loop: each trip advances every lane by one unit of work (an inner-node step OR a whole leaf
-  // scan), then backs up through LDS-parked bounds.  Measured alternatives on C3 (same box, same
-  // build otherwise): "while-while" (all lanes walk to a leaf, then scan together) 442 us vs 283 us;
-  // one unified 6-load trip per lane state 467 us.
+  bvh_walk(t, qx, qy, qz, v, stk, stk_stride, node, trail, minb, false);
+}
+
+// The walk proper, from a state {node, trail, minb, parked bounds}.  Flat loop: each trip advances every lane by
+// one unit of work (an inner-node step OR a whole leaf scan), then backs up through LDS-parked bounds.  Measured
+// alternatives on C3 (same box, same build otherwise): "while-while" (all lanes walk to a leaf, then scan
+// together) 442 us vs 283 us; one unified 6-load trip per lane state 467 us.
+// node_done: `node` has been dealt with already (start by backing up).
+template <class Visitor>
+__device__ __forceinline__ void bvh_walk(const BvhView &t, float qx, float qy, float qz, Visitor &v, float *stk, int stk_stride,
+                                         uint32_t node, uint32_t trail, float minb, bool node_done) {
+  const uint32_t leaf0 = 1u << t.depth;
   for (;;) {
-    if (node < leaf0) {
+    if (node_done) {
+      node_done = false;
+    } else if (node < leaf0) {
       v.on_node();
       v4f c0, c1, c2, c3, c4, c5;
       load_node(t, 2 * node, c0, c1, c2);
@@ -172,6 +186,115 @@ struct NearestVisitor {
   }
   __device__ __forceinline__ void on_node() {}
 };
+
+// ------------------------------------------------------------------------------------------
+// Packet traversal: ONE walk for the 64 queries of a coherent chunk.  Morton-adjacent surface points were matched to
+// a handful of leaves in the previous iteration and walk nearly the same nodes; here the walk's control state (node,
+// pending bits) is wave-uniform, so nodes and leaf points are fetched through the SCALAR cache (one s_load per record
+// for the whole wave instead of 64 divergent 16-byte gathers) and only the box / distance arithmetic is per lane.
+// A sibling is entered if ANY lane can still improve there; per-lane bounds of pending siblings are parked in the
+// same LDS slots as in the per-lane walk.  Exact for every lane.  Returns false (nothing lost: v keeps what was
+// found) if the chunk is not coherent enough (more than kPacketMaxLeaves distinct start leaves, or a lane without
+// one); the caller then runs the per-lane walk.  Measured on C3: 6 leaves 184 us, 3 leaves 197 us (= no packets),
+// 12 leaves 306 us (the union of less coherent walks is long); handing over to per-lane walks after the shared
+// start (leaf scans + ancestor siblings through the scalar cache only) 198 us.
+constexpr int kPacketMaxLeaves = 6;
+
+// A 16-byte load through the CONSTANT address space: with a wave-uniform address the compiler selects s_load_dwordx4
+// (scalar cache, result in SGPRs).  Legal because the index is never written while a search kernel runs.
+typedef const __attribute__((address_space(4))) v4f *scalar_ptr_v4f;
+__device__ __forceinline__ v4f ld16_scalar(const float4 *p) {
+  return *reinterpret_cast<scalar_ptr_v4f>(reinterpret_cast<unsigned long long>(p));
+}
+__device__ __forceinline__ void load_node_scalar(const BvhView &t, uint32_t node, v4f &a, v4f &b, v4f &c) {
+  const float4 *o = t.nodes + 3 * (size_t)node;
+  a = ld16_scalar(o); b = ld16_scalar(o + 1); c = ld16_scalar(o + 2);
+}
+
+__device__ __forceinline__ void scan_leaf_uniform(const BvhView &t, uint32_t node, float qx, float qy, float qz, NearestVisitor &v) {
+  const uint32_t j = node - (1u << t.depth);
+  const uint32_t s = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
+  const uint32_t e = (uint32_t)(((unsigned long long)(j + 1) * t.n) >> t.depth);
+  for (uint32_t i = s; i < e; i += 4) {
+    const uint32_t m = e - 1;
+    const v4f p0 = ld16_scalar(t.pts + i), p1 = ld16_scalar(t.pts + min(i + 1, m)), p2 = ld16_scalar(t.pts + min(i + 2, m)),
+              p3 = ld16_scalar(t.pts + min(i + 3, m));
+    v.point(sq_dist3(__fsub_rn(qx, p0.x), __fsub_rn(qy, p0.y), __fsub_rn(qz, p0.z)), p0, i, node);
+    if (i + 1 < e) v.point(sq_dist3(__fsub_rn(qx, p1.x), __fsub_rn(qy, p1.y), __fsub_rn(qz, p1.z)), p1, i + 1, node);
+    if (i + 2 < e) v.point(sq_dist3(__fsub_rn(qx, p2.x), __fsub_rn(qy, p2.y), __fsub_rn(qz, p2.z)), p2, i + 2, node);
+    if (i + 3 < e) v.point(sq_dist3(__fsub_rn(qx, p3.x), __fsub_rn(qy, p3.y), __fsub_rn(qz, p3.z)), p3, i + 3, node);
+  }
+}
+
+__device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, float qy, float qz, bool active, NearestVisitor &v,
+                                                    uint32_t hint, float *stk, int stk_stride) {
+  const uint32_t leaf0 = 1u << t.depth;
+  const int D = t.depth;
+  const unsigned long long act = __ballot(active);
+  if (act == 0ull || __ballot(active && hint == 0u) != 0ull) return false;
+  // the distinct start leaves, scanned by every lane
+  uint32_t seen[kPacketMaxLeaves];
+  int nd = 0;
+  unsigned long long todo = act;
+  while (todo != 0ull) {
+    if (nd == kPacketMaxLeaves) return false;
+    const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)hint, (int)__builtin_ctzll(todo));
+    scan_leaf_uniform(t, L, qx, qy, qz, v);
+    todo &= ~__ballot(hint == L);
+    seen[nd++] = L;
+  }
+  // per-lane bounds of the first leaf's ancestor siblings (that leaf plus those D subtrees cover the tree), two
+  // scalar fetches (24 SGPRs) in flight, parked like the per-lane walk parks them
+  const uint32_t anchor = seen[0];
+  uint32_t node = anchor, trail = leaf0 - 1u;   // wave-uniform
+  float minb = INFINITY;
+  for (int k = 0; k < D; k += 2) {
+    v4f a0, b0, c0, a1, b1, c1;
+    const uint32_t s0 = (anchor >> k) ^ 1u;
+    const uint32_t s1 = (k + 1 < D) ? ((anchor >> (k + 1)) ^ 1u) : s0;
+    load_node_scalar(t, s0, a0, b0, c0);
+    load_node_scalar(t, s1, a1, b1, c1);
+    const float e0 = obb_dist2(a0, b0, c0, qx, qy, qz), e1 = obb_dist2(a1, b1, c1, qx, qy, qz);
+    stk[(D - k) * stk_stride] = e0;
+    if (k + 1 < D) stk[(D - k - 1) * stk_stride] = e1;
+    minb = fminf(minb, fminf(e0, e1));
+  }
+  for (;;) {
+    // back up to the deepest pending sibling that ANY lane can still improve in (inactive lanes carry best = -inf)
+    if (__ballot(minb < v.best) == 0ull) return true;
+    bool more = false;
+    while (trail != 0u) {
+      const int k = __builtin_ctz(trail);
+      node = (node >> k) ^ 1u;
+      trail = (trail >> k) & ~1u;
+      if (__ballot(stk[(31 - __clz(node)) * stk_stride] < v.best) != 0ull) { more = true; break; }
+    }
+    if (!more) return true;
+    // walk down from there
+    for (;;) {
+      if (node >= leaf0) {
+        bool dup = false;
+        for (int q = 0; q < nd; ++q) dup = dup || (seen[q] == node);
+        if (!dup) scan_leaf_uniform(t, node, qx, qy, qz, v);
+        break;
+      }
+      v4f c0, c1, c2, c3, c4, c5;
+      load_node_scalar(t, 2 * node, c0, c1, c2);
+      load_node_scalar(t, 2 * node + 1, c3, c4, c5);
+      const float d0 = obb_dist2(c0, c1, c2, qx, qy, qz);
+      const float d1 = obb_dist2(c3, c4, c5, qx, qy, qz);
+      const unsigned long long n0 = __ballot(d0 < v.best), n1 = __ballot(d1 < v.best);
+      if ((n0 | n1) == 0ull) break;
+      // nearer child first by majority; the other one is parked if any lane wants it
+      const bool right = (n0 == 0ull) || (n1 != 0ull && 2 * __popcll(__ballot(d1 < d0) & act) > __popcll(act));
+      const bool pend = right ? (n0 != 0ull) : (n1 != 0ull);
+      const float df = right ? d0 : d1;
+      node = 2 * node + (right ? 1u : 0u);
+      trail = (trail << 1) | (pend ? 1u : 0u);
+      if (pend) { stk[(31 - __clz(node)) * stk_stride] = df; minb = fminf(minb, df); }
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // Group ("oct") traversal: EIGHT lanes serve ONE query.  Used for the chunks whose queries are far from

@@ -27,7 +27,7 @@ namespace ope {
 // if the nearest SOURCE point of target point j is i again.  The reference searches a kd-tree rebuilt
 // over the transformed source every iteration; here the source index is built once in the source's own
 // frame and queried with F^-1 * t_j (a rigid map preserves the ranking up to fp32 rounding).
-template <int MODE, bool NRM, bool RECIP = false>
+template <int MODE, bool NRM, bool RECIP = false, bool PACKET = false>
 __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !RECIP) ? kAccWavesPerSimd : 4) void icp_accumulate_kernel(
     CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
@@ -41,10 +41,9 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   float *stk = &s_stk[0][threadIdx.x];
   extern __shared__ unsigned char s_dyn[];  // MODE 1: k-NN lists
 
-  float F[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) F[i] = st->Ff[i];
-  const float psx = (float)st->pivot[0], psy = (float)st->pivot[1], psz = (float)st->pivot[2];
+  // Per-run constants live in LDS and are re-read where they are used (through a pointer the optimiser cannot see
+  // through): held in registers across the walk they were spilled to scratch, 13 dwords per lane and launch.
+  __shared__ float s_const[16];   // F rows [0..11], pivot [12..14], best0 [15]
   const double max_d2 = st->max_d2;
   // With a finite setMaxCorrespondenceDistance the 1-NN search only has to see points that can survive the
   // threshold test (correspondence_estimation_mod.hpp:171 rejects d2 > max_d2 afterwards anyway): start from the
@@ -55,6 +54,10 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     if ((double)f < max_d2) f = nextafterf(f, INFINITY);
     best0 = nextafterf(f, INFINITY);
   }
+  if (threadIdx.x < 12) s_const[threadIdx.x] = st->Ff[threadIdx.x];
+  else if (threadIdx.x < 15) s_const[threadIdx.x] = (float)st->pivot[threadIdx.x - 12];
+  else if (threadIdx.x == 15) s_const[15] = best0;
+  __syncthreads();
   const bool rej_sn = NRM && st->use_surface_normal_rej;
   const bool rej_so = NRM && st->use_self_occluded_rej;
   const double thr_sn = st->surface_normal_thr, thr_so = st->self_occluded_thr;
@@ -96,6 +99,11 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     const uint32_t i = oct ? (base + (slot & 7u) * 8u + (lane_id >> 3)) : (base + lane_id);
     const bool active = i < src.n_valid;
     const bool owner = active && (!oct || (lane_id & 7u) == 0u);  // the one lane that reports a query
+    const float *cst = s_const;
+    asm volatile("" : "+v"(cst));   // keep the constants' loads here, inside the chunk loop
+    float F[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) F[k] = cst[k];
     const float4 s = src.xyzw[active ? i : base];
     const float x = xform_row(F + 0, s.x, s.y, s.z);
     const float y = xform_row(F + 4, s.x, s.y, s.z);
@@ -112,12 +120,16 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     uint32_t pos = 0;
     int match = -1;
     if (MODE == 0) {
-      NearestVisitor v{active ? best0 : -INFINITY, kNoPos, 0};
+      NearestVisitor v{active ? cst[15] : -INFINITY, kNoPos, 0};
       // start at the leaf that held this query's nearest neighbour one iteration ago (0 = none yet)
       if (OCT_OK && oct) {
         if (active) bvh_traverse_oct(tgt, x, y, z, v, &s_stk[0][threadIdx.x & ~7u], BLOCK, hint[i]);
       } else {
-        if (active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, hint[i]);
+        // coherent chunks (a handful of start leaves for 64 queries) take one packet walk through the scalar cache
+        // (PACKET instantiation: launches that fill the GPU); everything else the per-lane walk from its own leaf
+        const uint32_t h = active ? hint[i] : 0u;
+        const bool done = PACKET && bvh_traverse_packet(tgt, x, y, z, active, v, h, stk, BLOCK);
+        if (!done && active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, h);
       }
       if (owner) hint[i] = v.leaf;
       const bool found = active && v.pos != kNoPos;
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
         for (int k = 0; k < 12; ++k) G[k] = st->Finv[k];
         const float4 t = tgt.pts[pos];
         const float bx = xform_row(G + 0, t.x, t.y, t.z), by = xform_row(G + 4, t.x, t.y, t.z), bz = xform_row(G + 8, t.x, t.y, t.z);
-        NearestVisitor r{ok ? best0 : -INFINITY, kNoPos, 0};
+        NearestVisitor r{ok ? cst[15] : -INFINITY, kNoPos, 0};
         if (ok) bvh_traverse(srcix, bx, by, bz, r, stk, BLOCK);
         ok = ok && r.pos != kNoPos && !((double)r.best > max_d2) &&
              __float_as_int(srcix.pts[r.pos].w) == __float_as_int(s.w);
@@ -179,6 +191,9 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       // fp64 terms: differences and products of fp32 values are exact in fp64, so the 17 sums do not
       // depend (beyond 1e-16) on how queries are grouped into lanes, chunks, waves or ranks
       const float4 t = tgt.pts[ok ? pos : 0];
+      const float *cs2 = s_const;
+      asm volatile("" : "+v"(cs2));
+      const float psx = cs2[12], psy = cs2[13], psz = cs2[14];
       const double sx = (double)x - (double)psx, sy = (double)y - (double)psy, sz = (double)z - (double)psz;
       const double tx = (double)t.x - (double)psx, ty = (double)t.y - (double)psy, tz = (double)t.z - (double)psz;
       // 16-lane row sums by DPP (pure VALU), then one ds_add_f64 per row and component into the wave's
@@ -798,10 +813,19 @@ __global__ __launch_bounds__(256) void fitness_kernel(CloudView q, BvhView tgt, 
 void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, bool recip, const CloudView &src,
                            const BvhView &tgt, const BvhView &srcix, const IcpState *st, double *partials,
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
-                           const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info) {
+                           const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet) {
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS)                                                                       \
   hipLaunchKernelGGL((icp_accumulate_kernel<M, N, R>), dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, \
                      partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info)
+  if (mode == 0 && !recip && packet) {
+    if (nrm)
+      hipLaunchKernelGGL((icp_accumulate_kernel<0, true, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info);
+    else
+      hipLaunchKernelGGL((icp_accumulate_kernel<0, false, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info);
+    return;
+  }
   if (mode == 0) {
     if (recip) { if (nrm) OPE_LAUNCH_ACC(0, true, true, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, true, kAccBlock, 0); }
     else       { if (nrm) OPE_LAUNCH_ACC(0, true, false, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, false, kAccBlock, 0); }

@@ -73,6 +73,7 @@ constexpr int kAccMaxBlocks = 1024;  // partials rows; the update kernel reduces
 
 struct ope_ctx {
   int device = -1;
+  int n_cu = 256;   // compute units of the device (MI355X: 256)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string err;
