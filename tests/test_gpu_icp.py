@@ -347,3 +347,32 @@ def test_point_to_plane_needs_target_normals(ctx):
     with pytest.raises(ope.OpeError) as e:
         ctx.icp(cs, ix, ope.default_icp_params(estimator=ope.EST_POINT_TO_PLANE_LLS))
     assert e.value.code == ope.OPE_EINVAL
+
+
+def test_icp_large_launch_packet_walk_matches_oracle(ctx):
+    """A launch that fills the GPU (> 6144 chunks of 64 queries on an MI355X) runs the PACKET instantiation:
+    coherent chunks take one wave-uniform walk through the scalar cache.  Same exact correspondences."""
+    src = synth.scene_cloud(420_000)
+    tgt = synth.model_surface(20_000, 1)
+    kw = dict(max_iterations=4, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0)
+    out, cs, ix = gpu_icp(ctx, src, tgt, **kw)
+    ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw))
+    assert out.iterations == ref.iterations == 4
+    assert frob(out.T, ref.T) < 1e-5                       # north_star tolerance is 1e-4
+    q, m, d = ctx.icp_correspondences(len(src))
+    assert len(q) == ref.n_corr == len(src)
+    same = m == ref.corr_m
+    assert same.mean() > 0.9999
+    # the last iteration's squared distances: same unfused fp32 arithmetic wherever the transforms agree to the bit
+    np.testing.assert_allclose(d, ref.corr_d2, rtol=2e-3, atol=1e-10)
+    # bit for bit: the second iteration (start leaves known -> packet walks) searches with the transform the first
+    # one produced; the oracle searching with that very transform must see identical squared distances
+    ope = load_pkg()
+    one = ctx.icp(cs, ix, ope.default_icp_params(**{**kw, "max_iterations": 1}))
+    two = ctx.icp(cs, ix, ope.default_icp_params(**{**kw, "max_iterations": 2}))
+    q2, m2, d2 = ctx.icp_correspondences(len(src))
+    oi, od, _ = oracle.KdTree(tgt).knn(oracle.transform_points(src, one.T), 1)
+    np.testing.assert_array_equal(d2, od[:, 0])
+    diff = m2 != oi[:, 0]
+    assert diff.mean() < 1e-4                              # exact fp32 distance ties may pick another index
+    assert two.iterations == 2
