@@ -19,7 +19,7 @@ int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint
 void fill_iota(hipStream_t, uint32_t *, uint32_t);
 hipError_t morton_order_device(hipStream_t, const float *, size_t, const float[3], const float[3], float4 *, int32_t *);
 hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t, int, const float[3], const float[3], int *, float4 **,
-                            float4 **, float4 **);
+                            float4 **, float4 **, float4 **);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
 void launch_icp_update(hipStream_t, IcpState *, const double *);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
@@ -286,7 +286,7 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
     std::memcpy(ix->bb_hi, target->bb_hi, sizeof ix->bb_hi);
     for (int d = 0; d < 3; ++d) ix->pivot[d] = 0.5 * ((double)target->bb_lo[d] + (double)target->bb_hi[d]);
     const hipError_t e = build_bvh_device(ctx->stream, target->d_xyzw, target->d_nrm, n, dp.leaf_size, target->bb_lo, target->bb_hi,
-                                          &ix->depth, &ix->d_nodes, &ix->d_pts, &ix->d_nrm);
+                                          &ix->depth, &ix->d_nodes, &ix->d_pts, &ix->d_nrm, &ix->d_axis2);
     if (e != hipSuccess) {
       ope_index_free(ix);
       return set_err(ctx, OPE_EHIP, std::string("ope_index_build: ") + hipGetErrorString(e));
@@ -346,6 +346,7 @@ void ope_index_free(ope_index *index) {
   if (index->d_nodes) (void)hipFree(index->d_nodes);
   if (index->d_pts) (void)hipFree(index->d_pts);
   if (index->d_nrm) (void)hipFree(index->d_nrm);
+  if (index->d_axis2) (void)hipFree(index->d_axis2);
   delete index;
 }
 

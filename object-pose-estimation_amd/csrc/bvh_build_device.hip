@@ -157,7 +157,7 @@ __device__ void jacobi_eig3_dev(double S[9], double V[9]) {
 
 // One block per node of `level`: oriented box of the node's points (final order), written in the 48-byte layout.
 __global__ __launch_bounds__(kFitBlock) void fit_obb_kernel(const float4 *__restrict__ pts, uint32_t n, int D, int level, double scale,
-                                                            float *__restrict__ nodes) {
+                                                            float *__restrict__ nodes, float4 *__restrict__ axis2) {
   __shared__ double s_tmp[kFitBlock / 64];
   __shared__ double s_A[9];
   __shared__ float s_cf[3];
@@ -172,6 +172,7 @@ __global__ __launch_bounds__(kFitBlock) void fit_obb_kernel(const float4 *__rest
       if (threadIdx.x == 4 || threadIdx.x == 9) v = 1.f;
       o[threadIdx.x] = v;
     }
+    if (threadIdx.x == 0) axis2[node] = make_float4(0.f, 0.f, 1.f, 0.f);
     return;
   }
   const double cnt = (double)(e - b);
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(kFitBlock) void fit_obb_kernel(const float4 *__rest
     s_A[8] = s_A[0] * s_A[4] - s_A[1] * s_A[3];
     o[4] = a0[0]; o[5] = a0[1]; o[6] = a0[2];
     o[8] = a1[0]; o[9] = a1[1]; o[10] = a1[2];
+    axis2[node] = make_float4((float)s_A[6], (float)s_A[7], (float)s_A[8], 0.f);
   }
   __syncthreads();
   double A[9];
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(kFitBlock) void fit_obb_kernel(const float4 *__rest
 // Allocates *d_nodes ((2 << D) * 48 B), *d_pts and (if normals) *d_nrm.
 hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float4 *d_src_nrm, size_t n, int leaf_size,
                             const float bb_lo[3], const float bb_hi[3], int *out_depth, float4 **d_nodes, float4 **d_pts,
-                            float4 **d_nrm) {
+                            float4 **d_nrm, float4 **d_axis2) {
   if (leaf_size < 1) leaf_size = 16;
   int D = 0;
   while (((n + ((size_t)1 << D) - 1) >> D) > (size_t)leaf_size) ++D;
@@ -262,6 +264,7 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
   const uint32_t nn = (uint32_t)n;
   const unsigned nb = (unsigned)((n + 255) / 256);
   hipError_t e = hipMalloc((void **)d_nodes, n_nodes * kNodeFloats * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void **)d_axis2, n_nodes * sizeof(float4));
   if (e == hipSuccess) e = hipMalloc((void **)d_pts, sizeof(float4) * n);
   if (e == hipSuccess && d_src_nrm) e = hipMalloc((void **)d_nrm, sizeof(float4) * n);
   if (e == hipSuccess) e = hipMalloc((void **)&d_keys, 8 * n);
@@ -291,10 +294,11 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
                        d_src_nrm ? *d_nrm : nullptr);
     for (int level = 0; level <= D; ++level)
       hipLaunchKernelGGL(fit_obb_kernel, dim3(1u << level), dim3(kFitBlock), 0, stream, *d_pts, nn, D, level, scale,
-                         reinterpret_cast<float *>(*d_nodes));
+                         reinterpret_cast<float *>(*d_nodes), *d_axis2);
     // node 0 is unused: give it the root box so stray reads are harmless
     e = hipMemcpyAsync(*d_nodes, reinterpret_cast<float *>(*d_nodes) + kNodeFloats, kNodeFloats * sizeof(float), hipMemcpyDeviceToDevice,
                        stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(*d_axis2, *d_axis2 + 1, sizeof(float4), hipMemcpyDeviceToDevice, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
   }
   for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_order, (void *)d_order2, (void *)d_mn, (void *)d_mx, d_tmp})

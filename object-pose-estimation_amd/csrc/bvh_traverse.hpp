@@ -210,6 +210,20 @@ __device__ __forceinline__ void load_node_scalar(const BvhView &t, uint32_t node
   const float4 *o = t.nodes + 3 * (size_t)node;
   a = ld16_scalar(o); b = ld16_scalar(o + 1); c = ld16_scalar(o + 2);
 }
+// box bound with the third axis given (packet walk: a fourth scalar fetch instead of nine per-lane multiplies)
+__device__ __forceinline__ float obb_dist2_axes(const v4f n0, const v4f n1, const v4f n2, const v4f n3, float qx, float qy, float qz) {
+  const float dx = qx - n0.x, dy = qy - n0.y, dz = qz - n0.z;
+  const float t0 = fmaxf(fabsf(__fmaf_rn(dz, n1.z, __fmaf_rn(dy, n1.y, dx * n1.x))) - n0.w, 0.f);
+  const float t1 = fmaxf(fabsf(__fmaf_rn(dz, n2.z, __fmaf_rn(dy, n2.y, dx * n2.x))) - n1.w, 0.f);
+  const float t2 = fmaxf(fabsf(__fmaf_rn(dz, n3.z, __fmaf_rn(dy, n3.y, dx * n3.x))) - n2.w, 0.f);
+  return __fmaf_rn(t2, t2, __fmaf_rn(t1, t1, t0 * t0)) * 0.999996f;
+}
+__device__ __forceinline__ float packet_box_bound(const BvhView &t, uint32_t node, float qx, float qy, float qz) {
+  v4f a, b, c;
+  load_node_scalar(t, node, a, b, c);
+  if (t.axis2 == nullptr) return obb_dist2(a, b, c, qx, qy, qz);
+  return obb_dist2_axes(a, b, c, ld16_scalar(t.axis2 + node), qx, qy, qz);
+}
 
 __device__ __forceinline__ void scan_leaf_uniform(const BvhView &t, uint32_t node, float qx, float qy, float qz, NearestVisitor &v) {
   const uint32_t j = node - (1u << t.depth);
@@ -249,12 +263,9 @@ __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, 
   uint32_t node = anchor, trail = leaf0 - 1u;   // wave-uniform
   float minb = INFINITY;
   for (int k = 0; k < D; k += 2) {
-    v4f a0, b0, c0, a1, b1, c1;
     const uint32_t s0 = (anchor >> k) ^ 1u;
     const uint32_t s1 = (k + 1 < D) ? ((anchor >> (k + 1)) ^ 1u) : s0;
-    load_node_scalar(t, s0, a0, b0, c0);
-    load_node_scalar(t, s1, a1, b1, c1);
-    const float e0 = obb_dist2(a0, b0, c0, qx, qy, qz), e1 = obb_dist2(a1, b1, c1, qx, qy, qz);
+    const float e0 = packet_box_bound(t, s0, qx, qy, qz), e1 = packet_box_bound(t, s1, qx, qy, qz);
     stk[(D - k) * stk_stride] = e0;
     if (k + 1 < D) stk[(D - k - 1) * stk_stride] = e1;
     minb = fminf(minb, fminf(e0, e1));
@@ -278,11 +289,8 @@ __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, 
         if (!dup) scan_leaf_uniform(t, node, qx, qy, qz, v);
         break;
       }
-      v4f c0, c1, c2, c3, c4, c5;
-      load_node_scalar(t, 2 * node, c0, c1, c2);
-      load_node_scalar(t, 2 * node + 1, c3, c4, c5);
-      const float d0 = obb_dist2(c0, c1, c2, qx, qy, qz);
-      const float d1 = obb_dist2(c3, c4, c5, qx, qy, qz);
+      const float d0 = packet_box_bound(t, 2 * node, qx, qy, qz);
+      const float d1 = packet_box_bound(t, 2 * node + 1, qx, qy, qz);
       const unsigned long long n0 = __ballot(d0 < v.best), n1 = __ballot(d1 < v.best);
       if ((n0 | n1) == 0ull) break;
       // nearer child first by majority; the other one is parked if any lane wants it

@@ -30,6 +30,8 @@ struct BvhView {
   const float4 *nrm;    // optional normals in the same order (xyz, w = curvature)
   uint32_t n;
   int depth;            // D <= kMaxDepth
+  const float4 *axis2;  // optional (device-built indexes): third box axis per node, for the packet walk (scalar fetches
+                        // are cheap, the per-lane cross product is not); null -> recomputed
 };
 
 // Device-side view of a (Morton-sorted) query cloud.
@@ -140,7 +142,8 @@ struct ope_index {
   float4 *d_nrm = nullptr;
   double pivot[3] = {0, 0, 0};
   float bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
-  ope::BvhView view() const { return ope::BvhView{d_nodes, d_pts, d_nrm, (uint32_t)n, depth}; }
+  float4 *d_axis2 = nullptr;
+  ope::BvhView view() const { return ope::BvhView{d_nodes, d_pts, d_nrm, (uint32_t)n, depth, d_axis2}; }
 };
 
 namespace ope {
