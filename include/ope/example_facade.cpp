@@ -65,6 +65,20 @@ int main() {
   gt(0, 3) = 0.03f; gt(1, 3) = -0.02f; gt(2, 3) = 0.7f;
   pcl::transformPointCloud(*scene0, *scene, gt);
 
+  // ---- BuildModel's ProcessingPcd::getPassThrough (z, y, x) and getDownSampled (processingpcd.cpp:8-52) on the scene
+  {
+    pcl::PointCloud<PointT>::Ptr fz(new pcl::PointCloud<PointT>), fzy(new pcl::PointCloud<PointT>), fzyx(new pcl::PointCloud<PointT>),
+        ds(new pcl::PointCloud<PointT>);
+    pcl::PassThrough<PointT> passThrough;
+    passThrough.setInputCloud(scene); passThrough.setFilterFieldName("z"); passThrough.setFilterLimits(0.0f, 0.7f); passThrough.filter(*fz);
+    passThrough.setInputCloud(fz); passThrough.setFilterFieldName("y"); passThrough.setFilterLimits(-1.0f, 1.0f); passThrough.filter(*fzy);
+    passThrough.setInputCloud(fzy); passThrough.setFilterFieldName("x"); passThrough.setFilterLimits(-1.0f, 1.0f); passThrough.filter(*fzyx);
+    pcl::VoxelGrid<PointT> voxGrid;
+    voxGrid.setInputCloud(scene); voxGrid.setLeafSize(0.005f, 0.005f, 0.005f); voxGrid.filter(*ds);
+    std::printf("PassThrough z<=0.7 kept %zu of %zu points; VoxelGrid(5 mm) %zu centroids\n", fzyx->size(), scene->size(), ds->size());
+    if (fzyx->empty() || fzyx->size() >= scene->size() || fz->size() != fzyx->size() || ds->empty() || ds->size() >= scene->size()) return 4;
+  }
+
   // ---- estimateCoarsePose
   pcl::PointCloud<PointT>::Ptr srcKey, tgtKey;
   pcl::PointCloud<pcl::Normal>::Ptr srcN, tgtN;

@@ -20,6 +20,7 @@ def test_facade_example_recovers_pose():
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Aligned Strength" in r.stdout
+    assert "PassThrough z<=0.7 kept" in r.stdout and "VoxelGrid(5 mm)" in r.stdout
 
 
 def test_rigid_transform_svd_entry_point():
