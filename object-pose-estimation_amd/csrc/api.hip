@@ -470,7 +470,7 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   if (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && (p.k_normal_shooting < 1 || p.k_normal_shooting > 32))
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: 1 <= k_normal_shooting <= 32");
   OPE_HIP(ctx, hipSetDevice(ctx->device));
-  if (ctx->corr_cap < src->n) {
+  if (ctx->corr_cap < std::max<size_t>(src->n, 1)) {   // an empty source still gets one (unused) slot
     if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
     if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
     if (ctx->d_hint) (void)hipFree(ctx->d_hint);

@@ -83,6 +83,29 @@ def test_nn_search_degenerate_targets(ctx, kind):
     assert np.allclose(alt.sum(1), od[~same, 0], rtol=1e-6)      # only exact ties may pick another index
 
 
+def test_nn_search_depth_cap_on_a_large_target(ctx):
+    """1.2 M target points with leaf_size 4: the tree depth is capped at 16 (one LDS slot per level), leaves grow."""
+    rng = np.random.default_rng(9)
+    tgt = synth.model_surface(1_200_000, 3)
+    q = (tgt[rng.integers(0, len(tgt), 30_000)] + rng.normal(0, 2e-3, (30_000, 3))).astype(np.float32)
+    ct, cq = ctx.upload(tgt), ctx.upload(q)
+    ix = ctx.build_index(ct, leaf_size=4)
+    idx, d2 = ctx.nn(cq, ix)
+    oi, od, _ = oracle.KdTree(tgt).knn(q, 1)
+    np.testing.assert_array_equal(d2, od[:, 0])
+    assert (idx == oi[:, 0]).mean() > 0.999
+
+
+def test_icp_empty_and_all_nan_source(ctx):
+    ope = load_pkg()
+    tgt = synth.model_surface(2000, 1)
+    ix = ctx.build_index(ctx.upload(tgt))
+    for src in (np.empty((0, 3), np.float32), np.full((50, 3), np.nan, np.float32)):
+        out = ctx.icp(ctx.upload(src), ix, ope.default_icp_params(max_iterations=5))
+        assert not out.converged and out.state == 5 and out.n_corr == 0      # NO_CORRESPONDENCES (icp_mod.hpp:232-240)
+        np.testing.assert_array_equal(out.T, np.eye(4, dtype=np.float32))
+
+
 def test_nn_search_with_transform_and_nan_queries(ctx):
     rng = np.random.default_rng(1)
     tgt = synth.model_surface(5000, 1)
