@@ -256,3 +256,33 @@ def test_voxel_grid_on_model_surface_and_refused_leaf(ctx):
     assert e.value.code == ope.OPE_ERANGE and oracle.voxel_grid(m, 1e-5) is None
     allnan = ctx.upload(np.full((10, 3), np.nan, np.float32))
     assert len(ctx.voxel_grid(allnan, 0.1)) == 0 and len(ctx.remove_nan(allnan)) == 0
+
+
+def test_empty_and_tiny_clouds_through_every_feature_entry_point(ctx):
+    """Edge cases the reference guards by hand (`if (cloud->points.size() < 10)`, poseestimator.cpp:38-43): the
+    entry points must answer empty / tiny inputs with empty outputs or an error code, never crash."""
+    ope = load_pkg()
+    empty = ctx.upload(np.empty((0, 3), np.float32))
+    assert len(ctx.remove_nan(empty)) == 0 and len(ctx.pass_through(empty, [-1] * 3, [1] * 3)) == 0
+    assert len(ctx.voxel_grid(empty, 0.1)) == 0 and len(ctx.uniform_sampling(empty, 0.1)) == 0
+    n0, c0 = ctx.normals(empty, 5)
+    assert n0.shape == (0, 3) and c0.shape == (0,)
+    with pytest.raises(ope.OpeError) as e:
+        ctx.build_index(empty)
+    assert e.value.code == ope.OPE_EEMPTY
+    # fewer points than k: PCL computes the normal from what it finds (>= 3 neighbours), NaN below that
+    three = np.array([[0, 0, 0], [1e-2, 0, 0], [0, 1e-2, 0]], np.float32)
+    c3 = ctx.upload(three)
+    nrm, _ = ctx.normals(c3, 30)
+    on, _ = oracle.normals_knn(three, 30)
+    np.testing.assert_allclose(np.abs(nrm), np.abs(on), atol=1e-6, equal_nan=True)
+    two = ctx.upload(three[:2])
+    nrm2, _ = ctx.normals(two, 30)
+    assert np.isnan(nrm2).all()
+    # FPFH on a cloud whose points have no neighbours inside the radius: all-zero histograms, as PCL leaves them
+    c3.set_normals(np.tile(np.float32([0, 0, 1]), (3, 1)))
+    f = ctx.fpfh(c3, 1e-4)
+    np.testing.assert_array_equal(f, oracle.fpfh(three, np.tile(np.float32([0, 0, 1]), (3, 1)), 1e-4)[0])
+    # k-NN asked for more neighbours than the kernel's list holds is refused, not truncated
+    with pytest.raises(ope.OpeError):
+        ctx.knn(c3, ctx.build_index(c3), 64)
