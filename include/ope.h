@@ -218,7 +218,7 @@ int ope_comm_destroy(ope_ctx *ctx);
 /* ---------------- features (coarse stage) ---------------- */
 /* pcl::NormalEstimation::compute with setKSearch(k) and viewpoint vp (poseestimator.cpp:151-156).
  * out_normals n*3, out_curvature n (optional), ORIGINAL order; NaN where fewer than 3 neighbours.
- * The normals are also attached to `cloud` on the device. */
+ * The normals are also attached to `cloud` on the device; with both outputs NULL nothing is copied back. */
 int ope_normals(ope_ctx *ctx, ope_cloud *cloud, int k, const float vp[3], float *out_normals, float *out_curvature);
 /* pcl::FPFHEstimation::compute with setRadiusSearch(radius) on a cloud that carries
  * normals (poseestimator.cpp:121-125).  out33 n*33 floats. */

@@ -385,8 +385,13 @@ class Context:
         self._chk(lib().ope_comm_destroy(self.h))
 
     # ---- features
-    def normals(self, cloud: "Cloud", k: int = 30, vp=(0.0, 0.0, 0.0)):
+    def normals(self, cloud: "Cloud", k: int = 30, vp=(0.0, 0.0, 0.0), fetch: bool = True):
+        """pcl::NormalEstimation (k-NN).  The normals stay attached to `cloud` on the device; fetch=False skips the
+        copy back to the host and returns None."""
         v = np.asarray(vp, np.float32)
+        if not fetch:
+            self._chk(lib().ope_normals(self.h, cloud.h, k, _p(v, _fp), None, None))
+            return None
         nrm = np.empty((cloud.n, 3), np.float32)
         curv = np.empty(cloud.n, np.float32)
         self._chk(lib().ope_normals(self.h, cloud.h, k, _p(v, _fp), _p(nrm, _fp), _p(curv, _fp)))

@@ -62,10 +62,8 @@ def get_icp_normal(ope, ctx, source_xyz, target_xyz, corr_rej_thresh: float = 0.
     src = ctx.upload(source_xyz)
     tgt = ctx.upload(target_xyz)
     try:
-        ns, _ = ctx.normals(src, k_normals)     # :72-84
-        nt, _ = ctx.normals(tgt, k_normals)     # :86-90
-        src.set_normals(ns)
-        tgt.set_normals(nt)
+        ctx.normals(src, k_normals, fetch=False)     # :72-84  (the normals stay on the device, attached to the cloud)
+        ctx.normals(tgt, k_normals, fetch=False)     # :86-90
         index = ctx.build_index(tgt)
         try:
             p = icp_params_with_normals(ope, corr_rej_thresh, max_iterations,

@@ -329,11 +329,11 @@ __device__ __forceinline__ void bvh_traverse_oct(const BvhView &t, float qx, flo
   if (start_leaf != 0) {
     node = start_leaf;
     trail = leaf0 - 1u;
-    // ancestor-sibling bounds: lane g takes levels g and g + 8
+    // ancestor-sibling bounds: lane g takes levels g, g + 8 and g + 16
     float e0 = INFINITY, e1 = INFINITY;
     {
       v4f a, b, c;
-      const int k0 = (int)g, k1 = (int)g + 8;
+      const int k0 = (int)g, k1 = (int)g + 8, k2 = (int)g + 16;
       const uint32_t s0 = (k0 < D) ? ((start_leaf >> k0) ^ 1u) : 1u;
       const uint32_t s1 = (k1 < D) ? ((start_leaf >> k1) ^ 1u) : 1u;
       load_node(t, s0, a, b, c);
@@ -341,6 +341,11 @@ __device__ __forceinline__ void bvh_traverse_oct(const BvhView &t, float qx, flo
       load_node(t, s1, a1, b1, c1);
       if (k0 < D) { e0 = obb_dist2(a, b, c, qx, qy, qz); stk[(D - k0) * stk_stride] = e0; }
       if (k1 < D) { e1 = obb_dist2(a1, b1, c1, qx, qy, qz); stk[(D - k1) * stk_stride] = e1; }
+      if (D > 16) {   // deep trees only (more than a million points)
+        const uint32_t s2 = (k2 < D) ? ((start_leaf >> k2) ^ 1u) : 1u;
+        load_node(t, s2, a, b, c);
+        if (k2 < D) { const float e2 = obb_dist2(a, b, c, qx, qy, qz); stk[(D - k2) * stk_stride] = e2; e1 = fminf(e1, e2); }
+      }
     }
     minb = group8_min(fminf(e0, e1));
   } else {
@@ -424,6 +429,44 @@ struct KnnVisitor {
     d[j * stride] = dist;
     pos[j * stride] = i;
     if (count == k) worst = d[(k - 1) * stride];
+  }
+  __device__ __forceinline__ void on_node() {}
+};
+
+// k-nearest list of one lane in REGISTERS, ascending, for a compile-time K (normal shooting's k = 20).  The LDS list
+// above costs a data-dependent shifting loop per candidate, which under SIMT runs as long as the unluckiest lane
+// needs (and its 64 KB per block hold the kernel at two waves per SIMD); here an insertion is a fixed, branch-free
+// sequence of K compare/select steps, skipped for the whole wave when no lane has a candidate.
+template <int K>
+struct KnnRegVisitor {
+  float d[K];
+  uint32_t p[K];
+  int count;
+  uint32_t leaf;   // leaf of the current nearest entry (next iteration's start hint)
+  __device__ __forceinline__ void init(bool active) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) { d[j] = active ? INFINITY : -INFINITY; p[j] = 0; }
+    count = 0;
+    leaf = 0;
+  }
+  __device__ __forceinline__ bool prune(float bound) const { return !(bound < d[K - 1]); }
+  __device__ __forceinline__ void point(float dist, const v4f &, uint32_t i, uint32_t lf) {
+    const bool ins = dist < d[K - 1];
+    if (__ballot(ins) == 0ull) return;
+    if (ins && dist < d[0]) leaf = lf;
+    count += (ins && count < K) ? 1 : 0;
+    // d[j] <- d[j-1] where the new distance sorts before d[j-1]; the new distance lands at the first such gap
+    // (strict comparisons: an equal earlier entry stays in front, like the LDS list)
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) {
+      const bool shift = dist < d[j - 1];
+      const bool here = !shift && dist < d[j];
+      d[j] = shift ? d[j - 1] : (here ? dist : d[j]);
+      p[j] = shift ? p[j - 1] : (here ? i : p[j]);
+    }
+    const bool first = dist < d[0];
+    d[0] = first ? dist : d[0];
+    p[0] = first ? i : p[0];
   }
   __device__ __forceinline__ void on_node() {}
 };

@@ -131,6 +131,9 @@ __device__ void eigen33_smallest(const float mat[9], float *eigenvalue, float ev
 // NormalEstimation::computeFeature with a k-NN neighbourhood.  The k nearest (self included) come out
 // of the traversal ascending by distance, exactly the order in which PCL's single-pass fp32
 // computeMeanAndCovarianceMatrix accumulates them.
+// KREG = 0: list in LDS (any k <= 32); KREG = 12 / 30: list in registers for the two values the reference uses
+// (regmeshpcd.cpp:80, poseestimator.cpp:154), see KnnRegVisitor.
+template <int KREG>
 __global__ __launch_bounds__(kKnnBlock) void normals_kernel(CloudView q, BvhView tgt, int k, float vpx, float vpy,
                                                              float vpz, float4 *__restrict__ out_nrm) {
   extern __shared__ unsigned char s_dyn[];
@@ -142,17 +145,32 @@ __global__ __launch_bounds__(kKnnBlock) void normals_kernel(CloudView q, BvhView
   for (uint32_t i = blockIdx.x * kKnnBlock + threadIdx.x; i < q.n; i += gridDim.x * kKnnBlock) {
     if (i >= q.n_valid) { out_nrm[i] = make_float4(qnan, qnan, qnan, qnan); continue; }
     const float4 s = q.xyzw[i];
-    KnnVisitor v{ld, lp, kKnnBlock, k, 0, INFINITY};
-    bvh_traverse(tgt, s.x, s.y, s.z, v, stk, kKnnBlock);
-    if (v.count < 3) { out_nrm[i] = make_float4(qnan, qnan, qnan, qnan); continue; }
     float accu[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < v.count; ++j) {
-      const float4 p = tgt.pts[lp[j * kKnnBlock]];
-      accu[0] += p.x * p.x; accu[1] += p.x * p.y; accu[2] += p.x * p.z;
-      accu[3] += p.y * p.y; accu[4] += p.y * p.z; accu[5] += p.z * p.z;
-      accu[6] += p.x; accu[7] += p.y; accu[8] += p.z;
+    int count;
+#define OPE_ACCUMULATE_NEIGHBOUR(P)                                       \
+  accu[0] += P.x * P.x; accu[1] += P.x * P.y; accu[2] += P.x * P.z;       \
+  accu[3] += P.y * P.y; accu[4] += P.y * P.z; accu[5] += P.z * P.z;       \
+  accu[6] += P.x; accu[7] += P.y; accu[8] += P.z
+    if constexpr (KREG > 0) {
+      KnnRegVisitor<KREG> v;
+      v.init(true);
+      bvh_traverse(tgt, s.x, s.y, s.z, v, stk, kKnnBlock);
+      count = v.count;
+      if (count >= 3) {
+#pragma unroll
+        for (int j = 0; j < KREG; ++j)
+          if (j < count) { const float4 p = tgt.pts[v.p[j]]; OPE_ACCUMULATE_NEIGHBOUR(p); }
+      }
+    } else {
+      KnnVisitor v{ld, lp, kKnnBlock, k, 0, INFINITY};
+      bvh_traverse(tgt, s.x, s.y, s.z, v, stk, kKnnBlock);
+      count = v.count;
+      if (count >= 3)
+        for (int j = 0; j < count; ++j) { const float4 p = tgt.pts[lp[j * kKnnBlock]]; OPE_ACCUMULATE_NEIGHBOUR(p); }
     }
-    const float fc = (float)v.count;
+#undef OPE_ACCUMULATE_NEIGHBOUR
+    if (count < 3) { out_nrm[i] = make_float4(qnan, qnan, qnan, qnan); continue; }
+    const float fc = (float)count;
 #pragma unroll
     for (int a = 0; a < 9; ++a) accu[a] /= fc;
     float cov[9];
@@ -566,23 +584,34 @@ int ope_normals(ope_ctx *ctx, ope_cloud *cloud, int k, const float vp[3], float 
   static const float origin[3] = {0.f, 0.f, 0.f};
   const float *v = vp ? vp : origin;
   if (!cloud->d_nrm) OPE_HIP(ctx, hipMalloc((void **)&cloud->d_nrm, sizeof(float4) * n));
-  std::vector<float> packed(n * 4);
+  const bool want_host = out_normals || out_curvature;   // both null: the normals only stay attached to the cloud
+  std::vector<float> packed(want_host ? n * 4 : 0);
   if (cloud->n_valid > 0) {
     ope_index *ix = nullptr;
     int rc = self_index(ctx, cloud, &ix);
     if (rc != OPE_OK) return rc;
     const int nblocks = (int)std::min<size_t>((n + kKnnBlock - 1) / kKnnBlock, 4096);
-    hipLaunchKernelGGL(normals_kernel, dim3(nblocks), dim3(kKnnBlock), kKnnLdsBytes, ctx->stream, cloud->view(), ix->view(),
-                       k, v[0], v[1], v[2], cloud->d_nrm);
-    hipError_t e = hipMemcpyAsync(packed.data(), cloud->d_nrm, sizeof(float4) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (k == 12)
+      hipLaunchKernelGGL(normals_kernel<12>, dim3(nblocks), dim3(kKnnBlock), 0, ctx->stream, cloud->view(), ix->view(), k, v[0], v[1],
+                         v[2], cloud->d_nrm);
+    else if (k == 30)
+      hipLaunchKernelGGL(normals_kernel<30>, dim3(nblocks), dim3(kKnnBlock), 0, ctx->stream, cloud->view(), ix->view(), k, v[0], v[1],
+                         v[2], cloud->d_nrm);
+    else
+      hipLaunchKernelGGL(normals_kernel<0>, dim3(nblocks), dim3(kKnnBlock), kKnnLdsBytes, ctx->stream, cloud->view(), ix->view(), k,
+                         v[0], v[1], v[2], cloud->d_nrm);
+    hipError_t e = hipSuccess;
+    if (want_host) e = hipMemcpyAsync(packed.data(), cloud->d_nrm, sizeof(float4) * n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     ope_index_free(ix);
     if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_normals: ") + hipGetErrorString(e));
   } else {
     const float qn = std::numeric_limits<float>::quiet_NaN();
-    std::fill(packed.begin(), packed.end(), qn);
-    OPE_HIP(ctx, hipMemcpy(cloud->d_nrm, packed.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    std::vector<float> nan4(n * 4, qn);
+    OPE_HIP(ctx, hipMemcpy(cloud->d_nrm, nan4.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    if (want_host) packed = nan4;
   }
+  if (!want_host) return OPE_OK;
   for (size_t i = 0; i < n; ++i) {
     const size_t o = (size_t)cloud->perm[i];
     if (out_normals) { out_normals[3 * o] = packed[4 * i]; out_normals[3 * o + 1] = packed[4 * i + 1]; out_normals[3 * o + 2] = packed[4 * i + 2]; }

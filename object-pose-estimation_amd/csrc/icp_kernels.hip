@@ -21,7 +21,9 @@
 
 namespace ope {
 
-// MODE 0: 1-NN correspondences.  MODE 1: normal shooting over the k nearest.
+// MODE 0: 1-NN correspondences.  MODE 1: normal shooting over the k nearest (list in LDS, any k <= 32).
+// MODE 2: the same for k = 20, the value the reference uses (poseestimator.cpp:246, regmeshpcd.cpp:144): list in
+// registers, walk started at last iteration's leaf.
 // NRM: source/target normals present (rejectors and/or normal shooting).
 // RECIP: reciprocal correspondences (vPCL impl/correspondence_estimation_mod.hpp:216-303): keep (i, j) only
 // if the nearest SOURCE point of target point j is i again.  The reference searches a kd-tree rebuilt
@@ -148,6 +150,32 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
         ok = ok && r.pos != kNoPos && !((double)r.best > max_d2) &&
              __float_as_int(srcix.pts[r.pos].w) == __float_as_int(s.w);
       }
+    } else if (MODE == 2) {
+      constexpr int K = 20;
+      KnnRegVisitor<K> v;
+      v.init(active);
+      bvh_traverse(tgt, x, y, z, v, stk, BLOCK, active ? hint[i] : 0u);
+      if (active) hint[i] = v.leaf;
+      // among the k nearest, the one with the smallest squared distance to the line (s, n)
+      // (…normal_shooting_weighted.hpp:115-135; cross product in double)
+      double min_dist = 1.79769313486231570815e308;
+      d2 = INFINITY;
+      pos = 0;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        if (j < v.count) {
+          const float4 p = tgt.pts[v.p[j]];
+          const double vx = (double)__fsub_rn(p.x, x), vy = (double)__fsub_rn(p.y, y), vz = (double)__fsub_rn(p.z, z);
+          const double cx = (double)ny * vz - (double)nz * vy;
+          const double cy = (double)nz * vx - (double)nx * vz;
+          const double cz = (double)nx * vy - (double)ny * vx;
+          const double dist = cx * cx + cy * cy + cz * cz;
+          if (dist < min_dist) { min_dist = dist; d2 = v.d[j]; pos = v.p[j]; }
+        }
+      }
+      // quirk Q2: squared line distance against the UNSQUARED max distance (:136)
+      ok = active && v.count > 0 && !(min_dist > max_dist_unsq);
+      match = v.count > 0 ? __float_as_int(tgt.pts[pos].w) : -1;
     } else {
       float *ld = reinterpret_cast<float *>(s_dyn) + threadIdx.x;
       uint32_t *lp = reinterpret_cast<uint32_t *>(s_dyn + sizeof(float) * BLOCK * kKnnMaxK) + threadIdx.x;
@@ -813,7 +841,8 @@ __global__ __launch_bounds__(256) void fitness_kernel(CloudView q, BvhView tgt, 
 void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, bool recip, const CloudView &src,
                            const BvhView &tgt, const BvhView &srcix, const IcpState *st, double *partials,
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
-                           const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet) {
+                           const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
+                           int k_normal_shooting) {
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS)                                                                       \
   hipLaunchKernelGGL((icp_accumulate_kernel<M, N, R>), dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, \
                      partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info)
@@ -829,6 +858,8 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
   if (mode == 0) {
     if (recip) { if (nrm) OPE_LAUNCH_ACC(0, true, true, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, true, kAccBlock, 0); }
     else       { if (nrm) OPE_LAUNCH_ACC(0, true, false, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, false, kAccBlock, 0); }
+  } else if (k_normal_shooting == 20) {
+    OPE_LAUNCH_ACC(2, true, false, kKnnBlock, 0);
   } else {
     OPE_LAUNCH_ACC(1, true, false, kKnnBlock, kKnnLdsBytes);
   }

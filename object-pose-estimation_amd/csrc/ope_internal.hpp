@@ -22,7 +22,7 @@ namespace ope {
 // The two children of node i are 96 contiguous bytes at nodes + 6*i float4.
 // ---------------------------------------------------------------------------
 constexpr int kNodeFloats = 12;
-constexpr int kMaxDepth = 16;  // one pending-bound LDS slot per level and lane
+constexpr int kMaxDepth = 20;  // one pending-bound LDS slot per level and lane (16 M points at 16 per leaf)
 
 struct BvhView {
   const float4 *nodes;  // (2^(D+1)) * 3 float4

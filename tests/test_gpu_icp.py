@@ -84,12 +84,13 @@ def test_nn_search_degenerate_targets(ctx, kind):
 
 
 def test_nn_search_depth_cap_on_a_large_target(ctx):
-    """1.2 M target points with leaf_size 4: the tree depth is capped at 16 (one LDS slot per level), leaves grow."""
+    """1.2 M target points with leaf_size 1 would need depth 21: the tree depth is capped at 20 (one LDS slot per
+    level), leaves grow; exercises the deep-tree paths (three levels per lane in the group walk's start)."""
     rng = np.random.default_rng(9)
     tgt = synth.model_surface(1_200_000, 3)
     q = (tgt[rng.integers(0, len(tgt), 30_000)] + rng.normal(0, 2e-3, (30_000, 3))).astype(np.float32)
     ct, cq = ctx.upload(tgt), ctx.upload(q)
-    ix = ctx.build_index(ct, leaf_size=4)
+    ix = ctx.build_index(ct, leaf_size=1)
     idx, d2 = ctx.nn(cq, ix)
     oi, od, _ = oracle.KdTree(tgt).knn(q, 1)
     np.testing.assert_array_equal(d2, od[:, 0])
