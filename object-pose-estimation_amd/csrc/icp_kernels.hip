@@ -71,10 +71,6 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   if ((threadIdx.x & 63u) < (uint32_t)kNumSumsMax) s_red[threadIdx.x >> 6][threadIdx.x & 63u] = 0.0;
   const bool p2p = NRM && st->estimator == OPE_EST_POINT_TO_PLANE_LLS;
 
-  // Dynamic work distribution: query cost is very uneven (a clutter point far from the model walks
-  // 10-40x more nodes than a surface point), so each WAVE pulls the next 64-query chunk of the Morton
-  // order from a device-wide ticket counter (reset by the reduce kernel).  Which wave sums which chunk
-  // only changes the fp32 partial-sum grouping, i.e. the last bits of the fp64 totals.
   const uint32_t lane_id = threadIdx.x & 63u;
   // Static, cost-aware work distribution.  Query cost is very uneven (a clutter point far from the model
   // walks 10-40x more nodes than a surface point) and the kernel ends with its slowest wave, so the
@@ -621,7 +617,6 @@ __global__ __launch_bounds__(kRedBlock) void icp_reduce_update_kernel(IcpState *
                                                                             double *S, int nblocks, int do_update,
                                                                             uint32_t *work_counter) {
   if (st->done) return;
-  if (threadIdx.x == 0) *work_counter = 0u;  // ticket counter of the next accumulate launch
   // LDS tree in a fixed order (cross-lane fp64 shuffles serialised into ~200 dependent
   // ds_bpermutes and took 15 us): rows -> 256 per-thread sums -> 8 group sums -> total.
   __shared__ double s_part[kNumSums][kRedBlock];

@@ -83,7 +83,7 @@ struct ope_ctx {
   // ICP run state
   ope::IcpState *d_state = nullptr;
   double *d_partials = nullptr;   // [kNumSumsMax][kAccMaxBlocks]
-  uint32_t *d_work_counter = nullptr;  // ticket counter of the accumulate kernel's dynamic work queue
+  uint32_t *d_work_counter = nullptr;  // small device scratch block: word 8 = number of chunks walked by 8-lane groups
   int32_t *d_corr_match = nullptr;  // per sorted query: ORIGINAL target index or -1
   float *d_corr_d2 = nullptr;
   // cost-aware chunk schedule of the accumulate kernel
