@@ -190,12 +190,12 @@ int ope_cloud_upload(ope_ctx *ctx, const void *base, size_t n, size_t stride_byt
   c->n = n;
   c->h_xyz.resize(n * 3);
   const unsigned char *b = static_cast<const unsigned char *>(base);
-  for (size_t i = 0; i < n; ++i) std::memcpy(&c->h_xyz[3 * i], b + i * stride_bytes + xyz_off, 12);
-  // bounding box of the finite points
+  // one pass: gather xyz out of the caller's structs and take the bounding box of the finite points
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   size_t nv = 0;
   for (size_t i = 0; i < n; ++i) {
-    const float *p = &c->h_xyz[3 * i];
+    float *p = &c->h_xyz[3 * i];
+    std::memcpy(p, b + i * stride_bytes + xyz_off, 12);
     if (!finite3(p)) continue;
     ++nv;
     for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], p[d]); hi[d] = std::max(hi[d], p[d]); }

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/ope.h"
@@ -73,6 +75,18 @@ constexpr int kAccMaxBlocks = 1024;  // partials rows; the update kernel reduces
 
 }  // namespace ope
 
+// std::vector without the zero fill on resize (the host copies of multi-million-point clouds are written in full
+// right after they are sized)
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+  template <class U> struct rebind { using other = default_init_allocator<U>; };
+  using std::allocator<T>::allocator;
+  template <class U, class... Args> void construct(U *p, Args &&...args) {
+    if constexpr (sizeof...(Args) == 0) ::new (static_cast<void *>(p)) U;
+    else ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...);
+  }
+};
+
 struct ope_ctx {
   int device = -1;
   int n_cu = 256;   // compute units of the device (MI355X: 256)
@@ -124,8 +138,8 @@ struct ope_cloud {
   size_t n = 0, n_valid = 0;
   float4 *d_xyzw = nullptr;
   float4 *d_nrm = nullptr;
-  std::vector<float> h_xyz;       // original order, n*3
-  std::vector<int32_t> perm;      // sorted position -> original index
+  std::vector<float, default_init_allocator<float>> h_xyz;   // original order, n*3
+  std::vector<int32_t, default_init_allocator<int32_t>> perm;   // sorted position -> original index
   float bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
   ope::CloudView view() const {
     return ope::CloudView{d_xyzw, d_nrm, (uint32_t)n, (uint32_t)n_valid};
