@@ -211,7 +211,7 @@ def main() -> int:
             except Exception:
                 traffic = None
         line = {
-            "metric": "ICP iterations/sec (1M scene pts vs 100k model pts)" if args.workload == "C3"
+            "metric": "ICP iterations/sec (1M scene pts vs 100k model pts) at 1/2/4/8 GPU" if args.workload == "C3"
                       else "ICP iterations/sec (100k scene pts vs 20k model pts)",
             "value": K / elapsed,
             "unit": "iterations/s",
