@@ -51,6 +51,11 @@ def main() -> int:
     ap.add_argument("--no-coarse", action="store_true", help="skip the FPFH + SAC-IA initial alignment (identity start)")
     ap.add_argument("--cpu-iters", type=int, default=3)
     args = ap.parse_args()
+    # Everything libraries print through fd 1 (RCCL's version banner, for one) goes to stderr; the one JSON line is
+    # written to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -237,7 +242,13 @@ def main() -> int:
             line["coarse_stage"] = coarse
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(np, scene, model, args.cpu_iters, guess)
-        print(json.dumps(line), flush=True)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)     # C stdio buffers (still pointing at fd 1 = stderr now)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     ctx.close()
     if launched:
         dist.barrier()
