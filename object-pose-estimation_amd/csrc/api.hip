@@ -71,12 +71,13 @@ static int enqueue_accumulate(ope_ctx *ctx) {
     if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
                    ctx->d_plan_tmp, tb) != 0)
       return set_err(ctx, OPE_EHIP, "chunk plan sort failed");
-    // chunks costlier than `factor` x the median chunk are walked by 8-lane groups.  Measured: with spare wave
-    // slots (fewer chunks than resident waves, e.g. a 1/8 shard) 2x is best (C2: 115 -> 79 us); on a saturated
-    // GPU the 8x lane cost must be reserved for the real tail, 4-6x (C3: 251 -> 225 us).
+    // Chunks costlier than `factor` x the median chunk are walked by 8-lane groups.  The fewer chunks there are per
+    // resident wave, the more the slowest wave decides the launch and the more chunks deserve the 8x lane cost.
+    // Measured optimum (model 100 k): 2 at a quarter chunk per wave (C2: 115 -> 79 us), 3 at 1.3 (500 k queries:
+    // 171 -> 142 us against a fixed 5), 5 at 2.5 (C3), 6-8 at 5 (2 M queries: 362 -> 299 us) — the line below.
     static const float heavy_env = [] { const char *e = getenv("OPE_HEAVY_FACTOR"); return e ? (float)atof(e) : -1.0f; }();
-    const uint32_t resident_waves = (uint32_t)ctx->acc_blocks * (kAccBlock / 64);
-    const float heavy_factor = heavy_env >= 0.f ? heavy_env : (nch <= resident_waves ? 2.0f : 5.0f);
+    const float chunks_per_wave = (float)nch / (float)(ctx->n_cu * 4 * kAccWavesPerSimd);
+    const float heavy_factor = heavy_env >= 0.f ? heavy_env : std::min(6.5f, std::max(2.0f, 1.8f + 1.25f * chunks_per_wave));
     plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch, heavy_factor, ctx->d_work_counter + 8);
     ctx->plan_valid = true;
   }
