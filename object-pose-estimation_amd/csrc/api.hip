@@ -73,7 +73,7 @@ static int enqueue_accumulate(ope_ctx *ctx) {
       return set_err(ctx, OPE_EHIP, "chunk plan sort failed");
     // Chunks costlier than `factor` x the median chunk are walked by 8-lane groups.  The fewer chunks there are per
     // resident wave, the more the slowest wave decides the launch and the more chunks deserve the 8x lane cost.
-    // Measured optimum (model 100 k; tools/heavy_sweep2.py): 2 at 0.25-0.6 chunks per wave (C2: 115 -> 79 us), 2.5 at
+    // Measured optimum (model 100 k; tools/heavy_sweep.py): 2 at 0.25-0.6 chunks per wave (C2: 115 -> 79 us), 2.5 at
     // 1.0, 3 at 1.3 (500 k queries: 171 -> 142 us against a fixed 5), 4 at 1.9, 5 at 2.5 (C3), 6.5 at 3.8, 6-8 at 5
     // (2 M queries: 362 -> 299 us) — the line below.
     static const float heavy_env = [] { const char *e = getenv("OPE_HEAVY_FACTOR"); return e ? (float)atof(e) : -1.0f; }();
