@@ -324,9 +324,27 @@ __device__ __forceinline__ void jacobi_rotate(double (&S)[9], double (&V)[9]) {
   }
 }
 
-__device__ __forceinline__ void jacobi_eig3(double (&S)[9], double (&V)[9]) {
+// `warm`: V holds an orthonormal basis that nearly diagonalises S already (the eigenvectors of the previous ICP
+// iteration's matrix): S is moved into that basis first and one or two sweeps finish the job instead of five or six
+// (the update lane is a serial tail of every iteration; its fp64 instructions issue one per 8 cycles).
+__device__ __forceinline__ void jacobi_eig3(double (&S)[9], double (&V)[9], bool warm = false) {
+  if (warm) {
+    double SV[9], W[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) SV[3 * r + c] = S[3 * r] * V[c] + S[3 * r + 1] * V[3 + c] + S[3 * r + 2] * V[6 + c];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = r; c < 3; ++c) W[3 * r + c] = V[r] * SV[c] + V[3 + r] * SV[3 + c] + V[6 + r] * SV[6 + c];
+    W[3] = W[1]; W[6] = W[2]; W[7] = W[5];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) S[i] = W[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  }
   for (int sweep = 0; sweep < 30; ++sweep) {
     const double off = fabs(S[1]) + fabs(S[2]) + fabs(S[5]);
     const double diag = fabs(S[0]) + fabs(S[4]) + fabs(S[8]);
@@ -352,13 +370,14 @@ __device__ __forceinline__ void sort_cols_desc(double (&ev)[3], double (&V)[9]) 
 }
 
 // A = U diag(s) V^T, s descending (row-major 3x3)
-__device__ __forceinline__ void svd3(const double (&A)[9], double (&U)[9], double (&s)[3], double (&V)[9]) {
+// warm: V comes in holding the previous call's V (see jacobi_eig3)
+__device__ __forceinline__ void svd3(const double (&A)[9], double (&U)[9], double (&s)[3], double (&V)[9], bool warm = false) {
   double AtA[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) AtA[3 * i + j] = A[i] * A[j] + A[3 + i] * A[3 + j] + A[6 + i] * A[6 + j];
-  jacobi_eig3(AtA, V);
+  jacobi_eig3(AtA, V, warm);
   double ev[3] = {AtA[0], AtA[4], AtA[8]};
   sort_cols_desc<0, 1>(ev, V);
   sort_cols_desc<0, 2>(ev, V);
@@ -417,7 +436,9 @@ __device__ __forceinline__ void svd3(const double (&A)[9], double (&U)[9], doubl
 }
 
 // Eigen::umeyama(src, dst, false) from the 17 sums (taken about `pivot`), column-major fp64 out.
-__device__ __forceinline__ void umeyama_from_sums(const double *S, const double *pivot, double (&T)[16]) {
+// Vwarm (optional): 9 doubles + a validity flag carried from one ICP iteration to the next
+__device__ __forceinline__ void umeyama_from_sums(const double *S, const double *pivot, double (&T)[16], double *Vwarm = nullptr,
+                                                  int *have_warm = nullptr) {
   const double n = S[0];
   double sm[3], dm[3], sigma[9];
   const double inv_n = 1.0 / n;
@@ -430,7 +451,17 @@ __device__ __forceinline__ void umeyama_from_sums(const double *S, const double 
 #pragma unroll
   for (int d = 0; d < 3; ++d) { sm[d] += pivot[d]; dm[d] += pivot[d]; }
   double U[9], sv[3], V[9];
-  svd3(sigma, U, sv, V);
+  const bool warm = Vwarm != nullptr && *have_warm != 0;
+  if (warm) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) V[i] = Vwarm[i];
+  }
+  svd3(sigma, U, sv, V, warm);
+  if (Vwarm != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Vwarm[i] = V[i];
+    *have_warm = 1;
+  }
   double Sg[3] = {1, 1, 1};
   if (det3(sigma) < 0) Sg[2] = -1;
   int rank = 0;
@@ -537,7 +568,7 @@ __device__ __forceinline__ void icp_update_lane(IcpState *st, const double *S) {
       return;
     }
   } else {
-    umeyama_from_sums(S, st->pivot, Tk);
+    umeyama_from_sums(S, st->pivot, Tk, st->Vwarm, &st->have_Vwarm);
   }
   // transformation_ is a Matrix4f in the reference
   float Tf[16];

@@ -51,6 +51,8 @@ struct IcpState {
   float Ff[12];        // F rounded to fp32: rows of the 3x4 [R|t] (r00 r01 r02 tx, …)
   float Finv[12];      // inverse of F, same layout (reciprocal correspondences query the SOURCE index with it)
   double S[44];        // reduced sums of the current iteration (17, or 44 with point-to-plane)
+  double Vwarm[9];     // right singular vectors of the previous iteration's covariance (warm start of the Jacobi sweeps)
+  int have_Vwarm, pad_;
   double pivot[3];
   double prev_mse, cur_mse;
   double rotation_threshold, translation_threshold;
