@@ -1000,7 +1000,7 @@ struct StepVisitor {
     __builtin_amdgcn_sched_barrier(0);                                                     \
   } while (0)
 
-__global__ __launch_bounds__(kAccBlock, 8) void debug_chunk_kernel(CloudView src, BvhView tgt, const float *__restrict__ T,
+__global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void debug_chunk_kernel(CloudView src, BvhView tgt, const float *__restrict__ T,
                                                                      const uint32_t *__restrict__ hint, int use_hint,
                                                                      long long *__restrict__ out) {
   __shared__ float s_stk[kMaxDepth + 1][kAccBlock];
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(kAccBlock, 8) void debug_chunk_kernel(CloudView src
   const uint32_t i = base + lane_id;
   const bool active = i < src.n_valid;
   unsigned long long t0, t1, ta, tb;
-  unsigned long long c_node = 0, c_leaf = 0, c_pop = 0, c_eager = 0, n_node = 0, n_leaf = 0, n_pop = 0;
+  unsigned long long c_node = 0, c_leaf = 0, c_pop = 0, c_eager = 0, n_node = 0;
   OPE_STAMP(t0);
   const float4 s4 = src.xyzw[active ? i : base];
   const float qx = xform_row(T + 0, s4.x, s4.y, s4.z), qy = xform_row(T + 4, s4.x, s4.y, s4.z), qz = xform_row(T + 8, s4.x, s4.y, s4.z);
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(kAccBlock, 8) void debug_chunk_kernel(CloudView src
       do_pop = true;
     }
     OPE_STAMP(tb);
-    c_leaf += tb - ta; n_leaf += 1;
+    c_leaf += tb - ta;
     OPE_STAMP(ta);
     if (alive && do_pop) {
       for (;;) {
@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(kAccBlock, 8) void debug_chunk_kernel(CloudView src
       }
     }
     OPE_STAMP(tb);
-    c_pop += tb - ta; n_pop += 1;
+    c_pop += tb - ta;
   }
   OPE_STAMP(t1);
   int mn = v.nodes, mp = v.points;
