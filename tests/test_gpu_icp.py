@@ -400,3 +400,17 @@ def test_icp_large_launch_packet_walk_matches_oracle(ctx):
     diff = m2 != oi[:, 0]
     assert diff.mean() < 1e-4                              # exact fp32 distance ties may pick another index
     assert two.iterations == 2
+
+
+def test_c3_full_size_iterations_match_oracle(ctx):
+    """BASELINE.json's headline configuration at full size (1 M scene points vs 100 k model points): three ICP
+    iterations on the HIP path (chunk plan, group walks, packet walks all active from the second iteration on)
+    against the CPU oracle; tolerance = north_star's 1e-4 Frobenius on the 4x4 (observed ~1e-6)."""
+    src, tgt = synth.config_clouds("C3")
+    kw = dict(max_iterations=3, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0)
+    out, cs, ix = gpu_icp(ctx, src, tgt, **kw)
+    ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw))
+    assert out.iterations == ref.iterations == 3
+    assert frob(out.T, ref.T) <= 1e-4
+    assert out.n_corr == ref.n_corr == len(src)
+    assert abs(out.last_mse - ref.last_mse) <= 1e-6 * max(ref.last_mse, 1e-12) + 1e-12
