@@ -220,6 +220,11 @@ int ope_comm_destroy(ope_ctx *ctx);
  * out_normals n*3, out_curvature n (optional), ORIGINAL order; NaN where fewer than 3 neighbours.
  * The normals are also attached to `cloud` on the device; with both outputs NULL nothing is copied back. */
 int ope_normals(ope_ctx *ctx, ope_cloud *cloud, int k, const float vp[3], float *out_normals, float *out_curvature);
+/* The same with the neighbourhoods taken from another cloud's index: NormalEstimation::setSearchSurface
+ * (pcl/features/feature.h), used here to shard the normals of one big cloud over ranks — every rank searches the whole
+ * cloud's index for its own slice of the points. */
+int ope_normals_from(ope_ctx *ctx, ope_cloud *queries, const ope_index *index, int k, const float vp[3], float *out_normals,
+                     float *out_curvature);
 /* pcl::FPFHEstimation::compute with setRadiusSearch(radius) on a cloud that carries
  * normals (poseestimator.cpp:121-125).  out33 n*33 floats. */
 int ope_fpfh(ope_ctx *ctx, const ope_cloud *cloud, float radius, float *out33);

@@ -139,6 +139,7 @@ ABI = [
     ("ope_comm_init_rank", C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
     ("ope_comm_destroy", C.c_int, [_vp]),
     ("ope_normals", C.c_int, [_vp, _vp, C.c_int, _fp, _fp, _fp]),
+    ("ope_normals_from", C.c_int, [_vp, _vp, _vp, C.c_int, _fp, _fp, _fp]),
     ("ope_fpfh", C.c_int, [_vp, _vp, C.c_float, _fp]),
     ("ope_uniform_sampling", C.c_int, [_vp, _vp, C.c_float, _ip, C.POINTER(C.c_size_t)]),
     ("ope_remove_nan", C.c_int, [_vp, _vp, _ip, C.POINTER(C.c_size_t)]),
@@ -395,6 +396,17 @@ class Context:
         nrm = np.empty((cloud.n, 3), np.float32)
         curv = np.empty(cloud.n, np.float32)
         self._chk(lib().ope_normals(self.h, cloud.h, k, _p(v, _fp), _p(nrm, _fp), _p(curv, _fp)))
+        return nrm, curv
+
+    def normals_from(self, queries: "Cloud", index: "Index", k: int = 30, vp=(0.0, 0.0, 0.0), fetch: bool = True):
+        """Normals of `queries` from their k nearest neighbours in `index` (setSearchSurface); attached to `queries`."""
+        v = np.asarray(vp, np.float32)
+        if not fetch:
+            self._chk(lib().ope_normals_from(self.h, queries.h, index.h, k, _p(v, _fp), None, None))
+            return None
+        nrm = np.empty((queries.n, 3), np.float32)
+        curv = np.empty(queries.n, np.float32)
+        self._chk(lib().ope_normals_from(self.h, queries.h, index.h, k, _p(v, _fp), _p(nrm, _fp), _p(curv, _fp)))
         return nrm, curv
 
     def fpfh(self, cloud: "Cloud", radius: float) -> np.ndarray:

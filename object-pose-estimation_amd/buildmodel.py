@@ -96,3 +96,60 @@ def register_point_clouds(ope, ctx, frames, max_corr_dist: float = 0.005, corr_r
         res.pairs.append(pr)
     res.cloud = acc
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# One process per GPU.  The frames are registered sequentially as in the reference, so the
+# parallelism is inside each pairwise registration: every rank uploads the whole accumulated source (its index is
+# what the normals of any point need) but computes normals and ICP sums only for its contiguous slice of it; the
+# target frame and its index are replicated; the sums are all-reduced once per iteration (sharded.run_sharded_icp).
+def get_icp_normal_sharded(ope, ctx, source_xyz, target_xyz, corr_rej_thresh: float = 0.7, max_iterations: int = 500,
+                           k_normals: int = 12, engine_cls=None, group=None):
+    """get_icp_normal with the source sharded over the ranks of `group`.  Every rank returns the same result."""
+    import torch.distributed as dist
+
+    from . import sharded
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    engine_cls = engine_cls or sharded.GpuEngine
+    source_xyz = np.ascontiguousarray(source_xyz, np.float32)
+    lo, hi = sharded.shard_range(len(source_xyz), world, rank)
+    src_all = ctx.upload(source_xyz)
+    src = ctx.upload(source_xyz[lo:hi])
+    tgt = ctx.upload(target_xyz)
+    try:
+        all_index = ctx.build_index(src_all)
+        try:
+            ctx.normals_from(src, all_index, k_normals, fetch=False)   # :72-84, this rank's slice only
+        finally:
+            all_index.free()
+        ctx.normals(tgt, k_normals, fetch=False)                       # :86-90
+        index = ctx.build_index(tgt)
+        try:
+            p = icp_params_with_normals(ope, corr_rej_thresh, max_iterations)
+            eng = engine_cls(ope, ctx, src, index, p, None, len(source_xyz), len(target_xyz))
+            out = sharded.run_sharded_icp(eng, max_iterations, check_every=p.check_every, group=group)   # :196
+            aligned = ctx.transform_cloud(src_all, out.T)             # :203
+        finally:
+            index.free()
+    finally:
+        src_all.free()
+        src.free()
+        tgt.free()
+    return aligned, PairResult(out.T, out.iterations, bool(out.converged), float("nan"), len(source_xyz), len(target_xyz))
+
+
+def register_point_clouds_sharded(ope, ctx, frames, corr_rej_thresh: float = 0.7, max_iterations: int = 500, **kw) -> RegistrationResult:
+    """register_point_clouds with every pairwise registration sharded over the process group (regmeshpcd.cpp:210-271)."""
+    if len(frames) == 0:
+        raise ValueError("register_point_clouds_sharded: no frames")
+    acc = np.ascontiguousarray(frames[0], np.float32)
+    res = RegistrationResult(acc)
+    for i in range(len(frames) - 1):
+        target = np.ascontiguousarray(frames[i + 1], np.float32)
+        aligned, pr = get_icp_normal_sharded(ope, ctx, acc, target, corr_rej_thresh, max_iterations, **kw)
+        acc = np.concatenate([aligned, target], axis=0)
+        res.pairs.append(pr)
+    res.cloud = acc
+    return res

@@ -576,8 +576,10 @@ int ope_radius_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *i
   return OPE_OK;
 }
 
-int ope_normals(ope_ctx *ctx, ope_cloud *cloud, int k, const float vp[3], float *out_normals, float *out_curvature) {
-  if (!ctx || !cloud || k < 1 || k > kKnnMaxK) return set_err(ctx, OPE_EINVAL, "ope_normals: bad argument (1 <= k <= 32)");
+// normals of `cloud`'s points from their k nearest neighbours in `index` (null: an index over the cloud itself)
+static int normals_impl(ope_ctx *ctx, ope_cloud *cloud, const ope_index *index, int k, const float vp[3], float *out_normals,
+                        float *out_curvature, const char *who) {
+  if (!ctx || !cloud || k < 1 || k > kKnnMaxK) return set_err(ctx, OPE_EINVAL, std::string(who) + ": bad argument (1 <= k <= 32)");
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   const size_t n = cloud->n;
   if (n == 0) return OPE_OK;
@@ -587,24 +589,27 @@ int ope_normals(ope_ctx *ctx, ope_cloud *cloud, int k, const float vp[3], float 
   const bool want_host = out_normals || out_curvature;   // both null: the normals only stay attached to the cloud
   std::vector<float> packed(want_host ? n * 4 : 0);
   if (cloud->n_valid > 0) {
-    ope_index *ix = nullptr;
-    int rc = self_index(ctx, cloud, &ix);
-    if (rc != OPE_OK) return rc;
+    ope_index *own = nullptr;
+    if (!index) {
+      int rc = self_index(ctx, cloud, &own);
+      if (rc != OPE_OK) return rc;
+      index = own;
+    }
     const int nblocks = (int)std::min<size_t>((n + kKnnBlock - 1) / kKnnBlock, 4096);
     if (k == 12)
-      hipLaunchKernelGGL(normals_kernel<12>, dim3(nblocks), dim3(kKnnBlock), 0, ctx->stream, cloud->view(), ix->view(), k, v[0], v[1],
+      hipLaunchKernelGGL(normals_kernel<12>, dim3(nblocks), dim3(kKnnBlock), 0, ctx->stream, cloud->view(), index->view(), k, v[0], v[1],
                          v[2], cloud->d_nrm);
     else if (k == 30)
-      hipLaunchKernelGGL(normals_kernel<30>, dim3(nblocks), dim3(kKnnBlock), 0, ctx->stream, cloud->view(), ix->view(), k, v[0], v[1],
+      hipLaunchKernelGGL(normals_kernel<30>, dim3(nblocks), dim3(kKnnBlock), 0, ctx->stream, cloud->view(), index->view(), k, v[0], v[1],
                          v[2], cloud->d_nrm);
     else
-      hipLaunchKernelGGL(normals_kernel<0>, dim3(nblocks), dim3(kKnnBlock), kKnnLdsBytes, ctx->stream, cloud->view(), ix->view(), k,
+      hipLaunchKernelGGL(normals_kernel<0>, dim3(nblocks), dim3(kKnnBlock), kKnnLdsBytes, ctx->stream, cloud->view(), index->view(), k,
                          v[0], v[1], v[2], cloud->d_nrm);
     hipError_t e = hipSuccess;
     if (want_host) e = hipMemcpyAsync(packed.data(), cloud->d_nrm, sizeof(float4) * n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    ope_index_free(ix);
-    if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_normals: ") + hipGetErrorString(e));
+    if (own) ope_index_free(own);
+    if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string(who) + ": " + hipGetErrorString(e));
   } else {
     const float qn = std::numeric_limits<float>::quiet_NaN();
     std::vector<float> nan4(n * 4, qn);
@@ -618,6 +623,16 @@ int ope_normals(ope_ctx *ctx, ope_cloud *cloud, int k, const float vp[3], float 
     if (out_curvature) out_curvature[o] = packed[4 * i + 3];
   }
   return OPE_OK;
+}
+
+int ope_normals(ope_ctx *ctx, ope_cloud *cloud, int k, const float vp[3], float *out_normals, float *out_curvature) {
+  return normals_impl(ctx, cloud, nullptr, k, vp, out_normals, out_curvature, "ope_normals");
+}
+
+int ope_normals_from(ope_ctx *ctx, ope_cloud *queries, const ope_index *index, int k, const float vp[3], float *out_normals,
+                     float *out_curvature) {
+  if (!index) return set_err(ctx, OPE_EINVAL, "ope_normals_from: bad argument");
+  return normals_impl(ctx, queries, index, k, vp, out_normals, out_curvature, "ope_normals_from");
 }
 
 int ope_fpfh(ope_ctx *ctx, const ope_cloud *cloud, float radius, float *out33) {
