@@ -355,6 +355,8 @@ template <class PointInT, class PointOutT = Normal> class NormalEstimation {
   template <class Tree> void setSearchMethod(const Tree &) {}  // the GPU index replaces the kd-tree
   void setKSearch(int k) { k_ = k; }
   void setViewPoint(float x, float y, float z) { vp_[0] = x; vp_[1] = y; vp_[2] = z; }
+  // pcl::Feature::setSearchSurface: neighbourhoods are taken from `surface` instead of the input cloud
+  void setSearchSurface(const typename PointCloud<PointInT>::ConstPtr &surface) { surface_ = surface; }
   void compute(PointCloud<PointOutT> &out) {
     out.clear();
     ope_ctx *ctx = default_context();
@@ -363,7 +365,16 @@ template <class PointInT, class PointOutT = Normal> class NormalEstimation {
     if (!dev->h) return;
     const size_t n = input_->size();
     std::vector<float> nrm(3 * n), curv(n);
-    if (ope_normals(ctx, dev->h, k_, vp_, nrm.data(), curv.data()) != OPE_OK) { log_error("NormalEstimation", ctx); return; }
+    int rc;
+    if (surface_ && surface_ != input_) {
+      auto sdev = upload(*surface_, false);
+      IndexHandle six;
+      rc = sdev->h ? ope_index_build(ctx, sdev->h, nullptr, &six.h) : OPE_EINVAL;
+      if (rc == OPE_OK) rc = ope_normals_from(ctx, dev->h, six.h, k_, vp_, nrm.data(), curv.data());
+    } else {
+      rc = ope_normals(ctx, dev->h, k_, vp_, nrm.data(), curv.data());
+    }
+    if (rc != OPE_OK) { log_error("NormalEstimation", ctx); return; }
     out.resize(n);
     out.is_dense = true;
     for (size_t i = 0; i < n; ++i) {
@@ -373,7 +384,7 @@ template <class PointInT, class PointOutT = Normal> class NormalEstimation {
     }
   }
  private:
-  typename PointCloud<PointInT>::ConstPtr input_;
+  typename PointCloud<PointInT>::ConstPtr input_, surface_;
   int k_ = 0;
   float vp_[3] = {0, 0, 0};
 };
