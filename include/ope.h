@@ -177,10 +177,14 @@ int ope_icp_update(ope_ctx *ctx);
 /* Use a caller-owned device buffer of OPE_NUM_SUMS_MAX doubles for the sums (e.g. a torch tensor that
  * torch.distributed all-reduces); NULL restores the internal buffer. */
 int ope_icp_set_sums_buffer(ope_ctx *ctx, void *device_ptr);
-/* Enqueue n whole iterations (accumulate -> reduce -> [RCCL all-reduce if ope_comm_init_rank was
- * called] -> update) without synchronising the host. */
+/* Enqueue n whole iterations (accumulate -> [RCCL all-reduce if ope_comm_init_rank was called] -> update)
+ * without synchronising the host.  The accumulate launches ADD into the sums and ope_icp_update leaves them at
+ * zero: in the stepwise form every ope_icp_accumulate must be followed by one ope_icp_update. */
 int ope_icp_iterate(ope_ctx *ctx, int n_iterations);
 int ope_icp_poll(ope_ctx *ctx, ope_icp_result *result); /* syncs the stream */
+/* getFinalTransformation() of a run in progress (polls the device state): the transform after the iterations
+ * enqueued so far. */
+int ope_icp_current_transform(ope_ctx *ctx, float out_T[16]);
 int ope_icp_end(ope_ctx *ctx, float out_T[16], ope_icp_result *result);
 /* In sharded runs: the sizes getAlignStrength divides by (defaults: local sizes). */
 int ope_icp_set_global_sizes(ope_ctx *ctx, int64_t n_src_total, int64_t n_tgt_total);

@@ -129,6 +129,7 @@ ABI = [
     ("ope_icp_profile", C.c_int, [_vp, C.c_int]),
     ("ope_icp_profile_read", C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     ("ope_icp_poll", C.c_int, [_vp, C.POINTER(IcpResult)]),
+    ("ope_icp_current_transform", C.c_int, [_vp, _fp]),
     ("ope_icp_end", C.c_int, [_vp, _fp, C.POINTER(IcpResult)]),
     ("ope_icp_set_global_sizes", C.c_int, [_vp, C.c_int64, C.c_int64]),
     ("ope_icp_correspondences", C.c_int, [_vp, _ip, _ip, _fp, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -341,6 +342,12 @@ class Context:
         r = IcpResult()
         self._chk(lib().ope_icp_poll(self.h, C.byref(r)))
         return r
+
+    def icp_current_transform(self) -> np.ndarray:
+        """(4,4) final transformation after the iterations enqueued so far (synchronises)."""
+        T = np.empty(16, np.float32)
+        self._chk(lib().ope_icp_current_transform(self.h, _p(T, _fp)))
+        return from_colmajor(T)
 
     def icp_end(self) -> IcpOut:
         T = np.empty(16, np.float32)

@@ -13,7 +13,7 @@ namespace ope {
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
-                           uint32_t *, const uint32_t *, bool, int);
+                           uint32_t *, const uint32_t *, bool, int, double *);
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, uint32_t *);
 int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t, void *, size_t &);
 void fill_iota(hipStream_t, uint32_t *, uint32_t);
@@ -21,7 +21,7 @@ hipError_t morton_order_device(hipStream_t, const float *, size_t, const float[3
 hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t, int, const float[3], const float[3], int *, float4 **,
                             float4 **, float4 **, float4 **);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
-void launch_icp_update(hipStream_t, IcpState *, const double *);
+void launch_icp_update(hipStream_t, IcpState *, double *);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
 void launch_knn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int, int32_t *, float *);
 void launch_fitness(hipStream_t, int, const CloudView &, const BvhView &, const float *, double, double *);
@@ -61,7 +61,16 @@ static double *sums_ptr(ope_ctx *ctx) {
 }
 
 // One accumulate launch, optionally bracketed by HIP events on the launch stream (bench.py's roofline leg).
-static int enqueue_accumulate(ope_ctx *ctx) {
+// Sums of an accumulate launch: by default every block adds its 17 (44) partial sums straight into the run's sums
+// (fp64 atomics; the update kernel leaves them at zero again), which saves the reduction kernel and one kernel boundary
+// per iteration (C3: 181 -> 174 us per step) — the addition order, and with it the last bit of the sums, varies from
+// run to run.  OPE_DETERMINISTIC_SUMS=1 keeps one row per block and reduces the rows in a fixed tree instead.
+static bool atomic_sums_default() {
+  static const bool det = getenv("OPE_DETERMINISTIC_SUMS") != nullptr;
+  return !det;
+}
+
+static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   // re-sort the chunks by the cost they measured: after launches 1, 2, 4, ..., 32 and then every 32
   static const bool no_plan = getenv("OPE_NO_PLAN") != nullptr;  // developer A/B switch
   const int it_done = ctx->acc_launches++;
@@ -94,7 +103,7 @@ static int enqueue_accumulate(ope_ctx *ctx) {
   const bool packet = !no_packet && nch > (uint32_t)ctx->n_cu * 4u * (uint32_t)kAccWavesPerSimd;
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
                         recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
-                        ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting);
+                        ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr);
   if (timed) {
     OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
     ++ctx->prof_used;
@@ -558,6 +567,7 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
     if (rc != OPE_OK) return rc;
   }
   OPE_HIP(ctx, hipMemcpyAsync(ctx->d_state, h, sizeof *h, hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->d_sums_ext) OPE_HIP(ctx, hipMemsetAsync(ctx->d_sums_ext, 0, sizeof(double) * kNumSumsMax, ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 256, ctx->stream));
   // partial-sum rows of blocks that do not exist in this run must read as zero
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_partials, 0, sizeof(double) * kNumSumsMax * kAccMaxBlocks, ctx->stream));
@@ -581,9 +591,11 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
 
 int ope_icp_accumulate(ope_ctx *ctx) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_accumulate: no run in progress");
-  int rc = enqueue_accumulate(ctx);
+  const bool atomic = atomic_sums_default();
+  int rc = enqueue_accumulate(ctx, atomic);
   if (rc != OPE_OK) return rc;
-  launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, /*do_update=*/false, ctx->d_work_counter);
+  if (!atomic)
+    launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, /*do_update=*/false, ctx->d_work_counter);
   OPE_HIP(ctx, hipGetLastError());
   return OPE_OK;
 }
@@ -596,20 +608,29 @@ void *ope_icp_sums_device(ope_ctx *ctx) {
 int ope_icp_set_sums_buffer(ope_ctx *ctx, void *device_ptr) {
   if (!ctx) return OPE_EINVAL;
   ctx->d_sums_ext = static_cast<double *>(device_ptr);
+  // accumulate launches add into the sums: a buffer handed over mid-run starts from zero like the built-in one
+  if (ctx->d_sums_ext) OPE_HIP(ctx, hipMemsetAsync(ctx->d_sums_ext, 0, sizeof(double) * kNumSumsMax, ctx->stream));
   return OPE_OK;
 }
 
 int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_iterate: no run in progress");
-  const bool sharded = ctx->nccl_comm != nullptr && ctx->comm_nranks > 1;
+  // OPE_FORCE_SHARDED_PATH: run the accumulate -> all-reduce -> update sequence with a one-rank communicator too
+  // (developer / test switch: a one-GPU box can exercise the path the multi-GPU runs take)
+  static const bool force_sharded = getenv("OPE_FORCE_SHARDED_PATH") != nullptr;
+  const bool sharded = ctx->nccl_comm != nullptr && (ctx->comm_nranks > 1 || force_sharded);
   static const bool split_update = getenv("OPE_SPLIT_UPDATE") != nullptr;  // developer A/B switch
+  const bool atomic = atomic_sums_default();
   for (int b = 0; b < n_iterations; ++b) {
-    int rc = enqueue_accumulate(ctx);
+    int rc = enqueue_accumulate(ctx, atomic);
     if (rc != OPE_OK) return rc;
     if (sharded) {
-      launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
+      if (!atomic)
+        launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
       rc = comm_allreduce_sums(ctx, sums_ptr(ctx), ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LLS ? kNumSumsMax : kNumSums);
       if (rc != OPE_OK) return rc;
+      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx));
+    } else if (atomic) {
       launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx));
     } else if (split_update) {
       launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
@@ -674,6 +695,14 @@ int ope_icp_poll(ope_ctx *ctx, ope_icp_result *result) {
   OPE_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (result) fill_result(ctx, result);
+  return OPE_OK;
+}
+
+int ope_icp_current_transform(ope_ctx *ctx, float out_T[16]) {
+  if (!ctx || !ctx->run_active || !out_T) return set_err(ctx, OPE_ESTATE, "ope_icp_current_transform: no run in progress");
+  int rc = ope_icp_poll(ctx, nullptr);
+  if (rc != OPE_OK) return rc;
+  for (int i = 0; i < 16; ++i) out_T[i] = (float)ctx->h_state->F[i];
   return OPE_OK;
 }
 

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
-    const uint32_t *__restrict__ plan_info) {
+    const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic) {
   if (st->done) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
@@ -273,7 +273,11 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     double v = 0.0;
 #pragma unroll
     for (int w = 0; w < BLOCK / 64; ++w) v += s_red[w][threadIdx.x];
-    partials[threadIdx.x * kAccMaxBlocks + blockIdx.x] = v;
+    // One-GPU runs keep one row per block and reduce the rows in a fixed tree (bit-reproducible for a launch
+    // geometry).  Sharded runs add straight into the 17 (44) sums that the all-reduce takes next: one launch and one
+    // kernel boundary less per iteration, at the price of an addition order that varies from run to run (1e-16).
+    if (S_atomic != nullptr) unsafeAtomicAdd(S_atomic + threadIdx.x, v);
+    else partials[threadIdx.x * kAccMaxBlocks + blockIdx.x] = v;
   }
 }
 
@@ -696,7 +700,8 @@ __global__ __launch_bounds__(kRedBlock) void icp_reduce_update_kernel(IcpState *
   }
 }
 
-__global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, const double *S) {
+// The sums are consumed: they are left at zero, ready for the next accumulate launch to add into (sharded runs).
+__global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, double *S) {
   if (st->done) return;
   __shared__ double s_S[kNumSumsMax];
   __shared__ IcpState s_st;
@@ -705,7 +710,10 @@ __global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, const doub
   __syncthreads();
   if (threadIdx.x == 0) icp_update_lane(&s_st, s_S);
   __syncthreads();
+  if (threadIdx.x < kNumSumsMax) s_st.S[threadIdx.x] = 0.0;   // S may be the state's own array
+  __syncthreads();
   state_to_lds(st, &s_st);
+  if (threadIdx.x < kNumSumsMax) S[threadIdx.x] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -868,17 +876,17 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
                            const BvhView &tgt, const BvhView &srcix, const IcpState *st, double *partials,
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
                            const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
-                           int k_normal_shooting) {
+                           int k_normal_shooting, double *S_atomic) {
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS)                                                                       \
   hipLaunchKernelGGL((icp_accumulate_kernel<M, N, R>), dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, \
-                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info)
+                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic)
   if (mode == 0 && !recip && packet) {
     if (nrm)
       hipLaunchKernelGGL((icp_accumulate_kernel<0, true, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info);
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic);
     else
       hipLaunchKernelGGL((icp_accumulate_kernel<0, false, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info);
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic);
     return;
   }
   if (mode == 0) {
@@ -898,7 +906,7 @@ void launch_icp_reduce_update(hipStream_t stream, IcpState *st, const double *pa
                      do_update ? 1 : 0, work_counter);
 }
 
-void launch_icp_update(hipStream_t stream, IcpState *st, const double *S) {
+void launch_icp_update(hipStream_t stream, IcpState *st, double *S) {
   hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(64), 0, stream, st, S);
 }
 

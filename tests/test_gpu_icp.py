@@ -392,10 +392,13 @@ def test_icp_large_launch_packet_walk_matches_oracle(ctx):
     # bit for bit: the second iteration (start leaves known -> packet walks) searches with the transform the first
     # one produced; the oracle searching with that very transform must see identical squared distances
     ope = load_pkg()
-    one = ctx.icp(cs, ix, ope.default_icp_params(**{**kw, "max_iterations": 1}))
-    two = ctx.icp(cs, ix, ope.default_icp_params(**{**kw, "max_iterations": 2}))
+    ctx.icp_begin(cs, ix, ope.default_icp_params(**{**kw, "max_iterations": 2}), None)
+    ctx.icp_iterate(1)
+    T1 = ctx.icp_current_transform()
+    ctx.icp_iterate(1)
+    two = ctx.icp_end()
     q2, m2, d2 = ctx.icp_correspondences(len(src))
-    oi, od, _ = oracle.KdTree(tgt).knn(oracle.transform_points(src, one.T), 1)
+    oi, od, _ = oracle.KdTree(tgt).knn(oracle.transform_points(src, T1), 1)
     np.testing.assert_array_equal(d2, od[:, 0])
     diff = m2 != oi[:, 0]
     assert diff.mean() < 1e-4                              # exact fp32 distance ties may pick another index

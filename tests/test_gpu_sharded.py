@@ -137,3 +137,43 @@ def test_buildmodel_loop_sharded_over_two_ranks_matches_one_rank(tmp_path):
     ctx.close()
     assert np.abs(np.stack([p.T for p in ref.pairs]).astype(np.float64) - T2).max() < 1e-5
     assert np.abs(ref.cloud - c2).max() < 2e-5
+
+
+def _native_worker(force, out_path):
+    """One rank, the library's own RCCL communicator; with OPE_FORCE_SHARDED_PATH the loop takes the multi-GPU sequence
+    (accumulate straight into the sums -> ncclAllReduce -> update)."""
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if force:
+        os.environ["OPE_FORCE_SHARDED_PATH"] = "1"
+    import torch  # noqa: F401  (librccl / libamdhip64 of the torch wheel must be loaded first)
+    ope = importlib.import_module("object-pose-estimation_amd")
+    synth = importlib.import_module("object-pose-estimation_amd.synth")
+    src = synth.scene_cloud(60000); tgt = synth.model_surface(10000, 1)
+    ctx = ope.Context(0)
+    ctx.comm_init(ope.comm_unique_id(), 1, 0)
+    cs = ctx.upload(src); ix = ctx.build_index(ctx.upload(tgt))
+    p = ope.default_icp_params(max_iterations=30, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0,
+                               check_every=0)
+    ctx.icp_begin(cs, ix, p, None)
+    ctx.icp_iterate(30)
+    out = ctx.icp_end()
+    np.save(out_path, np.concatenate([out.T.ravel(), [out.iterations, out.n_corr, out.last_mse]]))
+    ctx.comm_destroy()
+    ctx.close()
+
+
+@pytest.mark.timeout(600)
+def test_native_rccl_loop_sequence_matches_the_one_gpu_loop(tmp_path):
+    res = []
+    for force in (False, True):
+        path = str(tmp_path / f"native_{int(force)}.npy")
+        ctx_mp = mp.get_context("spawn")
+        pr = ctx_mp.Process(target=_native_worker, args=(force, path))
+        pr.start(); pr.join(300)
+        assert pr.exitcode == 0
+        res.append(np.load(path))
+    a, b = res
+    assert a[16] == b[16] == 30 and a[17] == b[17] == 60000
+    assert np.abs(a[:16] - b[:16]).max() < 1e-6          # atomic sums: the addition order differs at the 1e-16 level
+    assert abs(a[18] - b[18]) <= 1e-9 * abs(a[18])
