@@ -7,8 +7,8 @@
 //       finds its exact nearest target point by BVH traversal (correspondence_estimation_mod.hpp:170),
 //       applies the distance threshold (:171) and the optional normal-based rejectors
 //       (correspondence_rejection_mod.h:368-391), stores the correspondence and accumulates the
-//       17 sums TransformationEstimationSVD/umeyama needs.  Block partials go to a fixed slot:
-//       no atomics, so results are bit-reproducible for a given launch geometry.
+//       17 sums TransformationEstimationSVD/umeyama needs.  Block sums are added into the run's sums
+//       (fp64 atomics), or written to one row per block for the fixed-tree reduction (OPE_DETERMINISTIC_SUMS).
 //   icp_reduce_update_kernel : fixed-order reduction of the block partials, then (one lane)
 //       mean/covariance -> 3x3 Jacobi SVD in fp64 -> incremental T, final_T = T * final_T
 //       (icp_mod.hpp:243-251) and DefaultConvergenceCriteria::hasConverged (:257).  The "done" flag
