@@ -208,8 +208,8 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     }
     ok = ok && owner;
     if (owner) {
-      corr_match[i] = ok ? match : -1;
-      corr_d2[i] = d2;
+      __builtin_nontemporal_store(ok ? match : -1, corr_match + i);   // streamed out: nothing re-reads them in this launch
+      __builtin_nontemporal_store(d2, corr_d2 + i);
     }
     {
       // fp64 terms: differences and products of fp32 values are exact in fp64, so the 17 sums do not
