@@ -120,16 +120,16 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     if (MODE == 0) {
       NearestVisitor v{active ? cst[15] : -INFINITY, kNoPos, 0};
       // start at the leaf that held this query's nearest neighbour one iteration ago (0 = none yet)
+      const uint32_t h = active ? hint[i] : 0u;
       if (OCT_OK && oct) {
-        if (active) bvh_traverse_oct(tgt, x, y, z, v, &s_stk[0][threadIdx.x & ~7u], BLOCK, hint[i]);
+        if (active) bvh_traverse_oct(tgt, x, y, z, v, &s_stk[0][threadIdx.x & ~7u], BLOCK, h);
       } else {
         // coherent chunks (a handful of start leaves for 64 queries) take one packet walk through the scalar cache
         // (PACKET instantiation: launches that fill the GPU); everything else the per-lane walk from its own leaf
-        const uint32_t h = active ? hint[i] : 0u;
         const bool done = PACKET && bvh_traverse_packet(tgt, x, y, z, active, v, h, stk, BLOCK);
         if (!done && active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, h);
       }
-      if (owner) hint[i] = v.leaf;
+      if (owner && v.leaf != h) hint[i] = v.leaf;   // most start leaves survive an iteration: 4 MB of writes saved on C3
       const bool found = active && v.pos != kNoPos;
       ok = found && !((double)v.best > max_d2);
       d2 = found ? v.best : INFINITY;
