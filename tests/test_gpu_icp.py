@@ -417,3 +417,23 @@ def test_c3_full_size_iterations_match_oracle(ctx):
     assert frob(out.T, ref.T) <= 1e-4
     assert out.n_corr == ref.n_corr == len(src)
     assert abs(out.last_mse - ref.last_mse) <= 1e-6 * max(ref.last_mse, 1e-12) + 1e-12
+
+
+def test_c3_full_size_properties_permutation_and_restart(ctx):
+    """Size-independent properties at BASELINE.json's full size (1 M x 100 k): the result does not depend on the order
+    of the scene points (the sums are exact fp64 terms, so regrouping changes them by ~1e-16), and restarting from the
+    transform of a 30-iteration run continues exactly where a 40-iteration run goes (the loop carries no hidden state
+    besides final_T: start leaves and chunk plans only steer the search)."""
+    ope = load_pkg()
+    src, tgt = synth.config_clouds("C3")
+    ct = ctx.upload(tgt)
+    ix = ctx.build_index(ct)
+    kw = dict(transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0, check_every=0)
+    a = ctx.icp(ctx.upload(src), ix, ope.default_icp_params(max_iterations=40, **kw))
+    perm = np.random.default_rng(0).permutation(len(src))
+    b = ctx.icp(ctx.upload(src[perm]), ix, ope.default_icp_params(max_iterations=40, **kw))
+    assert a.n_corr == b.n_corr == len(src)
+    assert frob(a.T, b.T) < 1e-6
+    c30 = ctx.icp(ctx.upload(src), ix, ope.default_icp_params(max_iterations=30, **kw))
+    c40 = ctx.icp(ctx.upload(src), ix, ope.default_icp_params(max_iterations=10, **kw), guess=c30.T)
+    assert frob(c40.T, a.T) < 1e-5       # final_T is carried in fp64 inside a run and handed over as fp32 here
