@@ -455,18 +455,20 @@ struct KnnRegVisitor {
     if (__ballot(ins) == 0ull) return;
     if (ins && dist < d[0]) leaf = lf;
     count += (ins && count < K) ? 1 : 0;
-    // d[j] <- d[j-1] where the new distance sorts before d[j-1]; the new distance lands at the first such gap
-    // (strict comparisons: an equal earlier entry stays in front, like the LDS list)
+    // Sorted insert of `dist` into ascending d[]: new d[j] = median(d[j-1], d[j], dist) — one v_med3_f32 per slot —
+    // and the index follows the same move: p[j-1] where dist sorts before d[j-1], i where it lands, p[j] otherwise
+    // (strict comparisons: an equal earlier entry stays in front, like the LDS list).  Lanes without a candidate
+    // (dist >= d[K-1]) come out unchanged.
+    bool lt_hi = dist < d[K - 1];   // dist < d[j]
 #pragma unroll
     for (int j = K - 1; j > 0; --j) {
-      const bool shift = dist < d[j - 1];
-      const bool here = !shift && dist < d[j];
-      d[j] = shift ? d[j - 1] : (here ? dist : d[j]);
-      p[j] = shift ? p[j - 1] : (here ? i : p[j]);
+      const bool lt_lo = dist < d[j - 1];
+      p[j] = lt_lo ? p[j - 1] : (lt_hi ? i : p[j]);
+      d[j] = __builtin_amdgcn_fmed3f(d[j - 1], d[j], dist);
+      lt_hi = lt_lo;
     }
-    const bool first = dist < d[0];
-    d[0] = first ? dist : d[0];
-    p[0] = first ? i : p[0];
+    p[0] = lt_hi ? i : p[0];
+    d[0] = fminf(d[0], dist);
   }
   __device__ __forceinline__ void on_node() {}
 };
