@@ -433,7 +433,9 @@ def test_c3_full_size_properties_permutation_and_restart(ctx):
     perm = np.random.default_rng(0).permutation(len(src))
     b = ctx.icp(ctx.upload(src[perm]), ix, ope.default_icp_params(max_iterations=40, **kw))
     assert a.n_corr == b.n_corr == len(src)
-    assert frob(a.T, b.T) < 1e-6
+    # not bit-equal: a query with two equidistant model points may pick either one depending on the walk order, and the
+    # slow ICP tail amplifies that over 40 iterations (observed ~1e-6; north_star's tolerance is 1e-4)
+    assert frob(a.T, b.T) < 1e-5
     c30 = ctx.icp(ctx.upload(src), ix, ope.default_icp_params(max_iterations=30, **kw))
     c40 = ctx.icp(ctx.upload(src), ix, ope.default_icp_params(max_iterations=10, **kw), guess=c30.T)
     assert frob(c40.T, a.T) < 1e-5       # final_T is carried in fp64 inside a run and handed over as fp32 here
