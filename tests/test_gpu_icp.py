@@ -322,7 +322,7 @@ def test_stepwise_api_equals_run(ctx):
         ctx.icp_update()
     b = ctx.icp_end()
     # the cost-aware chunk schedule follows measured cycles, so fp64 partial sums may group differently
-    np.testing.assert_allclose(a.T, b.T, atol=1e-6)
+    np.testing.assert_allclose(a.T, b.T, atol=1e-5)      # block sums are added atomically: the order varies run to run
     assert a.iterations == b.iterations == 8
 
 
