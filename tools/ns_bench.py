@@ -8,8 +8,9 @@ src, tgt = synth.config_clouds(name)
 ctx = ope.Context(0)
 cs = ctx.upload(src); ct = ctx.upload(tgt)
 t0 = time.perf_counter(); ctx.normals(cs, 30, fetch=False); ctx.normals(ct, 30, fetch=False); ctx.sync(); t1 = time.perf_counter()
-ix = ctx.build_index(ct)
-print(f"{name}: normals k=30 on both clouds {1e3*(t1-t0):.1f} ms", flush=True)
+leaf = int(sys.argv[2]) if len(sys.argv) > 2 else None
+ix = ctx.build_index(ct, leaf_size=leaf)
+print(f"{name}: normals k=30 on both clouds {1e3*(t1-t0):.1f} ms; index leaf size {leaf or 'default'}", flush=True)
 for k in (20, 10):
     kw = dict(max_iterations=50, mse_threshold_absolute=-1.0, check_every=0, corr_mode=ope.CORR_NORMAL_SHOOTING, k_normal_shooting=k,
               use_surface_normal_rej=1, surface_normal_thr=0.7)
