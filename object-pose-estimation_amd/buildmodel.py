@@ -36,6 +36,7 @@ class PairResult:
 class RegistrationResult:
     cloud: np.ndarray                      # accumulated, registered cloud (frame of the last input)
     pairs: list = field(default_factory=list)
+    rgb: np.ndarray | None = None          # packed colours of `cloud`, when the frames came with colours
 
 
 def icp_params_with_normals(ope, corr_rej_thresh: float, max_iterations: int, max_corr_dist: float | None = None):
@@ -80,13 +81,17 @@ def get_icp_normal(ope, ctx, source_xyz, target_xyz, corr_rej_thresh: float = 0.
 
 
 def register_point_clouds(ope, ctx, frames, max_corr_dist: float = 0.005, corr_rej_thresh: float = 0.7,
-                          max_iterations: int = 500, **kw) -> RegistrationResult:
+                          max_iterations: int = 500, colors=None, **kw) -> RegistrationResult:
     """Sequential accumulate-and-register over N frames (regmeshpcd.cpp:210-271).
 
     cloudTemp = frame 0; for every next frame: align cloudTemp to it, then cloudTemp = aligned + frame.
+    `colors` (one packed-rgb uint32 array per frame, the PointXYZRGB payload) ride along untouched, as the rgb
+    field does through transformPointCloud and operator+= in the reference.
     """
     if len(frames) == 0:
         raise ValueError("register_point_clouds: no frames")
+    if colors is not None and (len(colors) != len(frames) or any(len(c) != len(f) for c, f in zip(colors, frames))):
+        raise ValueError("register_point_clouds: colors must match the frames point for point")
     acc = np.ascontiguousarray(frames[0], np.float32)
     res = RegistrationResult(acc)
     for i in range(len(frames) - 1):
@@ -95,6 +100,54 @@ def register_point_clouds(ope, ctx, frames, max_corr_dist: float = 0.005, corr_r
         acc = np.concatenate([aligned, target], axis=0)   # :254-258
         res.pairs.append(pr)
     res.cloud = acc
+    if colors is not None:
+        res.rgb = np.concatenate([np.ascontiguousarray(c, np.uint32) for c in colors])
+    return res
+
+
+def build_model_from_directory(ope, ctx, pcd_dir: str, out_path: str | None = None, limits=None, segment=None,
+                               max_corr_dist: float = 0.005, corr_rej_thresh: float = 0.7, max_iterations: int = 500,
+                               **kw) -> RegistrationResult:
+    """BuildModel's file-to-file loop (BuildModel/src/main.cpp:113-153 load, :185-190 crop, :207-225 register + save).
+
+    Loads every `*.pcd` of `pcd_dir`, crops each frame with the pass-through box `limits` = (xmin, xmax, ymin, ymax,
+    zmin, zmax) on the device, registers the frames sequentially and writes `<out_path>` as binary PCD
+    (`FIELDS x y z rgb` when the inputs carry colour), which is what `savePCDFile(name, cloud, true)` writes.
+
+    The reference walks the directory in `boost::filesystem::directory_iterator` order, which is unspecified; here
+    the files are taken in name order.  Between crop and registration the reference cuts the object off its
+    supporting plane (`ObjectSegmentationPlane`, main.cpp:186): that step is outside this path (SURVEY.md §8f-4
+    ranks it after the file loop) and enters as the optional `segment(xyz, rgb) -> (xyz, rgb)` hook.
+    """
+    import os
+    from . import pcd
+
+    names = sorted(n for n in os.listdir(pcd_dir) if n.lower().endswith(".pcd"))
+    if not names:
+        raise ValueError(f"build_model_from_directory: no .pcd files in {pcd_dir!r}")
+    frames, colors = [], []
+    for name in names:
+        xyz, rgb = pcd.read_pcd(os.path.join(pcd_dir, name))
+        if limits is not None:
+            lim = np.asarray(limits, np.float32).reshape(3, 2)
+            c = ctx.upload(xyz)
+            try:
+                keep = ctx.pass_through(c, lim[:, 0], lim[:, 1])      # processingpcd.cpp getPassThrough
+            finally:
+                c.free()
+        else:
+            keep = np.flatnonzero(np.isfinite(xyz).all(axis=1)).astype(np.int32)
+        xyz = xyz[keep]
+        rgb = rgb[keep] if rgb is not None else None
+        if segment is not None:
+            xyz, rgb = segment(xyz, rgb)
+        frames.append(np.ascontiguousarray(xyz, np.float32))
+        colors.append(rgb)
+    have_rgb = all(c is not None for c in colors)
+    res = register_point_clouds(ope, ctx, frames, max_corr_dist, corr_rej_thresh, max_iterations,
+                                colors=colors if have_rgb else None, **kw)
+    if out_path is not None:
+        pcd.write_pcd(out_path, res.cloud, res.rgb)
     return res
 
 

@@ -83,3 +83,42 @@ def test_register_point_clouds_single_frame_and_empty(env):
     assert res.pairs == [] and np.array_equal(res.cloud, f[0])
     with pytest.raises(ValueError):
         buildmodel.register_point_clouds(ope, ctx, [])
+
+
+def test_build_model_from_directory_round_trip(env, tmp_path):
+    """main.cpp:113-153,185-190,207-225: PCD files in, pass-through crop, sequential registration, binary PCD out.
+    The file loop must give exactly what the in-memory loop gives on the same (cropped) frames, and carry the packed
+    colours point for point."""
+    ope, ctx = env
+    pcd = _imp("object-pose-estimation_amd.pcd")
+    frames = synth.frame_views(3, 2500, n_azimuths=32)
+    rng = np.random.default_rng(5)
+    src_dir = tmp_path / "scans"
+    src_dir.mkdir()
+    colors, padded = [], []
+    for i, f in enumerate(frames):
+        # every file also holds points outside the crop box and a NaN point, which the crop must drop
+        junk = (f[:50] + np.float32([2.0, 0, 0])).astype(np.float32)
+        xyz = np.concatenate([f, junk, np.full((1, 3), np.nan, np.float32)])
+        rgb = rng.integers(0, 1 << 24, len(xyz), dtype=np.uint32)
+        pcd.write_pcd(str(src_dir / f"obj{i}.pcd"), xyz, rgb)
+        padded.append(xyz)
+        colors.append(rgb[: len(f)])
+    (src_dir / "notes.txt").write_text("not a cloud")
+    allpts = np.concatenate(frames)
+    lo, hi = allpts.min(0) - 0.01, allpts.max(0) + 0.01
+    limits = (lo[0], hi[0], lo[1], hi[1], lo[2], hi[2])
+    out_file = tmp_path / "objAligned.pcd"
+    res = buildmodel.build_model_from_directory(ope, ctx, str(src_dir), str(out_file), limits=limits, max_iterations=30)
+    ref = buildmodel.register_point_clouds(ope, ctx, frames, max_iterations=30, colors=colors)
+    assert res.cloud.shape == (3 * 2500, 3)
+    assert np.abs(res.cloud - ref.cloud).max() < 1e-5     # two GPU runs: summation order is not fixed
+    np.testing.assert_array_equal(res.rgb, ref.rgb)
+    np.testing.assert_array_equal(res.rgb, np.concatenate(colors))
+    xyz, rgb = pcd.read_pcd(str(out_file))
+    np.testing.assert_array_equal(xyz, res.cloud)
+    np.testing.assert_array_equal(rgb, res.rgb)
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    with pytest.raises(ValueError):
+        buildmodel.build_model_from_directory(ope, ctx, str(empty), None)
