@@ -124,7 +124,7 @@ def main() -> int:
 
     # ---- coarse stage (the "FPFH init" of config C3), as estimateCoarsePose runs it (poseestimator.cpp:16-73):
     # uniform keypoints (leaf 0.01) -> normals (k=30) -> FPFH (r=0.03) on both clouds -> SAC-IA (400 x 5 x 5).
-    # Every rank computes the same (deterministic) initial pose; it is reported, not part of `value`.
+    # Every rank computes the initial pose (rank 0's is broadcast and used); it is reported, not part of `value`.
     coarse = None
     guess = None
     if not args.no_coarse:
@@ -154,6 +154,13 @@ def main() -> int:
                   "note": "host wall-clock incl. uploads, device index builds and read-backs; not part of value. The synthetic "
                           "model is nearly symmetric under a half turn: SAC-IA may land on the mirrored fit "
                           "(Frobenius 2.83 from the generator's pose, same residual to 1%)"}
+
+    if launched and guess is not None:
+        # one initial pose for the whole job: every rank computed it from the same inputs, but the ranks must not
+        # depend on bit-identical results across devices, so rank 0's is the one that is used
+        g = torch.from_numpy(np.ascontiguousarray(guess)).cuda()
+        dist.broadcast(g, src=0)
+        guess = g.cpu().numpy()
 
     params = ope.default_icp_params(max_iterations=W + K + 1, transformation_epsilon=0.0,
                                     euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0, check_every=0)
