@@ -383,18 +383,20 @@ int ope_nn_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *index
   float *d_T;
   int rc = upload_T(ctx, T, &d_T);
   if (rc != OPE_OK) return rc;
-  int32_t *d_idx;
-  float *d_d2;
-  OPE_HIP(ctx, hipMalloc((void **)&d_idx, sizeof(int32_t) * n));
-  OPE_HIP(ctx, hipMalloc((void **)&d_d2, sizeof(float) * n));
-  launch_nn_search(ctx->stream, queries->view(), index->view(), d_T, d_idx, d_d2);
+  int32_t *d_idx = nullptr;
+  float *d_d2 = nullptr;
+  hipError_t e = hipMalloc((void **)&d_idx, sizeof(int32_t) * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_d2, sizeof(float) * n);
   std::vector<int32_t> hi(n);
   std::vector<float> hd(n);
-  hipError_t e = hipMemcpyAsync(hi.data(), d_idx, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) {
+    launch_nn_search(ctx->stream, queries->view(), index->view(), d_T, d_idx, d_d2);
+    e = hipMemcpyAsync(hi.data(), d_idx, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
+  }
   if (e == hipSuccess) e = hipMemcpyAsync(hd.data(), d_d2, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_idx);
-  (void)hipFree(d_d2);
+  if (d_idx) (void)hipFree(d_idx);
+  if (d_d2) (void)hipFree(d_d2);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_nn_search: ") + hipGetErrorString(e));
   for (size_t i = 0; i < n; ++i) {
     out_idx[queries->perm[i]] = hi[i];
@@ -413,18 +415,20 @@ int ope_knn_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *inde
   float *d_T;
   int rc = upload_T(ctx, T, &d_T);
   if (rc != OPE_OK) return rc;
-  int32_t *d_idx;
-  float *d_d2;
-  OPE_HIP(ctx, hipMalloc((void **)&d_idx, sizeof(int32_t) * n * k));
-  OPE_HIP(ctx, hipMalloc((void **)&d_d2, sizeof(float) * n * k));
-  launch_knn_search(ctx->stream, queries->view(), index->view(), d_T, k, d_idx, d_d2);
+  int32_t *d_idx = nullptr;
+  float *d_d2 = nullptr;
+  hipError_t e = hipMalloc((void **)&d_idx, sizeof(int32_t) * n * k);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_d2, sizeof(float) * n * k);
   std::vector<int32_t> hi(n * k);
   std::vector<float> hd(n * k);
-  hipError_t e = hipMemcpyAsync(hi.data(), d_idx, sizeof(int32_t) * n * k, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) {
+    launch_knn_search(ctx->stream, queries->view(), index->view(), d_T, k, d_idx, d_d2);
+    e = hipMemcpyAsync(hi.data(), d_idx, sizeof(int32_t) * n * k, hipMemcpyDeviceToHost, ctx->stream);
+  }
   if (e == hipSuccess) e = hipMemcpyAsync(hd.data(), d_d2, sizeof(float) * n * k, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_idx);
-  (void)hipFree(d_d2);
+  if (d_idx) (void)hipFree(d_idx);
+  if (d_d2) (void)hipFree(d_d2);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_knn_search: ") + hipGetErrorString(e));
   for (size_t i = 0; i < n; ++i) {
     std::memcpy(out_idx + (size_t)queries->perm[i] * k, hi.data() + i * k, sizeof(int32_t) * k);

@@ -551,19 +551,23 @@ int ope_radius_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *i
   int32_t *d_cnt = nullptr, *d_idx = nullptr;
   float *d_d2 = nullptr;
   const size_t m = std::max<size_t>((size_t)max_nn * n, 1);
-  OPE_HIP(ctx, hipMalloc((void **)&d_cnt, sizeof(int32_t) * n));
-  OPE_HIP(ctx, hipMalloc((void **)&d_idx, sizeof(int32_t) * m));
-  OPE_HIP(ctx, hipMalloc((void **)&d_d2, sizeof(float) * m));
-  const int nblocks = (int)std::min<size_t>((n + kKnnBlock - 1) / kKnnBlock, 4096);
-  hipLaunchKernelGGL(radius_search_kernel, dim3(nblocks), dim3(kKnnBlock), kKnnLdsBytes, ctx->stream, queries->view(),
-                     index->view(), radius * radius, max_nn, d_cnt, d_idx, d_d2);
+  hipError_t e = hipMalloc((void **)&d_cnt, sizeof(int32_t) * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_idx, sizeof(int32_t) * m);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_d2, sizeof(float) * m);
   std::vector<int32_t> hc(n), hi(m);
   std::vector<float> hd(m);
-  hipError_t e = hipMemcpyAsync(hc.data(), d_cnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) {
+    const int nblocks = (int)std::min<size_t>((n + kKnnBlock - 1) / kKnnBlock, 4096);
+    hipLaunchKernelGGL(radius_search_kernel, dim3(nblocks), dim3(kKnnBlock), kKnnLdsBytes, ctx->stream, queries->view(),
+                       index->view(), radius * radius, max_nn, d_cnt, d_idx, d_d2);
+    e = hipMemcpyAsync(hc.data(), d_cnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
+  }
   if (e == hipSuccess && max_nn) e = hipMemcpyAsync(hi.data(), d_idx, sizeof(int32_t) * m, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess && max_nn) e = hipMemcpyAsync(hd.data(), d_d2, sizeof(float) * m, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_cnt); (void)hipFree(d_idx); (void)hipFree(d_d2);
+  if (d_cnt) (void)hipFree(d_cnt);
+  if (d_idx) (void)hipFree(d_idx);
+  if (d_d2) (void)hipFree(d_d2);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_radius_search: ") + hipGetErrorString(e));
   for (size_t i = 0; i < n; ++i) {
     const size_t o = (size_t)queries->perm[i];

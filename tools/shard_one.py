@@ -10,7 +10,10 @@ W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 ctx = ope.Context(0)
 ix = ctx.build_index(ctx.upload(model))
 lo, hi = sharded.shard_range(len(scene), W, 0)
-cs = ctx.upload(scene[lo:hi])
+pts = scene[lo:hi]
+if len(sys.argv) > 2 and sys.argv[2] == "inliers":      # floor: every query sits on the model surface
+    pts = synth.model_surface(hi - lo, 7)
+cs = ctx.upload(pts)
 kw = dict(max_iterations=200, mse_threshold_absolute=-1.0, check_every=0)
 ctx.icp(cs, ix, ope.default_icp_params(**{**kw, "max_iterations": 40}))
 t0 = time.perf_counter(); ctx.icp(cs, ix, ope.default_icp_params(**kw)); dt = time.perf_counter() - t0
