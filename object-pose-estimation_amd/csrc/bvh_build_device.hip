@@ -9,7 +9,7 @@
 //                            the floats) -> split axis = widest extent -> ONE rocPRIM radix sort of
 //                            (node << 32 | coordinate along the node's axis): every node's range is sorted in
 //                            place, so its lower half is its left child.  D sorts of n keys in total.
-//   then, level by level:    one block per node fits the oriented box: mean and covariance in fp64, cyclic
+//   then, level by level:    one block per node (first ten levels of large clouds: see TopWork) fits the oriented box: mean and covariance in fp64, cyclic
 //                            Jacobi, mid-range centre along the rounded axes, half extents about the ROUNDED
 //                            centre plus the margin that covers the traversal's fp32 evaluation.
 //
@@ -46,29 +46,52 @@ __device__ __forceinline__ uint32_t leaf_of(uint32_t p, uint32_t n, int D) {
 }
 __device__ __forceinline__ uint32_t leaf_start(unsigned long long j, uint32_t n, int D) { return (uint32_t)((j * n) >> D); }
 
+constexpr int kBboxMaxRows = 16;   // consecutive 256-point rows one block walks (large clouds; 1 for small ones)
+
+// Per-node bounding boxes of `level`.  A wave walks `rows` rows of the sorted order; as long as its 64 points
+// stay inside one node it only keeps per-lane minima / maxima, and it issues ONE set of six atomics when the node
+// changes or the tile ends (at the top levels every wave of a 4 M-point cloud used to hit the same six words).
 __global__ __launch_bounds__(256) void level_bbox_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, uint32_t n,
-                                                          int D, int level, uint32_t *__restrict__ mn, uint32_t *__restrict__ mx) {
-  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
-  const bool active = p < n;
-  const uint32_t node = active ? (leaf_of(p, n, D) >> (D - level)) : 0xffffffffu;
-  float x = 0.f, y = 0.f, z = 0.f;
-  if (active) { const float4 q = pts[order[p]]; x = q.x; y = q.y; z = q.z; }
-  // a wave usually lies inside one node: reduce there, one atomic per wave and component
-  const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
-  if (__ballot(node != first) == 0ull) {
-    float lx = x, ly = y, lz = z, hx = x, hy = y, hz = z;
+                                                          int D, int level, int rows, uint32_t *__restrict__ mn, uint32_t *__restrict__ mx) {
+  constexpr uint32_t kNone = 0xffffffffu;
+  uint32_t cur = kNone;   // wave-uniform: node of the run being accumulated
+  float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
+  auto flush = [&]() {
+    if (cur == kNone) return;
     for (int off = 32; off >= 1; off >>= 1) {
       lx = fminf(lx, __shfl_xor(lx, off, 64)); ly = fminf(ly, __shfl_xor(ly, off, 64)); lz = fminf(lz, __shfl_xor(lz, off, 64));
       hx = fmaxf(hx, __shfl_xor(hx, off, 64)); hy = fmaxf(hy, __shfl_xor(hy, off, 64)); hz = fmaxf(hz, __shfl_xor(hz, off, 64));
     }
-    if ((threadIdx.x & 63u) == 0u && active) {
-      atomicMin(mn + 3 * node + 0, enc_f32(lx)); atomicMin(mn + 3 * node + 1, enc_f32(ly)); atomicMin(mn + 3 * node + 2, enc_f32(lz));
-      atomicMax(mx + 3 * node + 0, enc_f32(hx)); atomicMax(mx + 3 * node + 1, enc_f32(hy)); atomicMax(mx + 3 * node + 2, enc_f32(hz));
+    if ((threadIdx.x & 63u) == 0u) {
+      atomicMin(mn + 3 * cur + 0, enc_f32(lx)); atomicMin(mn + 3 * cur + 1, enc_f32(ly)); atomicMin(mn + 3 * cur + 2, enc_f32(lz));
+      atomicMax(mx + 3 * cur + 0, enc_f32(hx)); atomicMax(mx + 3 * cur + 1, enc_f32(hy)); atomicMax(mx + 3 * cur + 2, enc_f32(hz));
     }
-  } else if (active) {
-    atomicMin(mn + 3 * node + 0, enc_f32(x)); atomicMin(mn + 3 * node + 1, enc_f32(y)); atomicMin(mn + 3 * node + 2, enc_f32(z));
-    atomicMax(mx + 3 * node + 0, enc_f32(x)); atomicMax(mx + 3 * node + 1, enc_f32(y)); atomicMax(mx + 3 * node + 2, enc_f32(z));
+    cur = kNone;
+    lx = ly = lz = INFINITY; hx = hy = hz = -INFINITY;
+  };
+  const unsigned long long base = (unsigned long long)blockIdx.x * (256ull * (unsigned)rows);
+  for (int r = 0; r < rows; ++r) {
+    const unsigned long long pp = base + (unsigned long long)r * 256ull + threadIdx.x;
+    const bool active = pp < n;
+    const uint32_t p = (uint32_t)pp;
+    const uint32_t node = active ? (leaf_of(p, n, D) >> (D - level)) : kNone;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (active) { const float4 q = pts[order[p]]; x = q.x; y = q.y; z = q.z; }
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);
+    if (__ballot(node != first) == 0ull) {   // the whole wave in one node (or past the end)
+      if (first == kNone) continue;
+      if (first != cur) { flush(); cur = first; }
+      lx = fminf(lx, x); ly = fminf(ly, y); lz = fminf(lz, z);
+      hx = fmaxf(hx, x); hy = fmaxf(hy, y); hz = fmaxf(hz, z);
+    } else {
+      flush();
+      if (active) {
+        atomicMin(mn + 3 * node + 0, enc_f32(x)); atomicMin(mn + 3 * node + 1, enc_f32(y)); atomicMin(mn + 3 * node + 2, enc_f32(z));
+        atomicMax(mx + 3 * node + 0, enc_f32(x)); atomicMax(mx + 3 * node + 1, enc_f32(y)); atomicMax(mx + 3 * node + 2, enc_f32(z));
+      }
+    }
   }
+  flush();
 }
 
 __global__ __launch_bounds__(256) void level_key_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, uint32_t n, int D,
@@ -242,6 +265,182 @@ __global__ __launch_bounds__(kFitBlock) void fit_obb_kernel(const float4 *__rest
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Top of the tree for large clouds.  One block per node leaves the first levels to a handful of blocks (the root of a
+// 4 M-point cloud: one block, four passes over every point, 17 ms).  For levels < kTopLevels the fit is therefore
+// done from the 2^kTopLevels node ranges of level kTopLevels ("slices", one block each):
+//   moments   per slice: sum of d and d dT about a fixed pivot, fp64                       (top_moments_kernel)
+//   combine   pairwise up the tree in a fixed order: deterministic                          (top_combine_kernel)
+//   axes      per node: mean, covariance, Jacobi, rounded axes                              (top_axes_kernel)
+//   range     per slice and ancestor: min / max of the projections -> atomicMin/Max on
+//             order-preserving integer images (exact, order-independent)                    (top_range_kernel)
+//   centre    per node: mid-range point, rounded to float                                   (top_centre_kernel)
+//   extent    per slice and ancestor: half extents about the ROUNDED centre, farthest point (top_extent_kernel)
+//   write     per node: margins, 48-byte record                                             (top_write_kernel)
+// Same formulas and margins as fit_obb_kernel; only the mean / covariance come from raw moments instead of two
+// passes (axes may differ in the last bits, the boxes contain their points either way).
+constexpr int kTopLevels = 10;
+constexpr uint32_t kTopSlices = 1u << kTopLevels;
+constexpr size_t kTopMinPoints = 262144;
+
+__device__ __forceinline__ unsigned long long enc_f64(double d) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dec_f64(unsigned long long u) {
+  const unsigned long long b = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
+  return __longlong_as_double((long long)b);
+}
+
+struct TopWork {
+  double mom[2 * kTopSlices][9];            // heap-indexed raw moments: sum d (3), sum d dT (xx xy xz yy yz zz)
+  double A[kTopSlices][9];                  // rows: rounded axis 0, axis 1, their cross product (nodes 1..kTopSlices-1)
+  unsigned long long lo[kTopSlices][3];     // order-preserving images (memset 0xff = above every image)
+  unsigned long long hi[kTopSlices][3];     // (memset 0 = below every image)
+  unsigned long long ext[kTopSlices][4];    // bit patterns of non-negative doubles h0 h1 h2 far (memset 0)
+  float cf[kTopSlices][4];
+};
+
+__device__ __forceinline__ void slice_range(uint32_t s, uint32_t n, int D, uint32_t &b, uint32_t &e) {
+  const int sh = D - kTopLevels;
+  b = leaf_start((unsigned long long)s << sh, n, D);
+  e = leaf_start((unsigned long long)(s + 1) << sh, n, D);
+}
+
+__global__ __launch_bounds__(kFitBlock) void top_moments_kernel(const float4 *__restrict__ pts, uint32_t n, int D, double px, double py,
+                                                                double pz, TopWork *__restrict__ w) {
+  __shared__ double s_tmp[kFitBlock / 64];
+  uint32_t b, e;
+  slice_range(blockIdx.x, n, D, b, e);
+  double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t i = b + threadIdx.x; i < e; i += kFitBlock) {
+    const float4 p = pts[i];
+    const double dx = p.x - px, dy = p.y - py, dz = p.z - pz;
+    m[0] += dx; m[1] += dy; m[2] += dz;
+    m[3] += dx * dx; m[4] += dx * dy; m[5] += dx * dz; m[6] += dy * dy; m[7] += dy * dz; m[8] += dz * dz;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const double r = block_reduce(m[k], s_tmp, OpAdd());
+    if (threadIdx.x == 0) w->mom[kTopSlices + blockIdx.x][k] = r;
+  }
+}
+
+__global__ __launch_bounds__(1024) void top_combine_kernel(TopWork *__restrict__ w) {
+  for (int l = kTopLevels - 1; l >= 0; --l) {
+    if (threadIdx.x < (1u << l)) {
+      const uint32_t node = (1u << l) + threadIdx.x;
+      for (int k = 0; k < 9; ++k) w->mom[node][k] = w->mom[2 * node][k] + w->mom[2 * node + 1][k];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kFitBlock) void top_axes_kernel(uint32_t n, int D, TopWork *__restrict__ w, float *__restrict__ nodes,
+                                                             float4 *__restrict__ axis2) {
+  const uint32_t node = blockIdx.x * kFitBlock + threadIdx.x;
+  if (node == 0 || node >= kTopSlices) return;
+  const int l = 31 - __clz(node);
+  const uint32_t j = node - (1u << l);
+  const uint32_t b = leaf_start((unsigned long long)j << (D - l), n, D), e = leaf_start((unsigned long long)(j + 1) << (D - l), n, D);
+  const double cnt = (double)(e - b);
+  const double *m = w->mom[node];
+  const double mx = m[0] / cnt, my = m[1] / cnt, mz = m[2] / cnt;   // mean, relative to the pivot
+  double C[9], V[9];
+  C[0] = m[3] - cnt * mx * mx; C[1] = m[4] - cnt * mx * my; C[2] = m[5] - cnt * mx * mz;
+  C[4] = m[6] - cnt * my * my; C[5] = m[7] - cnt * my * mz; C[8] = m[8] - cnt * mz * mz;
+  C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
+  jacobi_eig3_dev(C, V);
+  float a0[3], a1[3];
+  for (int d = 0; d < 3; ++d) { a0[d] = (float)V[3 * d + 0]; a1[d] = (float)V[3 * d + 1]; }
+  double A[9];
+  for (int d = 0; d < 3; ++d) { A[d] = a0[d]; A[3 + d] = a1[d]; }
+  A[6] = A[1] * A[5] - A[2] * A[4];
+  A[7] = A[2] * A[3] - A[0] * A[5];
+  A[8] = A[0] * A[4] - A[1] * A[3];
+  for (int k = 0; k < 9; ++k) w->A[node][k] = A[k];
+  float *o = nodes + (size_t)kNodeFloats * node;
+  o[4] = a0[0]; o[5] = a0[1]; o[6] = a0[2];
+  o[8] = a1[0]; o[9] = a1[1]; o[10] = a1[2];
+  axis2[node] = make_float4((float)A[6], (float)A[7], (float)A[8], 0.f);
+}
+
+__global__ __launch_bounds__(kFitBlock) void top_range_kernel(const float4 *__restrict__ pts, uint32_t n, int D, TopWork *__restrict__ w) {
+  __shared__ double s_tmp[kFitBlock / 64];
+  uint32_t b, e;
+  slice_range(blockIdx.x, n, D, b, e);
+  for (int l = 0; l < kTopLevels; ++l) {
+    const uint32_t node = (1u << l) + (blockIdx.x >> (kTopLevels - l));
+    double A[9];
+    for (int k = 0; k < 9; ++k) A[k] = w->A[node][k];
+    double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (uint32_t i = b + threadIdx.x; i < e; i += kFitBlock) {
+      const float4 p = pts[i];
+      for (int k = 0; k < 3; ++k) {
+        const double t = A[3 * k] * p.x + A[3 * k + 1] * p.y + A[3 * k + 2] * p.z;
+        lo[k] = t < lo[k] ? t : lo[k];
+        hi[k] = t > hi[k] ? t : hi[k];
+      }
+    }
+    for (int k = 0; k < 3; ++k) {
+      const double rl = block_reduce(lo[k], s_tmp, OpMin()), rh = block_reduce(hi[k], s_tmp, OpMax());
+      if (threadIdx.x == 0 && e > b) {
+        atomicMin(&w->lo[node][k], enc_f64(rl));
+        atomicMax(&w->hi[node][k], enc_f64(rh));
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kFitBlock) void top_centre_kernel(TopWork *__restrict__ w) {
+  const uint32_t node = blockIdx.x * kFitBlock + threadIdx.x;
+  if (node == 0 || node >= kTopSlices) return;
+  const double *A = w->A[node];
+  double mid[3];
+  for (int k = 0; k < 3; ++k) mid[k] = 0.5 * (dec_f64(w->lo[node][k]) + dec_f64(w->hi[node][k]));
+  for (int d = 0; d < 3; ++d) w->cf[node][d] = (float)(mid[0] * A[d] + mid[1] * A[3 + d] + mid[2] * A[6 + d]);
+}
+
+__global__ __launch_bounds__(kFitBlock) void top_extent_kernel(const float4 *__restrict__ pts, uint32_t n, int D, TopWork *__restrict__ w) {
+  __shared__ double s_tmp[kFitBlock / 64];
+  uint32_t b, e;
+  slice_range(blockIdx.x, n, D, b, e);
+  for (int l = 0; l < kTopLevels; ++l) {
+    const uint32_t node = (1u << l) + (blockIdx.x >> (kTopLevels - l));
+    double A[9];
+    for (int k = 0; k < 9; ++k) A[k] = w->A[node][k];
+    const float cf0 = w->cf[node][0], cf1 = w->cf[node][1], cf2 = w->cf[node][2];
+    double h[3] = {0, 0, 0}, far = 0;
+    for (uint32_t i = b + threadIdx.x; i < e; i += kFitBlock) {
+      const float4 p = pts[i];
+      const double vx = (double)p.x - cf0, vy = (double)p.y - cf1, vz = (double)p.z - cf2;
+      const double r = sqrt(vx * vx + vy * vy + vz * vz);
+      far = r > far ? r : far;
+      for (int k = 0; k < 3; ++k) {
+        const double t = fabs(A[3 * k] * vx + A[3 * k + 1] * vy + A[3 * k + 2] * vz);
+        h[k] = t > h[k] ? t : h[k];
+      }
+    }
+    far = block_reduce(far, s_tmp, OpMax());
+    for (int k = 0; k < 3; ++k) h[k] = block_reduce(h[k], s_tmp, OpMax());
+    if (threadIdx.x == 0) {   // non-negative doubles order like their bit patterns
+      for (int k = 0; k < 3; ++k) atomicMax(&w->ext[node][k], (unsigned long long)__double_as_longlong(h[k]));
+      atomicMax(&w->ext[node][3], (unsigned long long)__double_as_longlong(far));
+    }
+  }
+}
+
+__global__ __launch_bounds__(kFitBlock) void top_write_kernel(const TopWork *__restrict__ w, double scale, float *__restrict__ nodes) {
+  const uint32_t node = blockIdx.x * kFitBlock + threadIdx.x;
+  if (node == 0 || node >= kTopSlices) return;
+  float *o = nodes + (size_t)kNodeFloats * node;
+  const double far = __longlong_as_double((long long)w->ext[node][3]);
+  const double margin = 4e-6 * far + 1e-7 * scale;   // as fit_obb_kernel / bvh_build.cpp
+  o[0] = w->cf[node][0]; o[1] = w->cf[node][1]; o[2] = w->cf[node][2];
+  for (int k = 0; k < 3; ++k) o[4 * k + 3] = nextafterf((float)(__longlong_as_double((long long)w->ext[node][k]) + margin), FLT_MAX);
+}
+
 }  // namespace
 
 // d_src: n finite points (float4, w = original index bits) in any order, d_src_nrm optional (same order).
@@ -261,8 +460,11 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
   unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
   uint32_t *d_order = nullptr, *d_order2 = nullptr, *d_mn = nullptr, *d_mx = nullptr;
   void *d_tmp = nullptr;
+  TopWork *d_top = nullptr;
   const uint32_t nn = (uint32_t)n;
   const unsigned nb = (unsigned)((n + 255) / 256);
+  const int bbox_rows = (int)std::max<size_t>(1, std::min<size_t>(kBboxMaxRows, n / (256 * 1024)));   // keep >= ~1024 blocks
+  const unsigned nb_bbox = (unsigned)((n + 256 * (size_t)bbox_rows - 1) / (256 * (size_t)bbox_rows));
   hipError_t e = hipMalloc((void **)d_nodes, n_nodes * kNodeFloats * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void **)d_axis2, n_nodes * sizeof(float4));
   if (e == hipSuccess) e = hipMalloc((void **)d_pts, sizeof(float4) * n);
@@ -282,7 +484,7 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
       const uint32_t cnt = 3u << level;
       hipLaunchKernelGGL(fill_u32_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_mn, cnt, 0xffffffffu);
       hipLaunchKernelGGL(fill_u32_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_mx, cnt, 0u);
-      hipLaunchKernelGGL(level_bbox_kernel, dim3(nb), dim3(256), 0, stream, d_src, d_order, nn, D, level, d_mn, d_mx);
+      hipLaunchKernelGGL(level_bbox_kernel, dim3(nb_bbox), dim3(256), 0, stream, d_src, d_order, nn, D, level, bbox_rows, d_mn, d_mx);
       hipLaunchKernelGGL(level_key_kernel, dim3(nb), dim3(256), 0, stream, d_src, d_order, nn, D, level, d_mn, d_mx, d_keys);
       size_t tb = tmp_bytes;
       e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_order, d_order2, n, 0, 32 + std::max(level, 1), stream);
@@ -292,7 +494,26 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
   if (e == hipSuccess) {
     hipLaunchKernelGGL(gather_points_kernel, dim3(nb), dim3(256), 0, stream, d_src, d_src_nrm, d_order, nn, *d_pts,
                        d_src_nrm ? *d_nrm : nullptr);
-    for (int level = 0; level <= D; ++level)
+    int first_level = 0;
+    if (n >= kTopMinPoints && D > kTopLevels) {   // first levels from 2^kTopLevels slices (see TopWork)
+      e = hipMalloc((void **)&d_top, sizeof(TopWork));
+      if (e == hipSuccess) e = hipMemsetAsync(d_top, 0, sizeof(TopWork), stream);
+      if (e == hipSuccess) e = hipMemsetAsync(d_top->lo, 0xff, sizeof d_top->lo, stream);
+      if (e == hipSuccess) {
+        const double px = 0.5 * ((double)bb_lo[0] + bb_hi[0]), py = 0.5 * ((double)bb_lo[1] + bb_hi[1]), pz = 0.5 * ((double)bb_lo[2] + bb_hi[2]);
+        float *nodes_f = reinterpret_cast<float *>(*d_nodes);
+        const unsigned per_node_blocks = kTopSlices / kFitBlock;
+        hipLaunchKernelGGL(top_moments_kernel, dim3(kTopSlices), dim3(kFitBlock), 0, stream, *d_pts, nn, D, px, py, pz, d_top);
+        hipLaunchKernelGGL(top_combine_kernel, dim3(1), dim3(1024), 0, stream, d_top);
+        hipLaunchKernelGGL(top_axes_kernel, dim3(per_node_blocks), dim3(kFitBlock), 0, stream, nn, D, d_top, nodes_f, *d_axis2);
+        hipLaunchKernelGGL(top_range_kernel, dim3(kTopSlices), dim3(kFitBlock), 0, stream, *d_pts, nn, D, d_top);
+        hipLaunchKernelGGL(top_centre_kernel, dim3(per_node_blocks), dim3(kFitBlock), 0, stream, d_top);
+        hipLaunchKernelGGL(top_extent_kernel, dim3(kTopSlices), dim3(kFitBlock), 0, stream, *d_pts, nn, D, d_top);
+        hipLaunchKernelGGL(top_write_kernel, dim3(per_node_blocks), dim3(kFitBlock), 0, stream, d_top, scale, nodes_f);
+        first_level = kTopLevels;
+      }
+    }
+    for (int level = first_level; level <= D && e == hipSuccess; ++level)
       hipLaunchKernelGGL(fit_obb_kernel, dim3(1u << level), dim3(kFitBlock), 0, stream, *d_pts, nn, D, level, scale,
                          reinterpret_cast<float *>(*d_nodes), *d_axis2);
     // node 0 is unused: give it the root box so stray reads are harmless
@@ -301,7 +522,7 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
     if (e == hipSuccess) e = hipMemcpyAsync(*d_axis2, *d_axis2 + 1, sizeof(float4), hipMemcpyDeviceToDevice, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
   }
-  for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_order, (void *)d_order2, (void *)d_mn, (void *)d_mx, d_tmp})
+  for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_order, (void *)d_order2, (void *)d_mn, (void *)d_mx, d_tmp, (void *)d_top})
     if (p) (void)hipFree(p);
   return e;
 }

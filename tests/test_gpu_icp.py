@@ -97,6 +97,30 @@ def test_nn_search_depth_cap_on_a_large_target(ctx):
     assert (idx == oi[:, 0]).mean() > 0.999
 
 
+@pytest.mark.parametrize("kind", ["surface", "volume", "flat_slab"])
+def test_nn_search_large_target_top_levels_fitted_from_slices(ctx, kind):
+    """Targets of >= 262144 points take the slice-based fit of the first ten tree levels (bvh_build_device.hip,
+    TopWork): near AND far queries (the latter are decided by the top boxes) must stay bit-exact."""
+    rng = np.random.default_rng(17)
+    n = 400_000
+    if kind == "surface":
+        tgt = synth.model_surface(n, 4)
+    elif kind == "volume":
+        tgt = rng.uniform(-0.3, 0.3, (n, 3)).astype(np.float32)
+    else:   # rank-deficient covariance at every level, far from the origin (raw-moment cancellation)
+        tgt = (np.concatenate([rng.uniform(-0.5, 0.5, (n, 2)), np.zeros((n, 1))], axis=1) + [10.0, -7.0, 3.0]).astype(np.float32)
+    lo, hi = tgt.min(0), tgt.max(0)
+    near = (tgt[rng.integers(0, n, 15_000)] + rng.normal(0, 2e-3, (15_000, 3))).astype(np.float32)
+    far = (rng.uniform(-1.0, 2.0, (15_000, 3)) * (hi - lo) + lo).astype(np.float32)
+    q = np.concatenate([near, far])
+    ct, cq = ctx.upload(tgt), ctx.upload(q)
+    ix = ctx.build_index(ct)
+    idx, d2 = ctx.nn(cq, ix)
+    oi, od, _ = oracle.KdTree(tgt).knn(q, 1)
+    np.testing.assert_array_equal(d2, od[:, 0])
+    assert (idx == oi[:, 0]).mean() > 0.999
+
+
 def test_icp_empty_and_all_nan_source(ctx):
     ope = load_pkg()
     tgt = synth.model_surface(2000, 1)
