@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void level_bbox_kernel(const float4 *__restric
   };
   const unsigned long long base = (unsigned long long)blockIdx.x * (256ull * (unsigned)rows);
   for (int r = 0; r < rows; ++r) {
-    const unsigned long long pp = base + (unsigned long long)r * 256ull + threadIdx.x;
+    // each wave walks its own contiguous 64*rows points, so consecutive rows mostly stay inside one node
+    const unsigned long long pp = base + (unsigned long long)(threadIdx.x >> 6) * (64ull * (unsigned)rows) + (unsigned long long)r * 64ull + (threadIdx.x & 63u);
     const bool active = pp < n;
     const uint32_t p = (uint32_t)pp;
     const uint32_t node = active ? (leaf_of(p, n, D) >> (D - level)) : kNone;
@@ -84,14 +85,58 @@ __global__ __launch_bounds__(256) void level_bbox_kernel(const float4 *__restric
       lx = fminf(lx, x); ly = fminf(ly, y); lz = fminf(lz, z);
       hx = fmaxf(hx, x); hy = fmaxf(hy, y); hz = fmaxf(hz, z);
     } else {
+      // several nodes in the wave (deep levels).  The lanes are sorted by node: segmented min / max scan over the
+      // runs of equal node, and only the last lane of a run issues atomics
       flush();
-      if (active) {
-        atomicMin(mn + 3 * node + 0, enc_f32(x)); atomicMin(mn + 3 * node + 1, enc_f32(y)); atomicMin(mn + 3 * node + 2, enc_f32(z));
-        atomicMax(mx + 3 * node + 0, enc_f32(x)); atomicMax(mx + 3 * node + 1, enc_f32(y)); atomicMax(mx + 3 * node + 2, enc_f32(z));
+      const uint32_t ln = threadIdx.x & 63u;
+      float l0 = x, l1 = y, l2 = z, h0 = x, h1 = y, h2 = z;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t on = (uint32_t)__shfl_up((int)node, off, 64);
+        const float a0 = __shfl_up(l0, off, 64), a1 = __shfl_up(l1, off, 64), a2 = __shfl_up(l2, off, 64);
+        const float b0 = __shfl_up(h0, off, 64), b1 = __shfl_up(h1, off, 64), b2 = __shfl_up(h2, off, 64);
+        if (ln >= (uint32_t)off && on == node) {
+          l0 = fminf(l0, a0); l1 = fminf(l1, a1); l2 = fminf(l2, a2);
+          h0 = fmaxf(h0, b0); h1 = fmaxf(h1, b1); h2 = fmaxf(h2, b2);
+        }
+      }
+      const uint32_t nxt = (uint32_t)__shfl_down((int)node, 1, 64);
+      if (active && (ln == 63u || nxt != node)) {
+        atomicMin(mn + 3 * node + 0, enc_f32(l0)); atomicMin(mn + 3 * node + 1, enc_f32(l1)); atomicMin(mn + 3 * node + 2, enc_f32(l2));
+        atomicMax(mx + 3 * node + 0, enc_f32(h0)); atomicMax(mx + 3 * node + 1, enc_f32(h1)); atomicMax(mx + 3 * node + 2, enc_f32(h2));
       }
     }
   }
-  flush();
+  // the runs still open at the end of the tile: merge the four waves' runs in LDS, one atomic set per distinct node
+  // (at the top levels that is one set per block instead of one per wave)
+  __shared__ uint32_t s_node[4];
+  __shared__ float s_box[4][6];
+  if (cur != kNone) {
+    for (int off = 32; off >= 1; off >>= 1) {
+      lx = fminf(lx, __shfl_xor(lx, off, 64)); ly = fminf(ly, __shfl_xor(ly, off, 64)); lz = fminf(lz, __shfl_xor(lz, off, 64));
+      hx = fmaxf(hx, __shfl_xor(hx, off, 64)); hy = fmaxf(hy, __shfl_xor(hy, off, 64)); hz = fmaxf(hz, __shfl_xor(hz, off, 64));
+    }
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+    const uint32_t wv = threadIdx.x >> 6;
+    s_node[wv] = cur;
+    s_box[wv][0] = lx; s_box[wv][1] = ly; s_box[wv][2] = lz; s_box[wv][3] = hx; s_box[wv][4] = hy; s_box[wv][5] = hz;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int a = 0; a < 4; ++a) {
+      const uint32_t nd = s_node[a];
+      if (nd == kNone) continue;
+      float b0 = s_box[a][0], b1 = s_box[a][1], b2 = s_box[a][2], b3 = s_box[a][3], b4 = s_box[a][4], b5 = s_box[a][5];
+      for (int c = a + 1; c < 4; ++c)
+        if (s_node[c] == nd) {
+          b0 = fminf(b0, s_box[c][0]); b1 = fminf(b1, s_box[c][1]); b2 = fminf(b2, s_box[c][2]);
+          b3 = fmaxf(b3, s_box[c][3]); b4 = fmaxf(b4, s_box[c][4]); b5 = fmaxf(b5, s_box[c][5]);
+          s_node[c] = kNone;
+        }
+      atomicMin(mn + 3 * nd + 0, enc_f32(b0)); atomicMin(mn + 3 * nd + 1, enc_f32(b1)); atomicMin(mn + 3 * nd + 2, enc_f32(b2));
+      atomicMax(mx + 3 * nd + 0, enc_f32(b3)); atomicMax(mx + 3 * nd + 1, enc_f32(b4)); atomicMax(mx + 3 * nd + 2, enc_f32(b5));
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void level_key_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, uint32_t n, int D,
@@ -131,14 +176,15 @@ __global__ __launch_bounds__(256) void gather_points_kernel(const float4 *__rest
 }
 
 // ---- block-wide reductions of a few doubles
-template <class Op>
-__device__ __forceinline__ double block_reduce(double v, double *s_tmp /*[kFitBlock/64]*/, Op op) {
+template <class Op, int BLOCK = kFitBlock>
+__device__ __forceinline__ double block_reduce(double v, double *s_tmp /*[BLOCK/64]*/, Op op) {
   for (int off = 32; off >= 1; off >>= 1) v = op(v, __shfl_xor(v, off, 64));
+  if (BLOCK == 64) return v;   // one wave: the butterfly left the result in every lane
   __syncthreads();   // s_tmp may still be read from the previous call
   if ((threadIdx.x & 63u) == 0u) s_tmp[threadIdx.x >> 6] = v;
   __syncthreads();
   double r = s_tmp[0];
-  for (int w = 1; w < kFitBlock / 64; ++w) r = op(r, s_tmp[w]);
+  for (int w = 1; w < BLOCK / 64; ++w) r = op(r, s_tmp[w]);
   return r;
 }
 struct OpAdd { __device__ double operator()(double a, double b) const { return a + b; } };
@@ -179,9 +225,11 @@ __device__ void jacobi_eig3_dev(double S[9], double V[9]) {
 }
 
 // One block per node of `level`: oriented box of the node's points (final order), written in the 48-byte layout.
-__global__ __launch_bounds__(kFitBlock) void fit_obb_kernel(const float4 *__restrict__ pts, uint32_t n, int D, int level, double scale,
+// BLOCK = 256 for the populous levels, 64 (one wave, no barriers in the reductions) where a node holds few points.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fit_obb_kernel(const float4 *__restrict__ pts, uint32_t n, int D, int level, double scale,
                                                             float *__restrict__ nodes, float4 *__restrict__ axis2) {
-  __shared__ double s_tmp[kFitBlock / 64];
+  __shared__ double s_tmp[BLOCK / 64];
   __shared__ double s_A[9];
   __shared__ float s_cf[3];
   const uint32_t j = blockIdx.x;
@@ -200,16 +248,16 @@ __global__ __launch_bounds__(kFitBlock) void fit_obb_kernel(const float4 *__rest
   }
   const double cnt = (double)(e - b);
   double sx = 0, sy = 0, sz = 0;
-  for (uint32_t i = b + threadIdx.x; i < e; i += kFitBlock) { const float4 p = pts[i]; sx += p.x; sy += p.y; sz += p.z; }
-  const double mx = block_reduce(sx, s_tmp, OpAdd()) / cnt, my = block_reduce(sy, s_tmp, OpAdd()) / cnt, mz = block_reduce(sz, s_tmp, OpAdd()) / cnt;
+  for (uint32_t i = b + threadIdx.x; i < e; i += BLOCK) { const float4 p = pts[i]; sx += p.x; sy += p.y; sz += p.z; }
+  const double mx = block_reduce<OpAdd, BLOCK>(sx, s_tmp, OpAdd()) / cnt, my = block_reduce<OpAdd, BLOCK>(sy, s_tmp, OpAdd()) / cnt, mz = block_reduce<OpAdd, BLOCK>(sz, s_tmp, OpAdd()) / cnt;
   double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-  for (uint32_t i = b + threadIdx.x; i < e; i += kFitBlock) {
+  for (uint32_t i = b + threadIdx.x; i < e; i += BLOCK) {
     const float4 p = pts[i];
     const double vx = p.x - mx, vy = p.y - my, vz = p.z - mz;
     c00 += vx * vx; c01 += vx * vy; c02 += vx * vz; c11 += vy * vy; c12 += vy * vz; c22 += vz * vz;
   }
-  c00 = block_reduce(c00, s_tmp, OpAdd()); c01 = block_reduce(c01, s_tmp, OpAdd()); c02 = block_reduce(c02, s_tmp, OpAdd());
-  c11 = block_reduce(c11, s_tmp, OpAdd()); c12 = block_reduce(c12, s_tmp, OpAdd()); c22 = block_reduce(c22, s_tmp, OpAdd());
+  c00 = block_reduce<OpAdd, BLOCK>(c00, s_tmp, OpAdd()); c01 = block_reduce<OpAdd, BLOCK>(c01, s_tmp, OpAdd()); c02 = block_reduce<OpAdd, BLOCK>(c02, s_tmp, OpAdd());
+  c11 = block_reduce<OpAdd, BLOCK>(c11, s_tmp, OpAdd()); c12 = block_reduce<OpAdd, BLOCK>(c12, s_tmp, OpAdd()); c22 = block_reduce<OpAdd, BLOCK>(c22, s_tmp, OpAdd());
   if (threadIdx.x == 0) {
     double C[9] = {c00, c01, c02, c01, c11, c12, c02, c12, c22}, V[9];
     jacobi_eig3_dev(C, V);
@@ -228,7 +276,7 @@ __global__ __launch_bounds__(kFitBlock) void fit_obb_kernel(const float4 *__rest
   double A[9];
   for (int k = 0; k < 9; ++k) A[k] = s_A[k];
   double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-  for (uint32_t i = b + threadIdx.x; i < e; i += kFitBlock) {
+  for (uint32_t i = b + threadIdx.x; i < e; i += BLOCK) {
     const float4 p = pts[i];
     for (int k = 0; k < 3; ++k) {
       const double t = A[3 * k] * p.x + A[3 * k + 1] * p.y + A[3 * k + 2] * p.z;
@@ -237,14 +285,14 @@ __global__ __launch_bounds__(kFitBlock) void fit_obb_kernel(const float4 *__rest
     }
   }
   double mid[3];
-  for (int k = 0; k < 3; ++k) mid[k] = 0.5 * (block_reduce(lo[k], s_tmp, OpMin()) + block_reduce(hi[k], s_tmp, OpMax()));
+  for (int k = 0; k < 3; ++k) mid[k] = 0.5 * (block_reduce<OpMin, BLOCK>(lo[k], s_tmp, OpMin()) + block_reduce<OpMax, BLOCK>(hi[k], s_tmp, OpMax()));
   if (threadIdx.x == 0)
     for (int d = 0; d < 3; ++d) s_cf[d] = (float)(mid[0] * A[d] + mid[1] * A[3 + d] + mid[2] * A[6 + d]);
   __syncthreads();
   const float cf0 = s_cf[0], cf1 = s_cf[1], cf2 = s_cf[2];
   // half extents about the ROUNDED centre, measured with the rounded axes
   double h[3] = {0, 0, 0}, far = 0;
-  for (uint32_t i = b + threadIdx.x; i < e; i += kFitBlock) {
+  for (uint32_t i = b + threadIdx.x; i < e; i += BLOCK) {
     const float4 p = pts[i];
     const double vx = (double)p.x - cf0, vy = (double)p.y - cf1, vz = (double)p.z - cf2;
     const double r = sqrt(vx * vx + vy * vy + vz * vz);
@@ -254,8 +302,8 @@ __global__ __launch_bounds__(kFitBlock) void fit_obb_kernel(const float4 *__rest
       h[k] = t > h[k] ? t : h[k];
     }
   }
-  far = block_reduce(far, s_tmp, OpMax());
-  for (int k = 0; k < 3; ++k) h[k] = block_reduce(h[k], s_tmp, OpMax());
+  far = block_reduce<OpMax, BLOCK>(far, s_tmp, OpMax());
+  for (int k = 0; k < 3; ++k) h[k] = block_reduce<OpMax, BLOCK>(h[k], s_tmp, OpMax());
   if (threadIdx.x == 0) {
     // margin covering the traversal's fp32 evaluation of the projections (relative 4e-6 of the offset, i.e.
     // > 10 fp32 ulps, and an absolute floor), exactly as bvh_build.cpp
@@ -513,9 +561,14 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
         first_level = kTopLevels;
       }
     }
-    for (int level = first_level; level <= D && e == hipSuccess; ++level)
-      hipLaunchKernelGGL(fit_obb_kernel, dim3(1u << level), dim3(kFitBlock), 0, stream, *d_pts, nn, D, level, scale,
-                         reinterpret_cast<float *>(*d_nodes), *d_axis2);
+    for (int level = first_level; level <= D && e == hipSuccess; ++level) {
+      if ((n >> level) > 512)
+        hipLaunchKernelGGL(fit_obb_kernel<kFitBlock>, dim3(1u << level), dim3(kFitBlock), 0, stream, *d_pts, nn, D, level, scale,
+                           reinterpret_cast<float *>(*d_nodes), *d_axis2);
+      else
+        hipLaunchKernelGGL(fit_obb_kernel<64>, dim3(1u << level), dim3(64), 0, stream, *d_pts, nn, D, level, scale,
+                           reinterpret_cast<float *>(*d_nodes), *d_axis2);
+    }
     // node 0 is unused: give it the root box so stray reads are harmless
     e = hipMemcpyAsync(*d_nodes, reinterpret_cast<float *>(*d_nodes) + kNodeFloats, kNodeFloats * sizeof(float), hipMemcpyDeviceToDevice,
                        stream);
