@@ -23,7 +23,8 @@ namespace ope {
 
 // MODE 0: 1-NN correspondences.  MODE 1: normal shooting over the k nearest (list in LDS, any k <= 32).
 // MODE 2: the same for k = 20, the value the reference uses (poseestimator.cpp:246, regmeshpcd.cpp:144): list in
-// registers, walk started at last iteration's leaf.
+// registers, walk started at last iteration's leaf.  MODE 3: the same for k = 10, the class default
+// (vPCL correspondence_estimation_normal_shooting_weighted.h:117).
 // NRM: source/target normals present (rejectors and/or normal shooting).
 // RECIP: reciprocal correspondences (vPCL impl/correspondence_estimation_mod.hpp:216-303): keep (i, j) only
 // if the nearest SOURCE point of target point j is i again.  The reference searches a kd-tree rebuilt
@@ -146,8 +147,8 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
         ok = ok && r.pos != kNoPos && !((double)r.best > max_d2) &&
              __float_as_int(srcix.pts[r.pos].w) == __float_as_int(s.w);
       }
-    } else if (MODE == 2) {
-      constexpr int K = 20;
+    } else if (MODE == 2 || MODE == 3) {
+      constexpr int K = (MODE == 3) ? 10 : 20;
       KnnRegVisitor<K> v;
       v.init(active);
       bvh_traverse(tgt, x, y, z, v, stk, BLOCK, active ? hint[i] : 0u);
@@ -894,6 +895,8 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
     else       { if (nrm) OPE_LAUNCH_ACC(0, true, false, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, false, kAccBlock, 0); }
   } else if (k_normal_shooting == 20) {
     OPE_LAUNCH_ACC(2, true, false, kKnnBlock, 0);
+  } else if (k_normal_shooting == 10) {
+    OPE_LAUNCH_ACC(3, true, false, kKnnBlock, 0);
   } else {
     OPE_LAUNCH_ACC(1, true, false, kKnnBlock, kKnnLdsBytes);
   }

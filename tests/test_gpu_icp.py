@@ -298,8 +298,10 @@ def test_icp_empty_target_and_missing_target_error_codes(ctx):
     assert e.value.code == ope.OPE_EEMPTY
 
 
-def test_icp_normal_shooting_and_rejectors_match_oracle(ctx):
-    """The configuration estimateFinePose actually runs (poseestimator.cpp:242-246,331-337)."""
+@pytest.mark.parametrize("k", [20, 10, 7])
+def test_icp_normal_shooting_and_rejectors_match_oracle(ctx, k):
+    """The configuration estimateFinePose actually runs (poseestimator.cpp:242-246,331-337): k = 20; k = 10 is the
+    class default (register lists for both), any other k takes the LDS list."""
     ope = load_pkg()
     rng = np.random.default_rng(3)
     u = rng.normal(size=(6000, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
@@ -307,7 +309,7 @@ def test_icp_normal_shooting_and_rejectors_match_oracle(ctx):
     P = (0.1 * u + c).astype(np.float32); nP = u.astype(np.float32)
     Tgt = rigid(1, -1, 2, [0.002, -0.001, 0.001])
     Q = apply(Tgt, P); nQ = (nP.astype(np.float64) @ Tgt[:3, :3].T).astype(np.float32)
-    kw = dict(max_iterations=15, corr_mode=1, k_normal_shooting=20, use_surface_normal_rej=1, surface_normal_thr=0.7,
+    kw = dict(max_iterations=15, corr_mode=1, k_normal_shooting=k, use_surface_normal_rej=1, surface_normal_thr=0.7,
               use_self_occluded_rej=1, self_occluded_thr=0.6)
     out, cs, ix = gpu_icp(ctx, P, Q, src_nrm=nP, tgt_nrm=nQ, **kw)
     ref = oracle.icp(P, Q, orc_params(acc_mode=1, transform_mode=1, **kw), src_nrm=nP, tgt_nrm=nQ)
