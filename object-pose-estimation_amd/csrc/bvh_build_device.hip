@@ -330,7 +330,7 @@ __global__ __launch_bounds__(BLOCK) void fit_obb_kernel(const float4 *__restrict
 // passes (axes may differ in the last bits, the boxes contain their points either way).
 constexpr int kTopLevels = 10;
 constexpr uint32_t kTopSlices = 1u << kTopLevels;
-constexpr size_t kTopMinPoints = 262144;
+constexpr size_t kTopMinPoints = 32768;
 
 __device__ __forceinline__ unsigned long long enc_f64(double d) {
   const unsigned long long b = (unsigned long long)__double_as_longlong(d);

@@ -97,12 +97,13 @@ def test_nn_search_depth_cap_on_a_large_target(ctx):
     assert (idx == oi[:, 0]).mean() > 0.999
 
 
-@pytest.mark.parametrize("kind", ["surface", "volume", "flat_slab"])
-def test_nn_search_large_target_top_levels_fitted_from_slices(ctx, kind):
-    """Targets of >= 262144 points take the slice-based fit of the first ten tree levels (bvh_build_device.hip,
-    TopWork): near AND far queries (the latter are decided by the top boxes) must stay bit-exact."""
+@pytest.mark.parametrize("kind,n", [("surface", 400_000), ("volume", 400_000), ("flat_slab", 400_000), ("surface", 33_000),
+                                    ("volume", 70_001)])
+def test_nn_search_large_target_top_levels_fitted_from_slices(ctx, kind, n):
+    """Targets of >= 32768 points take the slice-based fit of the first ten tree levels (bvh_build_device.hip,
+    TopWork): near AND far queries (the latter are decided by the top boxes) must stay bit-exact; 33 000 points give
+    slices of two leaves."""
     rng = np.random.default_rng(17)
-    n = 400_000
     if kind == "surface":
         tgt = synth.model_surface(n, 4)
     elif kind == "volume":
