@@ -21,8 +21,12 @@ def pytest_configure(config):
 
 
 def load_pkg():
-    """The package directory has a hyphen, so it is imported through importlib."""
-    return importlib.import_module(PKG_NAME)
+    """The package directory has a hyphen, so it is imported through importlib.  A checkout without the built
+    library (the .so files are git-ignored) gets it compiled here, exactly as __graft_entry__.build() does."""
+    pkg = importlib.import_module(PKG_NAME)
+    if not os.path.exists(pkg.LIB_PATH):
+        pkg.build_library()
+    return pkg
 
 
 @pytest.fixture(scope="session")
