@@ -218,26 +218,66 @@ __device__ __forceinline__ float obb_dist2_axes(const v4f n0, const v4f n1, cons
   const float t2 = fmaxf(fabsf(__fmaf_rn(dz, n3.z, __fmaf_rn(dy, n3.y, dx * n3.x))) - n2.w, 0.f);
   return __fmaf_rn(t2, t2, __fmaf_rn(t1, t1, t0 * t0)) * 0.999996f;
 }
-__device__ __forceinline__ float packet_box_bound(const BvhView &t, uint32_t node, float qx, float qy, float qz) {
-  v4f a, b, c;
-  load_node_scalar(t, node, a, b, c);
-  if (t.axis2 == nullptr) return obb_dist2(a, b, c, qx, qy, qz);
-  return obb_dist2_axes(a, b, c, ld16_scalar(t.axis2 + node), qx, qy, qz);
+// One node of the packet walk in SGPRs: the 48-byte record plus its stored third axis (the packet walk requires the
+// axis2 side array).  Byte offsets are formed in 32 bits (the arrays are far below 4 GB): one s_mul / s_lshl per node
+// instead of a 64-bit multiply-add chain -- scalar instructions take issue slots like vector ones.
+struct PacketNode { v4f a, b, c, x; };
+__device__ __forceinline__ void load_packet_node(const BvhView &t, uint32_t node, PacketNode &n) {
+  const float4 *o = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(t.nodes) + (size_t)(node * 48u));
+  const float4 *x = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(t.axis2) + (size_t)(node * 16u));
+  n.a = ld16_scalar(o); n.b = ld16_scalar(o + 1); n.c = ld16_scalar(o + 2);
+  n.x = ld16_scalar(x);
+}
+// the two children of `node`: 96 + 32 contiguous bytes
+__device__ __forceinline__ void load_packet_children(const BvhView &t, uint32_t node, PacketNode &l, PacketNode &r) {
+  const float4 *o = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(t.nodes) + (size_t)(node * 96u));
+  const float4 *x = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(t.axis2) + (size_t)(node * 32u));
+  l.a = ld16_scalar(o); l.b = ld16_scalar(o + 1); l.c = ld16_scalar(o + 2);
+  r.a = ld16_scalar(o + 3); r.b = ld16_scalar(o + 4); r.c = ld16_scalar(o + 5);
+  l.x = ld16_scalar(x); r.x = ld16_scalar(x + 1);
+}
+__device__ __forceinline__ float packet_node_bound(const PacketNode &n, float qx, float qy, float qz) {
+  return obb_dist2_axes(n.a, n.b, n.c, n.x, qx, qy, qz);
 }
 
+// Leaf scan of the packet walk: the leaf's points come through the scalar cache, four 16-byte fetches from ONE base
+// address in flight (immediate offsets, a single wait).  The last batch is moved back so that it ends at the leaf's
+// end instead of being range-checked per point: a point presented twice cannot change the result (d < best is
+// strict), and the order of first presentations is the same as in the per-lane scan.  The kernel is bound by
+// instruction issue (one slot per SIMD and 4 cycles, scalar instructions included), so per point this is 8 VALU for
+// the distance + compare + two selects, no scalar address arithmetic and no branch; `leaf` is set once per leaf.
 __device__ __forceinline__ void scan_leaf_uniform(const BvhView &t, uint32_t node, float qx, float qy, float qz, NearestVisitor &v) {
   const uint32_t j = node - (1u << t.depth);
   const uint32_t s = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
   const uint32_t e = (uint32_t)(((unsigned long long)(j + 1) * t.n) >> t.depth);
-  for (uint32_t i = s; i < e; i += 4) {
-    const uint32_t m = e - 1;
-    const v4f p0 = ld16_scalar(t.pts + i), p1 = ld16_scalar(t.pts + min(i + 1, m)), p2 = ld16_scalar(t.pts + min(i + 2, m)),
-              p3 = ld16_scalar(t.pts + min(i + 3, m));
-    v.point(sq_dist3(__fsub_rn(qx, p0.x), __fsub_rn(qy, p0.y), __fsub_rn(qz, p0.z)), p0, i, node);
-    if (i + 1 < e) v.point(sq_dist3(__fsub_rn(qx, p1.x), __fsub_rn(qy, p1.y), __fsub_rn(qz, p1.z)), p1, i + 1, node);
-    if (i + 2 < e) v.point(sq_dist3(__fsub_rn(qx, p2.x), __fsub_rn(qy, p2.y), __fsub_rn(qz, p2.z)), p2, i + 2, node);
-    if (i + 3 < e) v.point(sq_dist3(__fsub_rn(qx, p3.x), __fsub_rn(qy, p3.y), __fsub_rn(qz, p3.z)), p3, i + 3, node);
+  const uint32_t pos0 = v.pos;
+#define OPE_PKT_POINT(P, IDX)                                                                                  \
+  {                                                                                                            \
+    const float d_ = sq_dist3(__fsub_rn(qx, P.x), __fsub_rn(qy, P.y), __fsub_rn(qz, P.z));                     \
+    const bool c_ = d_ < v.best;                                                                               \
+    v.best = c_ ? d_ : v.best;                                                                                 \
+    v.pos = c_ ? (IDX) : v.pos;                                                                                \
   }
+  if (e - s >= 4u) {
+    for (uint32_t i = s;; i += 4) {
+      const bool last = i + 4u >= e;
+      const uint32_t b = last ? e - 4u : i;
+      const float4 *p = t.pts + b;
+      const v4f p0 = ld16_scalar(p), p1 = ld16_scalar(p + 1), p2 = ld16_scalar(p + 2), p3 = ld16_scalar(p + 3);
+      OPE_PKT_POINT(p0, b);
+      OPE_PKT_POINT(p1, b + 1u);
+      OPE_PKT_POINT(p2, b + 2u);
+      OPE_PKT_POINT(p3, b + 3u);
+      if (last) break;
+    }
+  } else {
+    for (uint32_t i = s; i < e; ++i) {
+      const v4f p0 = ld16_scalar(t.pts + i);
+      OPE_PKT_POINT(p0, i);
+    }
+  }
+#undef OPE_PKT_POINT
+  v.leaf = (v.pos != pos0) ? node : v.leaf;
 }
 
 __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, float qy, float qz, bool active, NearestVisitor &v,
@@ -245,7 +285,7 @@ __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, 
   const uint32_t leaf0 = 1u << t.depth;
   const int D = t.depth;
   const unsigned long long act = __ballot(active);
-  if (act == 0ull || __ballot(active && hint == 0u) != 0ull) return false;
+  if (t.axis2 == nullptr || act == 0ull || __ballot(active && hint == 0u) != 0ull) return false;
   // the distinct start leaves, scanned by every lane
   uint32_t seen[kPacketMaxLeaves];
   int nd = 0;
@@ -265,7 +305,10 @@ __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, 
   for (int k = 0; k < D; k += 2) {
     const uint32_t s0 = (anchor >> k) ^ 1u;
     const uint32_t s1 = (k + 1 < D) ? ((anchor >> (k + 1)) ^ 1u) : s0;
-    const float e0 = packet_box_bound(t, s0, qx, qy, qz), e1 = packet_box_bound(t, s1, qx, qy, qz);
+    PacketNode n0, n1;
+    load_packet_node(t, s0, n0);
+    load_packet_node(t, s1, n1);
+    const float e0 = packet_node_bound(n0, qx, qy, qz), e1 = packet_node_bound(n1, qx, qy, qz);
     stk[(D - k) * stk_stride] = e0;
     if (k + 1 < D) stk[(D - k - 1) * stk_stride] = e1;
     minb = fminf(minb, fminf(e0, e1));
@@ -289,8 +332,9 @@ __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, 
         if (!dup) scan_leaf_uniform(t, node, qx, qy, qz, v);
         break;
       }
-      const float d0 = packet_box_bound(t, 2 * node, qx, qy, qz);
-      const float d1 = packet_box_bound(t, 2 * node + 1, qx, qy, qz);
+      PacketNode cl, cr;
+      load_packet_children(t, node, cl, cr);
+      const float d0 = packet_node_bound(cl, qx, qy, qz), d1 = packet_node_bound(cr, qx, qy, qz);
       const unsigned long long n0 = __ballot(d0 < v.best), n1 = __ballot(d1 < v.best);
       if ((n0 | n1) == 0ull) break;
       // nearer child first by majority; the other one is parked if any lane wants it
