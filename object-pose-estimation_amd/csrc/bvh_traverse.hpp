@@ -66,6 +66,10 @@ __device__ __forceinline__ void load_node(const BvhView &t, uint32_t node, v4f &
   a = ld16(o); b = ld16(o + 1); c = ld16(o + 2);
 }
 
+// Visitors for which presenting a point a second time changes nothing (1-NN with a strict comparison) take a leaf scan
+// without per-point range checks; see the leaf branch of bvh_walk.
+template <class Visitor> struct leaf_rescan_is_harmless { static constexpr bool value = false; };
+
 template <class Visitor>
 __device__ __forceinline__ void bvh_walk(const BvhView &t, float qx, float qy, float qz, Visitor &v, float *stk, int stk_stride,
                                          uint32_t node, uint32_t trail, float minb, bool node_done);
@@ -141,11 +145,47 @@ __device__ __forceinline__ void bvh_walk(const BvhView &t, float qx, float qy, f
       const uint32_t j = node - leaf0;
       const uint32_t s = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
       const uint32_t e = (uint32_t)(((unsigned long long)(j + 1) * t.n) >> t.depth);
+      bool scanned = false;
+      if constexpr (leaf_rescan_is_harmless<Visitor>::value) {
+        // The kernel is bound by instruction issue, so the scan is written for few instructions: eight 16-byte loads
+        // from ONE per-lane base address (immediate offsets), the last batch moved back so that it ends at the leaf's
+        // end instead of clamping indices and guarding every point (a point seen twice cannot win twice: d < best is
+        // strict, and first presentations keep their order), compare + two selects per point, `leaf` set once.
+        if (e - s >= 8u) {
+          scanned = true;
+          const uint32_t pos0 = v.pos;
+#define OPE_LEAF_POINT_SEL(P, IDX)                                                                       \
+  {                                                                                                      \
+    const float d_ = sq_dist3(__fsub_rn(qx, P.x), __fsub_rn(qy, P.y), __fsub_rn(qz, P.z));               \
+    const bool c_ = d_ < v.best;                                                                         \
+    v.best = c_ ? d_ : v.best;                                                                           \
+    v.pos = c_ ? (IDX) : v.pos;                                                                          \
+  }
+          for (uint32_t i = s;; i += 8) {
+            const bool last = i + 8u >= e;
+            const uint32_t b = last ? e - 8u : i;
+            const float4 *p = t.pts + b;
+            const v4f p0 = ld16(p), p1 = ld16(p + 1), p2 = ld16(p + 2), p3 = ld16(p + 3), p4 = ld16(p + 4), p5 = ld16(p + 5),
+                      p6 = ld16(p + 6), p7 = ld16(p + 7);
+            OPE_LEAF_POINT_SEL(p0, b);
+            OPE_LEAF_POINT_SEL(p1, b + 1u);
+            OPE_LEAF_POINT_SEL(p2, b + 2u);
+            OPE_LEAF_POINT_SEL(p3, b + 3u);
+            OPE_LEAF_POINT_SEL(p4, b + 4u);
+            OPE_LEAF_POINT_SEL(p5, b + 5u);
+            OPE_LEAF_POINT_SEL(p6, b + 6u);
+            OPE_LEAF_POINT_SEL(p7, b + 7u);
+            if (last) break;
+          }
+#undef OPE_LEAF_POINT_SEL
+          v.leaf = (v.pos != pos0) ? node : v.leaf;
+        }
+      }
       // eight independent 16-byte loads in flight per batch (load indices clamped to the leaf, visitor
       // calls guarded, so every point is presented exactly once): a default 8-point bucket is ONE trip
 #define OPE_LEAF_POINT(P, IDX) \
   v.point(sq_dist3(__fsub_rn(qx, P.x), __fsub_rn(qy, P.y), __fsub_rn(qz, P.z)), P, IDX, node)
-      for (uint32_t i = s; i < e; i += 8) {
+      for (uint32_t i = s; !scanned && i < e; i += 8) {
         const uint32_t m = e - 1;
         const v4f p0 = ld16(t.pts + i), p1 = ld16(t.pts + min(i + 1, m)), p2 = ld16(t.pts + min(i + 2, m)),
                   p3 = ld16(t.pts + min(i + 3, m)), p4 = ld16(t.pts + min(i + 4, m)), p5 = ld16(t.pts + min(i + 5, m)),
@@ -186,6 +226,8 @@ struct NearestVisitor {
   }
   __device__ __forceinline__ void on_node() {}
 };
+
+template <> struct leaf_rescan_is_harmless<NearestVisitor> { static constexpr bool value = true; };
 
 // ------------------------------------------------------------------------------------------
 // Packet traversal: ONE walk for the 64 queries of a coherent chunk.  Morton-adjacent surface points were matched to
