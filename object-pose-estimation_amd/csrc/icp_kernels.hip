@@ -21,6 +21,8 @@
 
 namespace ope {
 
+typedef const __attribute__((address_space(3))) float *lds_cfloat_ptr;   // a pointer that stays an LDS pointer
+
 // MODE 0: 1-NN correspondences.  MODE 1: normal shooting over the k nearest (list in LDS, any k <= 32).
 // MODE 2: the same for k = 20, the value the reference uses (poseestimator.cpp:246, regmeshpcd.cpp:144): list in
 // registers, walk started at last iteration's leaf.  MODE 3: the same for k = 10, the class default
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
 
   // Per-run constants live in LDS and are re-read where they are used (through a pointer the optimiser cannot see
   // through): held in registers across the walk they were spilled to scratch, 13 dwords per lane and launch.
-  __shared__ float s_const[16];   // F rows [0..11], pivot [12..14], best0 [15]
+  __shared__ __attribute__((aligned(16))) float s_const[16];   // F rows [0..11], pivot [12..14], best0 [15]
   const double max_d2 = st->max_d2;
   // With a finite setMaxCorrespondenceDistance the 1-NN search only has to see points that can survive the
   // threshold test (correspondence_estimation_mod.hpp:171 rejects d2 > max_d2 afterwards anyway): start from the
@@ -98,7 +100,9 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     const uint32_t i = oct ? (base + (slot & 7u) * 8u + (lane_id >> 3)) : (base + lane_id);
     const bool active = i < src.n_valid;
     const bool owner = active && (!oct || (lane_id & 7u) == 0u);  // the one lane that reports a query
-    const float *cst = s_const;
+    // (the pointer keeps its LDS address space: through a generic pointer these became flat_loads, which take the
+    // vector-memory path and wait on both counters)
+    lds_cfloat_ptr cst = (lds_cfloat_ptr)s_const;
     asm volatile("" : "+v"(cst));   // keep the constants' loads here, inside the chunk loop
     float F[12];
 #pragma unroll
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       // fp64 terms: differences and products of fp32 values are exact in fp64, so the 17 sums do not
       // depend (beyond 1e-16) on how queries are grouped into lanes, chunks, waves or ranks
       const float4 t = tgt.pts[ok ? pos : 0];
-      const float *cs2 = s_const;
+      lds_cfloat_ptr cs2 = (lds_cfloat_ptr)s_const;
       asm volatile("" : "+v"(cs2));
       const float psx = cs2[12], psy = cs2[13], psz = cs2[14];
       const double sx = (double)x - (double)psx, sy = (double)y - (double)psy, sz = (double)z - (double)psz;
