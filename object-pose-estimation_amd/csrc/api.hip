@@ -6,6 +6,8 @@
 #include <limits>
 #include <numeric>
 
+#include <thread>
+
 #include "ope_internal.hpp"
 
 namespace ope {
@@ -202,14 +204,35 @@ int ope_cloud_upload(ope_ctx *ctx, const void *base, size_t n, size_t stride_byt
   c->h_xyz.resize(n * 3);
   const unsigned char *b = static_cast<const unsigned char *>(base);
   // one pass: gather xyz out of the caller's structs and take the bounding box of the finite points
+  // (large clouds: a few host threads, each over a contiguous range; min / max / count merge exactly)
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   size_t nv = 0;
-  for (size_t i = 0; i < n; ++i) {
-    float *p = &c->h_xyz[3 * i];
-    std::memcpy(p, b + i * stride_bytes + xyz_off, 12);
-    if (!finite3(p)) continue;
-    ++nv;
-    for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], p[d]); hi[d] = std::max(hi[d], p[d]); }
+  {
+    struct Part { float lo[3], hi[3]; size_t nv; };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = n >= ((size_t)1 << 18) ? std::min(8u, hw) : 1u;
+    std::vector<Part> parts(nt);
+    float *dst = c->h_xyz.data();
+    auto work = [&](unsigned t) {
+      Part pt{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}, 0};
+      const size_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
+      for (size_t i = i0; i < i1; ++i) {
+        float *p = dst + 3 * i;
+        std::memcpy(p, b + i * stride_bytes + xyz_off, 12);
+        if (!finite3(p)) continue;
+        ++pt.nv;
+        for (int d = 0; d < 3; ++d) { pt.lo[d] = std::min(pt.lo[d], p[d]); pt.hi[d] = std::max(pt.hi[d], p[d]); }
+      }
+      parts[t] = pt;
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    for (const Part &pt : parts) {
+      nv += pt.nv;
+      for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], pt.lo[d]); hi[d] = std::max(hi[d], pt.hi[d]); }
+    }
   }
   c->n_valid = nv;
   if (nv == 0) { for (int d = 0; d < 3; ++d) lo[d] = hi[d] = 0.f; }
