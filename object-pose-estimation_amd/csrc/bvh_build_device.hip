@@ -7,7 +7,7 @@
 //
 //   for every level l < D:   per-node bounding box (wave-reduced atomics on order-preserving integer images of
 //                            the floats) -> split axis = widest extent -> ONE rocPRIM radix sort of
-//                            (node << 32 | coordinate along the node's axis): every node's range is sorted in
+//                            (node << 16 | 16-bit position along the node's axis): every node's range is sorted in
 //                            place, so its lower half is its left child.  D sorts of n keys in total.
 //   then, level by level:    one block per node (first ten levels of large clouds: see TopWork) fits the oriented box: mean and covariance in fp64, cyclic
 //                            Jacobi, mid-range centre along the rounded axes, half extents about the ROUNDED
@@ -153,7 +153,14 @@ __global__ __launch_bounds__(256) void level_key_kernel(const float4 *__restrict
   if (ez > e) dim = 2;
   const float4 q = pts[order[p]];
   const float c = dim == 0 ? q.x : (dim == 1 ? q.y : q.z);
-  keys[p] = ((unsigned long long)node << 32) | (unsigned long long)enc_f32(c);
+  // 16-bit position inside the node's extent along its split axis instead of the full 32-bit coordinate: a third fewer
+  // radix passes per level.  Points closer than extent / 65536 keep their previous order (the sort is stable); the
+  // split is by rank either way, and the search is exact for any tree whose boxes contain their points.
+  const float lo_d = dec_f32(mn[3 * node + dim]);
+  const float ext = dim == 0 ? ex : (dim == 1 ? ey : ez);
+  const float tq = ext > 0.f ? (c - lo_d) * (65535.0f / ext) : 0.f;
+  const uint32_t qk = (uint32_t)fminf(fmaxf(tq, 0.f), 65535.0f);
+  keys[p] = ((unsigned long long)node << 16) | (unsigned long long)qk;
 }
 
 __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *v, uint32_t n, uint32_t value) {
@@ -535,7 +542,7 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
       hipLaunchKernelGGL(level_bbox_kernel, dim3(nb_bbox), dim3(256), 0, stream, d_src, d_order, nn, D, level, bbox_rows, d_mn, d_mx);
       hipLaunchKernelGGL(level_key_kernel, dim3(nb), dim3(256), 0, stream, d_src, d_order, nn, D, level, d_mn, d_mx, d_keys);
       size_t tb = tmp_bytes;
-      e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_order, d_order2, n, 0, 32 + std::max(level, 1), stream);
+      e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_order, d_order2, n, 0, 16 + std::max(level, 1), stream);
       std::swap(d_order, d_order2);
     }
   }
