@@ -360,7 +360,8 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
   for (int d = 0; d < 3; ++d) ix->pivot[d] = 0.5 * ((double)target->bb_lo[d] + (double)target->bb_hi[d]);
   hipError_t e = hipMalloc((void **)&ix->d_nodes, sizeof(float) * hb.nodes.size());
   if (e == hipSuccess) e = hipMemcpy(ix->d_nodes, hb.nodes.data(), sizeof(float) * hb.nodes.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMalloc((void **)&ix->d_pts, sizeof(float4) * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&ix->d_pts, sizeof(float4) * (n + kPtsPad));
+  if (e == hipSuccess) e = hipMemset(ix->d_pts + n, 0, sizeof(float4) * kPtsPad);
   if (e == hipSuccess) e = hipMemcpy(ix->d_pts, hb.pts4.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
   if (e == hipSuccess && !hb.nrm4.empty()) {
     e = hipMalloc((void **)&ix->d_nrm, sizeof(float4) * n);

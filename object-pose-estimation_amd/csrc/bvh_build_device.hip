@@ -522,7 +522,8 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
   const unsigned nb_bbox = (unsigned)((n + 256 * (size_t)bbox_rows - 1) / (256 * (size_t)bbox_rows));
   hipError_t e = hipMalloc((void **)d_nodes, n_nodes * kNodeFloats * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void **)d_axis2, n_nodes * sizeof(float4));
-  if (e == hipSuccess) e = hipMalloc((void **)d_pts, sizeof(float4) * n);
+  if (e == hipSuccess) e = hipMalloc((void **)d_pts, sizeof(float4) * (n + kPtsPad));
+  if (e == hipSuccess) e = hipMemsetAsync(*d_pts + n, 0, sizeof(float4) * kPtsPad, stream);
   if (e == hipSuccess && d_src_nrm) e = hipMalloc((void **)d_nrm, sizeof(float4) * n);
   if (e == hipSuccess) e = hipMalloc((void **)&d_keys, 8 * n);
   if (e == hipSuccess) e = hipMalloc((void **)&d_keys2, 8 * n);

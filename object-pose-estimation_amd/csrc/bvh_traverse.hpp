@@ -181,15 +181,16 @@ __device__ __forceinline__ void bvh_walk(const BvhView &t, float qx, float qy, f
           v.leaf = (v.pos != pos0) ? node : v.leaf;
         }
       }
-      // eight independent 16-byte loads in flight per batch (load indices clamped to the leaf, visitor
-      // calls guarded, so every point is presented exactly once): a default 8-point bucket is ONE trip
+      // eight independent 16-byte loads in flight per batch (visitor calls guarded, so every point is presented
+      // exactly once): a default 8-point bucket is ONE trip
 #define OPE_LEAF_POINT(P, IDX) \
   v.point(sq_dist3(__fsub_rn(qx, P.x), __fsub_rn(qy, P.y), __fsub_rn(qz, P.z)), P, IDX, node)
       for (uint32_t i = s; !scanned && i < e; i += 8) {
-        const uint32_t m = e - 1;
-        const v4f p0 = ld16(t.pts + i), p1 = ld16(t.pts + min(i + 1, m)), p2 = ld16(t.pts + min(i + 2, m)),
-                  p3 = ld16(t.pts + min(i + 3, m)), p4 = ld16(t.pts + min(i + 4, m)), p5 = ld16(t.pts + min(i + 5, m)),
-                  p6 = ld16(t.pts + min(i + 6, m)), p7 = ld16(t.pts + min(i + 7, m));
+        // one base address, immediate offsets; a batch may run past the leaf (the visitor calls are guarded) and, at
+        // the last leaf, up to seven entries past the points: the index allocates kPtsPad zeroed entries there
+        const float4 *pb = t.pts + i;
+        const v4f p0 = ld16(pb), p1 = ld16(pb + 1), p2 = ld16(pb + 2), p3 = ld16(pb + 3), p4 = ld16(pb + 4), p5 = ld16(pb + 5),
+                  p6 = ld16(pb + 6), p7 = ld16(pb + 7);
         OPE_LEAF_POINT(p0, i);
         if (i + 1 < e) OPE_LEAF_POINT(p1, i + 1);
         if (i + 2 < e) OPE_LEAF_POINT(p2, i + 2);

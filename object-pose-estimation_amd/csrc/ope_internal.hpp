@@ -25,6 +25,7 @@ namespace ope {
 // ---------------------------------------------------------------------------
 constexpr int kNodeFloats = 12;
 constexpr int kMaxDepth = 20;  // one pending-bound LDS slot per level and lane (16 M points at 16 per leaf)
+constexpr size_t kPtsPad = 8;    // float4 entries allocated (zeroed) past an index's points: leaf scans fetch whole batches
 
 struct BvhView {
   const float4 *nodes;  // (2^(D+1)) * 3 float4
