@@ -102,7 +102,9 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   // packet walks for coherent chunks pay off when the launch fills the GPU (C3: 195 -> 184 us); on an underfilled
   // one (a 1/8 shard, C2) the longer dependent chain of a packet costs more than its gathers save (77 -> 88 us)
   static const bool no_packet = getenv("OPE_NO_PACKET") != nullptr;  // developer A/B switch
-  const bool packet = !no_packet && nch > (uint32_t)ctx->n_cu * 4u * (uint32_t)kAccWavesPerSimd;
+  static const int packet_min_env = [] { const char *e = getenv("OPE_PACKET_MIN_CHUNKS"); return e ? atoi(e) : -1; }();  // developer sweep
+  const uint32_t packet_min = packet_min_env >= 0 ? (uint32_t)packet_min_env : (uint32_t)ctx->n_cu * 4u * (uint32_t)kAccWavesPerSimd;
+  const bool packet = !no_packet && nch > packet_min;
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
                         recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
                         ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr);
