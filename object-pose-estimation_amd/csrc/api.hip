@@ -77,7 +77,8 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   static const bool no_plan = getenv("OPE_NO_PLAN") != nullptr;  // developer A/B switch
   const int it_done = ctx->acc_launches++;
   const uint32_t nch = (uint32_t)((ctx->run_src->n_valid + 63) / 64);
-  if (!no_plan && nch > 1 && it_done >= 1 && (((it_done & (it_done - 1)) == 0 && it_done <= 32) || it_done % 32 == 0)) {
+  static const int plan_every = [] { const char *e = getenv("OPE_PLAN_EVERY"); return e ? std::max(1, atoi(e)) : 32; }();  // developer sweep
+  if (!no_plan && nch > 1 && it_done >= 1 && (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0)) {
     size_t tb = ctx->plan_tmp_bytes;
     if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
                    ctx->d_plan_tmp, tb) != 0)
