@@ -100,7 +100,7 @@ def main() -> int:
     ix = ctx.build_index(ctx.upload(model), leaf_size=args.leaf or None)
     sums = None
     if use_torch_comm:
-        sums = torch.zeros(17, dtype=torch.float64, device="cuda")
+        sums = torch.zeros(ope.NUM_SUMS, dtype=torch.float64, device="cuda")   # SVD estimator: exactly OPE_NUM_SUMS doubles are used
         ctx.icp_set_sums_buffer(sums.data_ptr())
     elif launched:
         ok = torch.ones(1, device="cuda")
@@ -119,7 +119,7 @@ def main() -> int:
                 pass
             args.comm = "torch"
             use_torch_comm = True
-            sums = torch.zeros(17, dtype=torch.float64, device="cuda")
+            sums = torch.zeros(ope.NUM_SUMS, dtype=torch.float64, device="cuda")   # SVD estimator: exactly OPE_NUM_SUMS doubles are used
             ctx.icp_set_sums_buffer(sums.data_ptr())
 
     # ---- coarse stage (the "FPFH init" of config C3), as estimateCoarsePose runs it (poseestimator.cpp:16-73):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OPE_ABI_VERSION 1
+#define OPE_ABI_VERSION 2
 
 enum {
   OPE_OK = 0,
@@ -58,6 +58,10 @@ void ope_ctx_destroy(ope_ctx *ctx);
  * NULL restores the context's own stream. */
 int ope_ctx_set_stream(ope_ctx *ctx, void *hip_stream);
 int ope_ctx_sync(ope_ctx *ctx);
+/* Named roctx ranges (rocprofv3 --marker-trace) around the host side of the path: icp_iter {nn, reduce}, normals,
+ * fpfh_spfh, fpfh_weight, sacia, index_build, uniform_sampling.  Off by default.  The reference's own instrumentation is
+ * pcl::ScopeTime("Initial Alignment" / "Final Alignment") (poseestimator.cpp:61,349): the facade keeps those names. */
+int ope_ctx_set_tracing(ope_ctx *ctx, int on);
 const char *ope_last_error(const ope_ctx *ctx);
 
 /* ---------------- clouds ---------------- */
@@ -142,6 +146,11 @@ typedef struct {
   /* host polling period for the on-device convergence flag (iterations); 0 = only at the end */
   int check_every;
   int estimator; /* OPE_EST_* */
+  /* 0 (default): every block adds its partial sums into the run's sums with fp64 atomics: the addition order, and with
+   * it the last bit of the sums (~1e-9 in the final transform after 100 iterations), varies from run to run.
+   * 1: one row of partial sums per block and a fixed-tree reduction: bit-reproducible for a launch geometry, one more
+   * kernel boundary per iteration. */
+  int deterministic_sums;
 } ope_icp_params;
 
 typedef struct {
@@ -171,11 +180,12 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
                   const ope_icp_params *params);
 int ope_icp_accumulate(ope_ctx *ctx);
 /* Device pointer to the fp64 sums {n, Σs[3], Σt[3], Σ t sᵀ[9], Σd²} (about the index pivot), followed for the
- * point-to-plane estimator by 21 + 6 normal-equation sums: all-reduce OPE_NUM_SUMS (or OPE_NUM_SUMS_MAX) doubles. */
+ * point-to-plane estimator by 21 + 6 normal-equation sums: all-reduce OPE_NUM_SUMS doubles (OPE_NUM_SUMS_MAX with
+ * OPE_EST_POINT_TO_PLANE_LLS); the library reads and writes exactly that many. */
 void *ope_icp_sums_device(ope_ctx *ctx);
 int ope_icp_update(ope_ctx *ctx);
-/* Use a caller-owned device buffer of OPE_NUM_SUMS_MAX doubles for the sums (e.g. a torch tensor that
- * torch.distributed all-reduces); NULL restores the internal buffer. */
+/* Use a caller-owned device buffer for the sums (e.g. a torch tensor that torch.distributed all-reduces):
+ * OPE_NUM_SUMS doubles, OPE_NUM_SUMS_MAX for runs with OPE_EST_POINT_TO_PLANE_LLS; NULL restores the internal buffer. */
 int ope_icp_set_sums_buffer(ope_ctx *ctx, void *device_ptr);
 /* Enqueue n whole iterations (accumulate -> [RCCL all-reduce if ope_comm_init_rank was called] -> update)
  * without synchronising the host.  The accumulate launches ADD into the sums and ope_icp_update leaves them at
@@ -196,7 +206,8 @@ int ope_icp_profile(ope_ctx *ctx, int max_launches);
 int ope_icp_profile_read(ope_ctx *ctx, double *total_ms, int *n_launches);
 
 /* Last iteration's post-rejection correspondences, compacted in query order
- * (pcl::Correspondences: index_query, index_match, distance = squared L2). */
+ * (pcl::Correspondences: index_query, index_match, distance = squared L2).  OPE_ESTATE when there is no finished
+ * run on this context, or its source cloud has been freed since. */
 int ope_icp_correspondences(ope_ctx *ctx, int32_t *index_query, int32_t *index_match, float *distance, size_t cap,
                             size_t *n);
 
@@ -251,6 +262,13 @@ int ope_pass_through(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], co
  * not carried).  out_xyz has room for 3 floats per finite input point.  OPE_ERANGE where PCL would warn
  * "Leaf size is too small for the input dataset" and return the input unchanged. */
 int ope_voxel_grid(ope_ctx *ctx, const ope_cloud *cloud, const float leaf[3], float *out_xyz, size_t *n_out);
+/* pcl::StatisticalOutlierRemoval::filter with setMeanK(mean_k) and setStddevMulThresh(stddev_mul)
+ * (ProcessingPcd::getOutlierRemove, DetectAndLocalize processingpcd.cpp:62-77: meanK 30): a point is removed iff its mean
+ * distance to its mean_k nearest neighbours exceeds mean + stddev_mul * stddev over the cloud.  ORIGINAL indices of the
+ * inliers, ascending (out_idx has room for every point); non-finite points pass, as in PCL.  1 <= mean_k <= 31.
+ * out_mean_dist (optional, n floats, ORIGINAL order): the per-point mean distances. */
+int ope_statistical_outlier_removal(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double stddev_mul, int32_t *out_idx,
+                                    size_t *n_out, float *out_mean_dist);
 
 typedef struct {
   int max_iterations;      /* 400  (poseestimator.cpp:55) */

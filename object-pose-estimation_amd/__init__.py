@@ -65,6 +65,7 @@ class IcpParams(C.Structure):
         ("failure_after_max_iter", C.c_int),
         ("check_every", C.c_int),
         ("estimator", C.c_int),
+        ("deterministic_sums", C.c_int),
     ]
 
 
@@ -107,6 +108,7 @@ ABI = [
     ("ope_ctx_destroy", None, [_vp]),
     ("ope_ctx_set_stream", C.c_int, [_vp, _vp]),
     ("ope_ctx_sync", C.c_int, [_vp]),
+    ("ope_ctx_set_tracing", C.c_int, [_vp, C.c_int]),
     ("ope_last_error", C.c_char_p, [_vp]),
     ("ope_cloud_upload", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_ssize_t, C.POINTER(_vp)]),
     ("ope_cloud_set_normals", C.c_int, [_vp, _vp, _fp]),
@@ -146,6 +148,7 @@ ABI = [
     ("ope_remove_nan", C.c_int, [_vp, _vp, _ip, C.POINTER(C.c_size_t)]),
     ("ope_pass_through", C.c_int, [_vp, _vp, _fp, _fp, _ip, C.POINTER(C.c_size_t)]),
     ("ope_voxel_grid", C.c_int, [_vp, _vp, _fp, _fp, C.POINTER(C.c_size_t)]),
+    ("ope_statistical_outlier_removal", C.c_int, [_vp, _vp, C.c_int, C.c_double, _ip, C.POINTER(C.c_size_t), _fp]),
     ("ope_sacia_default_params", None, [C.POINTER(SaciaParams)]),
     ("ope_sacia", C.c_int, [_vp, _vp, _fp, _vp, _vp, _fp, C.POINTER(SaciaParams), _ip, _fp, _dp, _ip]),
 ]
@@ -246,6 +249,9 @@ class Context:
 
     def sync(self):
         self._chk(lib().ope_ctx_sync(self.h))
+
+    def set_tracing(self, on: bool):
+        self._chk(lib().ope_ctx_set_tracing(self.h, int(on)))
 
     # ---- clouds / index
     def upload(self, xyz, normals=None) -> "Cloud":
@@ -452,6 +458,14 @@ class Context:
         n = C.c_size_t(0)
         self._chk(lib().ope_voxel_grid(self.h, cloud.h, _p(lf, _fp), _p(out, _fp), C.byref(n)))
         return out[: n.value].copy()
+
+    def statistical_outlier_removal(self, cloud: "Cloud", mean_k: int = 30, stddev_mul: float = 1.0, return_distances: bool = False):
+        """pcl::StatisticalOutlierRemoval (ProcessingPcd::getOutlierRemove): original indices of the inliers, ascending."""
+        out = np.empty(max(cloud.n, 1), np.int32)
+        dist = np.empty(max(cloud.n, 1), np.float32) if return_distances else None
+        n = C.c_size_t(0)
+        self._chk(lib().ope_statistical_outlier_removal(self.h, cloud.h, mean_k, stddev_mul, _p(out, _ip), C.byref(n), _p(dist, _fp)))
+        return (out[: n.value].copy(), dist[: cloud.n].copy()) if return_distances else out[: n.value].copy()
 
     def sacia(self, src: "Cloud", src_feat, tgt: "Cloud", tgt_index: "Index", tgt_feat, params: SaciaParams | None = None,
               forced_samples=None):

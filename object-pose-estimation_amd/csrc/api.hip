@@ -23,7 +23,7 @@ hipError_t morton_order_device(hipStream_t, const float *, size_t, const float[3
 hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t, int, const float[3], const float[3], int *, float4 **,
                             float4 **, float4 **, float4 **);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
-void launch_icp_update(hipStream_t, IcpState *, double *);
+void launch_icp_update(hipStream_t, IcpState *, double *, int);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
 void launch_knn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int, int32_t *, float *);
 void launch_fitness(hipStream_t, int, const CloudView &, const BvhView &, const float *, double, double *);
@@ -32,6 +32,14 @@ void launch_pairs_svd(hipStream_t, const float *, const float *, uint32_t, doubl
 int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count);
 
 static thread_local std::string g_global_err;
+
+// Developer A/B switches and sweeps (tools/*.py) read the environment only in builds made with -DOPE_DEVELOPER
+// (`make DEVELOPER=1`); the product library has no environment-dependent behaviour on its launch path.
+#ifdef OPE_DEVELOPER
+static const char *dev_env(const char *name) { return getenv(name); }
+#else
+static const char *dev_env(const char *) { return nullptr; }
+#endif
 
 int set_err(ope_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->err = msg;
@@ -57,6 +65,17 @@ static int ensure_scratch(ope_ctx *ctx, size_t bytes) {
   return OPE_OK;
 }
 
+// number of fp64 sums of the run in progress: 17, or 44 with the point-to-plane estimator; nothing past them is touched
+static int run_nsums(const ope_ctx *ctx) { return ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LLS ? kNumSumsMax : kNumSums; }
+
+// A run that cannot continue: the next begin starts from a clean slate (align strength sizes included).
+static void abort_run(ope_ctx *ctx) {
+  ctx->run_active = false;
+  ctx->run_src = nullptr;
+  ctx->run_tgt = nullptr;
+  ctx->n_src_total = ctx->n_tgt_total = 0;
+}
+
 static double *sums_ptr(ope_ctx *ctx) {
   if (ctx->d_sums_ext) return ctx->d_sums_ext;
   return reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(ctx->d_state) + offsetof(IcpState, S));
@@ -67,17 +86,14 @@ static double *sums_ptr(ope_ctx *ctx) {
 // (fp64 atomics; the update kernel leaves them at zero again), which saves the reduction kernel and one kernel boundary
 // per iteration (C3: 181 -> 174 us per step) — the addition order, and with it the last bit of the sums, varies from
 // run to run.  OPE_DETERMINISTIC_SUMS=1 keeps one row per block and reduces the rows in a fixed tree instead.
-static bool atomic_sums_default() {
-  static const bool det = getenv("OPE_DETERMINISTIC_SUMS") != nullptr;
-  return !det;
-}
+static bool atomic_sums(const ope_ctx *ctx) { return ctx->run_params.deterministic_sums == 0; }
 
 static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   // re-sort the chunks by the cost they measured: after launches 1, 2, 4, ..., 32 and then every 32
-  static const bool no_plan = getenv("OPE_NO_PLAN") != nullptr;  // developer A/B switch
+  static const bool no_plan = dev_env("OPE_NO_PLAN") != nullptr;  // developer A/B switch
   const int it_done = ctx->acc_launches++;
   const uint32_t nch = (uint32_t)((ctx->run_src->n_valid + 63) / 64);
-  static const int plan_every = [] { const char *e = getenv("OPE_PLAN_EVERY"); return e ? std::max(1, atoi(e)) : 32; }();  // developer sweep
+  static const int plan_every = [] { const char *e = dev_env("OPE_PLAN_EVERY"); return e ? std::max(1, atoi(e)) : 32; }();  // developer sweep
   if (!no_plan && nch > 1 && it_done >= 1 && (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0)) {
     size_t tb = ctx->plan_tmp_bytes;
     if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
@@ -88,7 +104,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     // Measured optimum (model 100 k; tools/heavy_sweep.py): 2 at 0.25-0.6 chunks per wave (C2: 115 -> 79 us), 2.5 at
     // 1.0, 3 at 1.3 (500 k queries: 171 -> 142 us against a fixed 5), 4 at 1.9, 5 at 2.5 (C3), 6.5 at 3.8, 6-8 at 5
     // (2 M queries: 362 -> 299 us) — the line below.
-    static const float heavy_env = [] { const char *e = getenv("OPE_HEAVY_FACTOR"); return e ? (float)atof(e) : -1.0f; }();
+    static const float heavy_env = [] { const char *e = dev_env("OPE_HEAVY_FACTOR"); return e ? (float)atof(e) : -1.0f; }();
     const float chunks_per_wave = (float)nch / (float)(ctx->n_cu * 4 * kAccWavesPerSimd);
     const float heavy_factor = heavy_env >= 0.f ? heavy_env : std::min(7.0f, std::max(2.0f, 1.2f + 1.5f * chunks_per_wave));
     plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch, heavy_factor, ctx->d_work_counter + 8);
@@ -102,8 +118,8 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   const bool recip = p.use_reciprocal != 0;
   // packet walks for coherent chunks pay off when the launch fills the GPU (C3: 195 -> 184 us); on an underfilled
   // one (a 1/8 shard, C2) the longer dependent chain of a packet costs more than its gathers save (77 -> 88 us)
-  static const bool no_packet = getenv("OPE_NO_PACKET") != nullptr;  // developer A/B switch
-  static const int packet_min_env = [] { const char *e = getenv("OPE_PACKET_MIN_CHUNKS"); return e ? atoi(e) : -1; }();  // developer sweep
+  static const bool no_packet = dev_env("OPE_NO_PACKET") != nullptr;  // developer A/B switch
+  static const int packet_min_env = [] { const char *e = dev_env("OPE_PACKET_MIN_CHUNKS"); return e ? atoi(e) : -1; }();  // developer sweep
   const uint32_t packet_min = packet_min_env >= 0 ? (uint32_t)packet_min_env : (uint32_t)ctx->n_cu * 4u * (uint32_t)kAccWavesPerSimd;
   const bool packet = !no_packet && nch > packet_min;
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
@@ -292,6 +308,8 @@ size_t ope_cloud_size(const ope_cloud *cloud) { return cloud ? cloud->n : 0; }
 void ope_cloud_free(ope_cloud *cloud) {
   if (!cloud) return;
   if (cloud->ctx) (void)hipSetDevice(cloud->ctx->device);
+  // the last run's source: its correspondences can no longer be mapped back (ope_icp_correspondences -> OPE_ESTATE)
+  if (cloud->ctx && cloud->ctx->run_src == cloud) { cloud->ctx->run_src = nullptr; cloud->ctx->run_active = false; }
   if (cloud->d_xyzw) (void)hipFree(cloud->d_xyzw);
   if (cloud->d_nrm) (void)hipFree(cloud->d_nrm);
   delete cloud;
@@ -308,11 +326,12 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
   // Registration::setInputTarget: "Invalid or empty point cloud dataset given!" (registration_mod.hpp:60-64)
   if (target->n_valid == 0) return set_err(ctx, OPE_EEMPTY, "ope_index_build: invalid or empty target cloud");
   OPE_HIP(ctx, hipSetDevice(ctx->device));
+  TraceRange r_build(ctx, "index_build");
   ope_index_params dp;
   ope_index_default_params(&dp);
   if (params) dp = *params;
   const size_t n = target->n_valid;
-  static const bool host_build = getenv("OPE_HOST_BUILD") != nullptr;  // developer A/B switch: the host reference builder
+  static const bool host_build = dev_env("OPE_HOST_BUILD") != nullptr;  // developer A/B switch: the host reference builder
   if (!host_build) {
     // the finite points are the first n_valid records of the Morton-sorted device copy (w = original index)
     ope_index *ix = new ope_index();
@@ -381,6 +400,7 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
 void ope_index_free(ope_index *index) {
   if (!index) return;
   if (index->ctx) (void)hipSetDevice(index->ctx->device);
+  if (index->ctx && index->ctx->run_tgt == index) { index->ctx->run_tgt = nullptr; index->ctx->run_active = false; }
   if (index->d_nodes) (void)hipFree(index->d_nodes);
   if (index->d_pts) (void)hipFree(index->d_pts);
   if (index->d_nrm) (void)hipFree(index->d_nrm);
@@ -484,6 +504,7 @@ void ope_icp_default_params(ope_icp_params *p) {
   p->failure_after_max_iter = 0;
   p->check_every = 10;
   p->estimator = OPE_EST_SVD;
+  p->deterministic_sums = 0;
 }
 
 int ope_icp_set_global_sizes(ope_ctx *ctx, int64_t n_src_total, int64_t n_tgt_total) {
@@ -493,8 +514,17 @@ int ope_icp_set_global_sizes(ope_ctx *ctx, int64_t n_src_total, int64_t n_tgt_to
   return OPE_OK;
 }
 
+static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float *guess, const ope_icp_params *params);
+
 int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float *guess,
                   const ope_icp_params *params) {
+  const int rc = icp_begin_impl(ctx, src, tgt, guess, params);
+  // sizes set with ope_icp_set_global_sizes for a run that never started must not leak into the next one
+  if (rc != OPE_OK && ctx) ctx->n_src_total = ctx->n_tgt_total = 0;
+  return rc;
+}
+
+static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float *guess, const ope_icp_params *params) {
   if (!ctx || !src) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: bad argument");
   // Registration::initCompute: "No input target dataset was given!" (registration_mod.hpp:73-77)
   if (!tgt) return set_err(ctx, OPE_EEMPTY, "ope_icp_begin: no input target dataset was given");
@@ -512,6 +542,15 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   if (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && (p.k_normal_shooting < 1 || p.k_normal_shooting > 32))
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: 1 <= k_normal_shooting <= 32");
   OPE_HIP(ctx, hipSetDevice(ctx->device));
+  // From here on the context's run state is being rebuilt: any failure leaves NO run behind (not the previous one
+  // with new buffers, and not stale align-strength sizes).
+  const int64_t keep_ns = ctx->n_src_total, keep_nt = ctx->n_tgt_total;
+  abort_run(ctx);
+  struct BeginGuard {
+    ope_ctx *c; bool ok = false;
+    ~BeginGuard() { if (!ok) abort_run(c); }
+  } guard{ctx};
+  ctx->n_src_total = keep_ns; ctx->n_tgt_total = keep_nt;
   if (ctx->corr_cap < std::max<size_t>(src->n, 1)) {   // an empty source still gets one (unused) slot
     if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
     if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
@@ -598,7 +637,8 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
     if (rc != OPE_OK) return rc;
   }
   OPE_HIP(ctx, hipMemcpyAsync(ctx->d_state, h, sizeof *h, hipMemcpyHostToDevice, ctx->stream));
-  if (ctx->d_sums_ext) OPE_HIP(ctx, hipMemsetAsync(ctx->d_sums_ext, 0, sizeof(double) * kNumSumsMax, ctx->stream));
+  if (ctx->d_sums_ext)
+    OPE_HIP(ctx, hipMemsetAsync(ctx->d_sums_ext, 0, sizeof(double) * (p.estimator == OPE_EST_POINT_TO_PLANE_LLS ? kNumSumsMax : kNumSums), ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 256, ctx->stream));
   // partial-sum rows of blocks that do not exist in this run must read as zero
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_partials, 0, sizeof(double) * kNumSumsMax * kAccMaxBlocks, ctx->stream));
@@ -607,6 +647,7 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
 
   ctx->run_src = src;
   ctx->run_tgt = tgt;
+  ctx->corr_run_n = src->n;
   ctx->run_params = p;
   ctx->run_active = true;
   ctx->iters_enqueued = 0;
@@ -614,15 +655,16 @@ int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, cons
   // twice the waves the chunks alone would need: the chunks handed to 8-lane groups take eight slots each, and on a
   // launch that does not fill the GPU every slot should find a wave of its own (125 k queries: 84 -> 74 us)
   ctx->acc_blocks = (int)std::min<size_t>(std::max<size_t>(2 * ((src->n_valid + block - 1) / block), 1), kAccMaxBlocks);
-  if (const char *e = getenv("OPE_ACC_BLOCKS")) ctx->acc_blocks = std::max(1, std::min(atoi(e), (int)kAccMaxBlocks));
+  if (const char *e = dev_env("OPE_ACC_BLOCKS")) ctx->acc_blocks = std::max(1, std::min(atoi(e), (int)kAccMaxBlocks));
   if (ctx->n_src_total <= 0) ctx->n_src_total = (int64_t)src->n;
   if (ctx->n_tgt_total <= 0) ctx->n_tgt_total = (int64_t)tgt->n_total;
+  guard.ok = true;
   return OPE_OK;
 }
 
 int ope_icp_accumulate(ope_ctx *ctx) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_accumulate: no run in progress");
-  const bool atomic = atomic_sums_default();
+  const bool atomic = atomic_sums(ctx);
   int rc = enqueue_accumulate(ctx, atomic);
   if (rc != OPE_OK) return rc;
   if (!atomic)
@@ -640,32 +682,38 @@ int ope_icp_set_sums_buffer(ope_ctx *ctx, void *device_ptr) {
   if (!ctx) return OPE_EINVAL;
   ctx->d_sums_ext = static_cast<double *>(device_ptr);
   // accumulate launches add into the sums: a buffer handed over mid-run starts from zero like the built-in one
-  if (ctx->d_sums_ext) OPE_HIP(ctx, hipMemsetAsync(ctx->d_sums_ext, 0, sizeof(double) * kNumSumsMax, ctx->stream));
+  // (before a run it is cleared by ope_icp_begin, which knows how many sums the estimator uses)
+  if (ctx->d_sums_ext && ctx->run_active) OPE_HIP(ctx, hipMemsetAsync(ctx->d_sums_ext, 0, sizeof(double) * run_nsums(ctx), ctx->stream));
   return OPE_OK;
 }
 
 int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_iterate: no run in progress");
-  // OPE_FORCE_SHARDED_PATH: run the accumulate -> all-reduce -> update sequence with a one-rank communicator too
-  // (developer / test switch: a one-GPU box can exercise the path the multi-GPU runs take)
-  static const bool force_sharded = getenv("OPE_FORCE_SHARDED_PATH") != nullptr;
-  const bool sharded = ctx->nccl_comm != nullptr && (ctx->comm_nranks > 1 || force_sharded);
-  static const bool split_update = getenv("OPE_SPLIT_UPDATE") != nullptr;  // developer A/B switch
-  const bool atomic = atomic_sums_default();
+  // a context with a communicator takes the accumulate -> all-reduce -> update sequence, also with one rank
+  // (that is how a one-GPU box exercises the path the multi-GPU runs take)
+  const bool sharded = ctx->nccl_comm != nullptr;
+  static const bool split_update = dev_env("OPE_SPLIT_UPDATE") != nullptr;  // developer A/B switch
+  const bool atomic = atomic_sums(ctx);
   for (int b = 0; b < n_iterations; ++b) {
-    int rc = enqueue_accumulate(ctx, atomic);
+    TraceRange r_iter(ctx, "icp_iter");
+    int rc;
+    {
+      TraceRange r_nn(ctx, "nn");
+      rc = enqueue_accumulate(ctx, atomic);
+    }
     if (rc != OPE_OK) return rc;
+    TraceRange r_red(ctx, "reduce");
     if (sharded) {
       if (!atomic)
         launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
       rc = comm_allreduce_sums(ctx, sums_ptr(ctx), ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LLS ? kNumSumsMax : kNumSums);
       if (rc != OPE_OK) return rc;
-      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx));
+      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx));
     } else if (atomic) {
-      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx));
+      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx));
     } else if (split_update) {
       launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
-      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx));
+      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx));
     } else {
       launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, true, ctx->d_work_counter);
     }
@@ -704,7 +752,7 @@ int ope_icp_profile_read(ope_ctx *ctx, double *total_ms, int *n_launches) {
 
 int ope_icp_update(ope_ctx *ctx) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_update: no run in progress");
-  launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx));
+  launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx));
   OPE_HIP(ctx, hipGetLastError());
   ++ctx->iters_enqueued;
   return OPE_OK;
@@ -760,11 +808,11 @@ int ope_icp_run(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const 
   while (it < max_it) {
     const int batch = p.check_every > 0 ? std::min(p.check_every, max_it - it) : (max_it - it);
     rc = ope_icp_iterate(ctx, batch);
-    if (rc != OPE_OK) { ctx->run_active = false; return rc; }
+    if (rc != OPE_OK) { abort_run(ctx); return rc; }
     it += batch;
     if (it < max_it) {
       rc = ope_icp_poll(ctx, nullptr);
-      if (rc != OPE_OK) { ctx->run_active = false; return rc; }
+      if (rc != OPE_OK) { abort_run(ctx); return rc; }
       if (ctx->h_state->done) break;
     }
   }
@@ -773,7 +821,9 @@ int ope_icp_run(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const 
 
 int ope_icp_correspondences(ope_ctx *ctx, int32_t *index_query, int32_t *index_match, float *distance, size_t cap,
                             size_t *n_out) {
-  if (!ctx || !ctx->run_src || !n_out) return set_err(ctx, OPE_EINVAL, "ope_icp_correspondences: bad argument");
+  if (!ctx || !n_out) return set_err(ctx, OPE_EINVAL, "ope_icp_correspondences: bad argument");
+  if (!ctx->run_src || ctx->corr_run_n != ctx->run_src->n)
+    return set_err(ctx, OPE_ESTATE, "ope_icp_correspondences: no finished run whose source cloud is still alive");
   const ope_cloud *src = ctx->run_src;
   const size_t n = src->n;
   std::vector<int32_t> hm(n);

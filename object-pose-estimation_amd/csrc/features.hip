@@ -600,6 +600,7 @@ static int normals_impl(ope_ctx *ctx, ope_cloud *cloud, const ope_index *index, 
       index = own;
     }
     const int nblocks = (int)std::min<size_t>((n + kKnnBlock - 1) / kKnnBlock, 4096);
+    TraceRange r_n(ctx, "normals");
     if (k == 12)
       hipLaunchKernelGGL(normals_kernel<12>, dim3(nblocks), dim3(kKnnBlock), 0, ctx->stream, cloud->view(), index->view(), k, v[0], v[1],
                          v[2], cloud->d_nrm);
@@ -664,10 +665,16 @@ int ope_fpfh(ope_ctx *ctx, const ope_cloud *cloud, float radius, float *out33) {
   if (e == hipSuccess) {
     const int nblocks = (int)std::min<size_t>((n + kFeatBlock - 1) / kFeatBlock, 4096);
     const float r2 = radius * radius;
-    hipLaunchKernelGGL(spfh_kernel, dim3(nblocks), dim3(kFeatBlock), 0, ctx->stream, cloud->view(), ix->view(), r2, d_spfh,
-                       d_self, d_total);
-    hipLaunchKernelGGL(fpfh_kernel, dim3(nblocks), dim3(kFeatBlock), 0, ctx->stream, cloud->view(), ix->view(), r2, d_spfh,
-                       d_out);
+    {
+      TraceRange r_s(ctx, "fpfh_spfh");
+      hipLaunchKernelGGL(spfh_kernel, dim3(nblocks), dim3(kFeatBlock), 0, ctx->stream, cloud->view(), ix->view(), r2, d_spfh,
+                         d_self, d_total);
+    }
+    {
+      TraceRange r_w(ctx, "fpfh_weight");
+      hipLaunchKernelGGL(fpfh_kernel, dim3(nblocks), dim3(kFeatBlock), 0, ctx->stream, cloud->view(), ix->view(), r2, d_spfh,
+                         d_out);
+    }
     e = hipMemcpyAsync(out33, d_out, sizeof(float) * 33 * n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
@@ -706,6 +713,7 @@ int ope_sacia(ope_ctx *ctx, const ope_cloud *src, const float *src_feat33, const
   if (S < 1 || ns < S || nt < 1 || H < 1 || K < 1 || K > kFeatK)
     return set_err(ctx, OPE_EINVAL, "ope_sacia: need nr_samples <= |source|, 1 <= k_correspondences <= 8");
   OPE_HIP(ctx, hipSetDevice(ctx->device));
+  TraceRange r_sac(ctx, "sacia");
 
   // ---- selectSamples / findSimilarFeatures draws (host; the RNG stream does not depend on device results)
   std::vector<int32_t> samp((size_t)H * S), pick((size_t)H * S), corr((size_t)H * S);
@@ -718,9 +726,11 @@ int ope_sacia(ope_ctx *ctx, const ope_cloud *src, const float *src_feat33, const
       rng = rng * 6364136223846793005ULL + 1442695040888963407ULL;
       return (double)(rng >> 11) * (1.0 / 9007199254740992.0);
     };
-    float msd = p.min_sample_dist;
     const float *xyz = src->h_xyz.data();
     for (int it = 0; it < H; ++it) {
+      // selectSamples takes min_sample_distance BY VALUE (ia_ransac.hpp): a halving after 3*ns failed draws lasts for
+      // this hypothesis only, the next one starts from the configured distance again
+      float msd = p.min_sample_dist;
       int cnt = 0, without = 0;
       const int max_without = 3 * ns;
       int32_t *sm = &samp[(size_t)it * S];

@@ -4,6 +4,7 @@
 //   pcl::removeNaNFromPointCloud   DetectAndLocalize/src/poseestimator.cpp:192-194
 //   pcl::PassThrough::filter       BuildModel/src/processingpcd.cpp:8-36 (z, then y, then x: an axis-aligned box)
 //   pcl::VoxelGrid::filter         BuildModel/src/processingpcd.cpp:39-52
+//   pcl::StatisticalOutlierRemoval DetectAndLocalize/src/processingpcd.cpp:62-77 (getOutlierRemove, meanK 30)
 //
 // Index filters return ORIGINAL indices in ascending order (PCL keeps the input order).  The cloud on the
 // device is Morton-sorted, so the keep flag of each point is scattered to its original position and a
@@ -20,7 +21,7 @@
 #include <cmath>
 #include <vector>
 
-#include "ope_internal.hpp"
+#include "bvh_traverse.hpp"
 
 namespace ope {
 
@@ -72,6 +73,62 @@ __global__ __launch_bounds__(256) void centroid_kernel(CloudView c, const unsign
   const float r = __fdiv_rn(1.0f, (float)(j - p));
   float *o = out_xyz + 3 * (size_t)slot[p];
   o[0] = __fmul_rn(sx, r); o[1] = __fmul_rn(sy, r); o[2] = __fmul_rn(sz, r);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// StatisticalOutlierRemoval, pass 1: per point the mean distance to its mean_k nearest neighbours (the point itself is
+// the first entry of the k = mean_k + 1 nearest and is skipped).  The k-NN distances come out of the tree walk in
+// ascending order; their square roots are summed in double in that order, as statistical_outlier_removal.hpp does.
+// KREG = mean_k + 1 for the reference's value (meanK 30, processingpcd.cpp:70): distances only, in registers.
+template <int K>
+struct KnnDistVisitor {
+  float d[K];
+  int count;
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < K; ++j) d[j] = INFINITY;
+    count = 0;
+  }
+  __device__ __forceinline__ bool prune(float bound) const { return !(bound < d[K - 1]); }
+  __device__ __forceinline__ void point(float dist, const v4f &, uint32_t, uint32_t) {
+    const bool ins = dist < d[K - 1];
+    if (__ballot(ins) == 0ull) return;
+    count += (ins && count < K) ? 1 : 0;
+    // sorted insert: new d[j] = median(d[j-1], d[j], dist), one v_med3_f32 per slot; lanes without a candidate unchanged
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) d[j] = __builtin_amdgcn_fmed3f(d[j - 1], d[j], dist);
+    d[0] = fminf(d[0], dist);
+  }
+  __device__ __forceinline__ void on_node() {}
+};
+
+template <int KREG>
+__global__ __launch_bounds__(kKnnBlock) void sor_mean_distance_kernel(CloudView q, BvhView tgt, int mean_k,
+                                                                       float *__restrict__ dist_orig) {
+  extern __shared__ unsigned char s_dyn[];
+  float *ld = reinterpret_cast<float *>(s_dyn) + threadIdx.x;
+  uint32_t *lp = reinterpret_cast<uint32_t *>(s_dyn + sizeof(float) * kKnnBlock * kKnnMaxK) + threadIdx.x;
+  __shared__ float s_stk[kMaxDepth + 1][kKnnBlock];
+  float *stk = &s_stk[0][threadIdx.x];
+  for (uint32_t i = blockIdx.x * kKnnBlock + threadIdx.x; i < q.n; i += gridDim.x * kKnnBlock) {
+    const float4 s = q.xyzw[i];
+    const uint32_t orig = (uint32_t)__float_as_int(s.w);
+    if (i >= q.n_valid) { dist_orig[orig] = 0.0f; continue; }   // non-finite: distance 0, not counted as valid
+    double sum = 0.0;
+    if constexpr (KREG > 0) {
+      KnnDistVisitor<KREG> v;
+      v.init();
+      bvh_traverse(tgt, s.x, s.y, s.z, v, stk, kKnnBlock);
+#pragma unroll
+      for (int j = 1; j < KREG; ++j)
+        if (j < v.count) sum += sqrt((double)v.d[j]);
+    } else {
+      KnnVisitor v{ld, lp, kKnnBlock, mean_k + 1, 0, INFINITY};
+      bvh_traverse(tgt, s.x, s.y, s.z, v, stk, kKnnBlock);
+      for (int j = 1; j < v.count; ++j) sum += sqrt((double)ld[j * kKnnBlock]);
+    }
+    dist_orig[orig] = (float)(sum / (double)mean_k);
+  }
 }
 
 static int box_filter(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], int32_t *out_idx,
@@ -183,5 +240,51 @@ extern "C" int ope_voxel_grid(ope_ctx *ctx, const ope_cloud *cloud, const float 
     if (p) (void)hipFree(p);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_voxel_grid: ") + hipGetErrorString(e));
   *n_out = count;
+  return OPE_OK;
+}
+
+extern "C" int ope_statistical_outlier_removal(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double stddev_mul,
+                                               int32_t *out_idx, size_t *n_out, float *out_mean_dist) {
+  if (!ctx || !cloud || !out_idx || !n_out || mean_k < 1 || mean_k + 1 > kKnnMaxK)
+    return set_err(ctx, OPE_EINVAL, "ope_statistical_outlier_removal: bad argument (1 <= mean_k <= 31)");
+  *n_out = 0;
+  const size_t n = cloud->n;
+  if (n == 0) return OPE_OK;
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<float> dist(n, 0.0f);
+  if (cloud->n_valid > 0) {
+    TraceRange r(ctx, "sor");
+    ope_index *ix = nullptr;
+    int rc = ope_index_build(ctx, cloud, nullptr, &ix);
+    if (rc != OPE_OK) return rc;
+    float *d_dist = nullptr;
+    hipError_t e = hipMalloc((void **)&d_dist, 4 * n);
+    if (e == hipSuccess) {
+      const int nblocks = (int)std::min<size_t>((n + kKnnBlock - 1) / kKnnBlock, 8192);
+      if (mean_k == 30)
+        hipLaunchKernelGGL(sor_mean_distance_kernel<31>, dim3(nblocks), dim3(kKnnBlock), 0, ctx->stream, cloud->view(), ix->view(), mean_k, d_dist);
+      else
+        hipLaunchKernelGGL(sor_mean_distance_kernel<0>, dim3(nblocks), dim3(kKnnBlock), kKnnLdsBytes, ctx->stream, cloud->view(), ix->view(),
+                           mean_k, d_dist);
+      e = hipMemcpyAsync(dist.data(), d_dist, 4 * n, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    if (d_dist) (void)hipFree(d_dist);
+    ope_index_free(ix);
+    if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_statistical_outlier_removal: ") + hipGetErrorString(e));
+  }
+  // mean and standard deviation of the distance vector: the reference's own sequential double sums over the points in
+  // input order (4 bytes per point through the host: the survivors' indices take the same way out)
+  double sum = 0.0, sq_sum = 0.0;
+  for (size_t i = 0; i < n; ++i) { sum += dist[i]; sq_sum += (double)dist[i] * (double)dist[i]; }
+  const double valid = (double)cloud->n_valid;
+  const double mean = sum / valid;
+  const double variance = (sq_sum - sum * sum / valid) / (valid - 1.0);
+  const double thr = mean + stddev_mul * std::sqrt(variance);
+  size_t m = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (!((double)dist[i] > thr)) out_idx[m++] = (int32_t)i;   // non-finite points carry distance 0 and pass (PCL quirk)
+  *n_out = m;
+  if (out_mean_dist) std::memcpy(out_mean_dist, dist.data(), 4 * n);
   return OPE_OK;
 }

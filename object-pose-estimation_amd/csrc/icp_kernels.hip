@@ -706,19 +706,21 @@ __global__ __launch_bounds__(kRedBlock) void icp_reduce_update_kernel(IcpState *
 }
 
 // The sums are consumed: they are left at zero, ready for the next accumulate launch to add into (sharded runs).
-__global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, double *S) {
+// nsums: 17, or 44 with the point-to-plane estimator: a caller-owned sums buffer (ope_icp_set_sums_buffer) only has to hold
+// what the estimator uses, and nothing past that is read or written.
+__global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, double *S, int nsums) {
   if (st->done) return;
   __shared__ double s_S[kNumSumsMax];
   __shared__ IcpState s_st;
   state_to_lds(&s_st, st);
-  if (threadIdx.x < kNumSumsMax) s_S[threadIdx.x] = S[threadIdx.x];
+  if ((int)threadIdx.x < kNumSumsMax) s_S[threadIdx.x] = (int)threadIdx.x < nsums ? S[threadIdx.x] : 0.0;
   __syncthreads();
   if (threadIdx.x == 0) icp_update_lane(&s_st, s_S);
   __syncthreads();
-  if (threadIdx.x < kNumSumsMax) s_st.S[threadIdx.x] = 0.0;   // S may be the state's own array
+  if ((int)threadIdx.x < kNumSumsMax) s_st.S[threadIdx.x] = 0.0;   // S may be the state's own array
   __syncthreads();
   state_to_lds(st, &s_st);
-  if (threadIdx.x < kNumSumsMax) S[threadIdx.x] = 0.0;
+  if ((int)threadIdx.x < nsums) S[threadIdx.x] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -913,8 +915,8 @@ void launch_icp_reduce_update(hipStream_t stream, IcpState *st, const double *pa
                      do_update ? 1 : 0, work_counter);
 }
 
-void launch_icp_update(hipStream_t stream, IcpState *st, double *S) {
-  hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(64), 0, stream, st, S);
+void launch_icp_update(hipStream_t stream, IcpState *st, double *S, int nsums) {
+  hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(64), 0, stream, st, S, nsums);
 }
 
 void launch_nn_search(hipStream_t stream, const CloudView &q, const BvhView &tgt, const float *d_T, int32_t *out_idx,
@@ -939,6 +941,7 @@ void launch_fitness(hipStream_t stream, int nblocks, const CloudView &q, const B
 
 }  // namespace ope
 
+#ifdef OPE_DEVELOPER   // `make DEVELOPER=1`: instrumentation kernels are not part of the product library
 // ------------------------------------------------------------------------------------------
 // Developer instrumentation (tools/visit_stats.py): per-query node / leaf-point visit counts of the
 // private per-lane traversal.  Not part of include/ope.h.
@@ -1147,3 +1150,4 @@ extern "C" int ope_debug_chunk_profile(ope_ctx *ctx, const ope_cloud *q, const o
   (void)hipFree(d_T); (void)hipFree(d_out);
   return OPE_OK;
 }
+#endif  // OPE_DEVELOPER

@@ -112,8 +112,9 @@ struct ope_ctx {
   uint32_t *d_hint = nullptr;       // per sorted query: leaf (heap id) of the previous iteration's match, 0 = none
   size_t corr_cap = 0;
   ope::IcpState *h_state = nullptr;  // pinned
-  const ope_cloud *run_src = nullptr;
+  const ope_cloud *run_src = nullptr;   // cleared by ope_cloud_free / ope_index_free of the handle they point at
   const ope_index *run_tgt = nullptr;
+  size_t corr_run_n = 0;                 // source size of the run the correspondence buffers belong to
   ope_index *run_src_index = nullptr;  // index over the source (reciprocal correspondences only)
   ope_icp_params run_params{};
   bool run_active = false;
@@ -130,6 +131,8 @@ struct ope_ctx {
   // RCCL (dlopen'ed lazily)
   void *nccl_comm = nullptr;
   int comm_nranks = 1, comm_rank = 0;
+
+  bool tracing = false;   // roctx ranges around the host side of the path (ope_ctx_set_tracing)
 
   // scratch
   void *d_scratch = nullptr;
@@ -166,6 +169,17 @@ struct ope_index {
 namespace ope {
 
 int set_err(ope_ctx *ctx, int code, const std::string &msg);
+
+// RAII roctx range (trace.cpp); a no-op unless ope_ctx_set_tracing(ctx, 1) was called and a roctx library loads.
+class TraceRange {
+ public:
+  TraceRange(const ope_ctx *ctx, const char *name);
+  ~TraceRange();
+  TraceRange(const TraceRange &) = delete;
+  TraceRange &operator=(const TraceRange &) = delete;
+ private:
+  bool on_;
+};
 
 #define OPE_HIP(ctx, call)                                                                       \
   do {                                                                                           \

@@ -14,7 +14,9 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libope_oracle.so")
+# OPE_ORACLE_LIB: load another build of the same sources (tests/test_oracle_sanitizers.py points it at the
+# AddressSanitizer/UBSan build)
+_LIB_PATH = os.environ.get("OPE_ORACLE_LIB") or os.path.join(_HERE, "libope_oracle.so")
 _SRCS = ["kdtree.c", "icp.c", "features.c", "filters.c", "ope_oracle.h", "Makefile"]
 
 
@@ -25,7 +27,7 @@ def build(force: bool = False) -> str:
         t = os.path.getmtime(_LIB_PATH)
         stale = any(os.path.getmtime(os.path.join(_HERE, s)) > t for s in _SRCS)
     if stale:
-        subprocess.check_call(["make", "-C", _HERE, "libope_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, os.path.basename(_LIB_PATH)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
@@ -136,6 +138,8 @@ def _declare(L):
     L.orc_pass_through.argtypes = [_fp, C.c_int, _fp, _fp, _ip]
     L.orc_voxel_grid.restype = C.c_int
     L.orc_voxel_grid.argtypes = [_fp, C.c_int, _fp, _fp]
+    L.orc_statistical_outlier_removal.restype = C.c_int
+    L.orc_statistical_outlier_removal.argtypes = [_fp, C.c_int, C.c_int, C.c_double, _ip, _fp]
     L.orc_uniform_sampling.restype = C.c_int
     L.orc_uniform_sampling.argtypes = [_fp, C.c_int, C.c_float, _ip]
     L.orc_sacia_error.restype = C.c_double
@@ -358,6 +362,15 @@ def voxel_grid(xyz, leaf):
     out = np.empty((max(len(xyz), 1), 3), np.float32)
     n = lib().orc_voxel_grid(_p(xyz, _fp), len(xyz), _p(lf, _fp), _p(out, _fp))
     return None if n < 0 else out[:n].copy()
+
+
+def statistical_outlier_removal(xyz, mean_k: int = 30, stddev_mul: float = 1.0, return_distances: bool = False):
+    """pcl::StatisticalOutlierRemoval: indices of the inliers, input order (+ the mean-distance vector if asked)."""
+    xyz = _f32(xyz, 3)
+    out = np.empty(max(len(xyz), 1), np.int32)
+    dist = np.zeros(max(len(xyz), 1), np.float32)
+    n = lib().orc_statistical_outlier_removal(_p(xyz, _fp), len(xyz), mean_k, stddev_mul, _p(out, _ip), _p(dist, _fp))
+    return (out[:n].copy(), dist[: len(xyz)].copy()) if return_distances else out[:n].copy()
 
 
 def feature_knn(feat, q, k: int):

@@ -365,8 +365,9 @@ int orc_sacia(const float *src_xyz, const float *src_feat33, int ns, const float
   float *pt = (float *)malloc(sizeof(float) * 3 * (size_t)nr_samples);
   uint64_t rng = seed;
   float lowest = 0.f;
-  float msd = min_sample_dist;
   for (int it = 0; it < n_iter; ++it) {
+    /* selectSamples receives min_sample_distance by value: a halving lasts for one hypothesis only */
+    float msd = min_sample_dist;
     if (forced_samples) {
       memcpy(samp, forced_samples + (size_t)it * nr_samples, sizeof(int32_t) * (size_t)nr_samples);
       memcpy(corr, forced_samples + (size_t)n_iter * nr_samples + (size_t)it * nr_samples,

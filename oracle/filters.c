@@ -5,10 +5,12 @@
  *   pcl::removeNaNFromPointCloud   DetectAndLocalize/src/poseestimator.cpp:192-194
  *   pcl::PassThrough::filter       BuildModel/src/processingpcd.cpp:8-36 (z, then y, then x)
  *   pcl::VoxelGrid::filter         BuildModel/src/processingpcd.cpp:39-52
+ *   pcl::StatisticalOutlierRemoval DetectAndLocalize/src/processingpcd.cpp:62-77 (getOutlierRemove: meanK 30)
  *
  * The three classes live in the un-vendored PCL (nominally 1.7.2); their published algorithms are restated:
  * filters/impl/passthrough.hpp (applyFilterIndices), filters/impl/voxel_grid.hpp (applyFilter),
- * common/impl/io / filter.hpp (removeNaNFromPointCloud).
+ * common/impl/io / filter.hpp (removeNaNFromPointCloud), filters/impl/statistical_outlier_removal.hpp
+ * (applyFilterIndices).
  */
 #include <float.h>
 #include <math.h>
@@ -104,4 +106,53 @@ int orc_voxel_grid(const float *xyz, int n, const float leaf[3], float *out_xyz)
   }
   free(cv);
   return cnt;
+}
+
+/* StatisticalOutlierRemoval::applyFilterIndices (negative_ = false), restated [uPCL-recall, PCL 1.7.2]:
+ *   pass 1, per point: non-finite -> distance 0 and NOT counted; else nearestKSearch(mean_k + 1) and
+ *           distance = (float)( sum_{k=1..mean_k} sqrt(d2[k]) / mean_k )   (k = 0 is the point itself; the sum and the
+ *           square roots are double: an unqualified sqrt() on a float resolves to ::sqrt(double) there);
+ *   mean / variance over the WHOLE distance vector (zeros of non-finite points included in the sums, excluded from
+ *           the count): mean = sum / valid, variance = (sq_sum - sum*sum/valid) / (valid - 1), all in double;
+ *   pass 2: a point is removed iff distance > mean + stddev_mul * stddev.  Non-finite points carry distance 0 and are
+ *           therefore KEPT (PCL quirk; the reference removes NaNs beforehand, poseestimator.cpp:192-194).
+ * Fewer than mean_k + 1 finite points: the neighbours that exist are summed, still divided by mean_k.
+ * out_idx: kept indices in input order (capacity n); out_dist (optional, n floats): the distance vector. */
+int orc_statistical_outlier_removal(const float *xyz, int n, int mean_k, double stddev_mul, int32_t *out_idx, float *out_dist) {
+  if (n <= 0 || mean_k < 1) return 0;
+  float *dist = (float *)malloc(sizeof(float) * (size_t)n);
+  const int k = mean_k + 1;
+  int32_t *nn = (int32_t *)malloc(sizeof(int32_t) * (size_t)k);
+  float *nd = (float *)malloc(sizeof(float) * (size_t)k);
+  orc_kdtree *tree = orc_kdtree_build(xyz, n, 15);
+  int valid = 0;
+  for (int i = 0; i < n; ++i) {
+    const float *p = xyz + 3 * i;
+    dist[i] = 0.0f;
+    if (!finite3(p)) continue;
+    int32_t found = 0;
+    orc_kdtree_knn(tree, p, 1, k, nn, nd, &found);
+    if (found == 0) continue;
+    double sum = 0.0;
+    for (int j = 1; j < found; ++j) sum += sqrt((double)nd[j]);
+    dist[i] = (float)(sum / (double)mean_k);
+    ++valid;
+  }
+  orc_kdtree_free(tree);
+  free(nn);
+  free(nd);
+  double sum = 0.0, sq_sum = 0.0;
+  for (int i = 0; i < n; ++i) { sum += dist[i]; sq_sum += (double)dist[i] * (double)dist[i]; }
+  const double mean = sum / (double)valid;
+  const double variance = (sq_sum - sum * sum / (double)valid) / ((double)valid - 1.0);
+  const double thr = mean + stddev_mul * sqrt(variance);
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    if ((double)dist[i] > thr) continue;
+    out_idx[m++] = i;
+  }
+  if (out_dist)
+    for (int i = 0; i < n; ++i) out_dist[i] = dist[i];
+  free(dist);
+  return m;
 }

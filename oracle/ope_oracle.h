@@ -213,6 +213,9 @@ int orc_uniform_sampling(const float *xyz, int n, float leaf, int32_t *out_idx);
 int orc_remove_nan(const float *xyz, int n, int32_t *out_idx);
 int orc_pass_through(const float *xyz, int n, const float lo[3], const float hi[3], int32_t *out_idx);
 int orc_voxel_grid(const float *xyz, int n, const float leaf[3], float *out_xyz);
+/* pcl::StatisticalOutlierRemoval (ProcessingPcd::getOutlierRemove, processingpcd.cpp:62-77: setMeanK(30),
+ * setStddevMulThresh(threshold)): indices of the inliers in input order; out_dist (optional) the per-point mean distance. */
+int orc_statistical_outlier_removal(const float *xyz, int n, int mean_k, double stddev_mul, int32_t *out_idx, float *out_dist);
 
 /* SAC-IA error metric for one hypothesis: sum of TruncatedError(1-NN d2). */
 double orc_sacia_error(const float *src_xyz, int ns, const orc_kdtree *tgt_tree,

@@ -286,3 +286,22 @@ def test_empty_and_tiny_clouds_through_every_feature_entry_point(ctx):
     # k-NN asked for more neighbours than the kernel's list holds is refused, not truncated
     with pytest.raises(ope.OpeError):
         ctx.knn(c3, ctx.build_index(c3), 64)
+
+
+# ---------------------------------------------------------------- StatisticalOutlierRemoval (processingpcd.cpp:62-77)
+@pytest.mark.parametrize("n,mean_k,mul", [(40, 30, 1.0), (5000, 30, 1.0), (5000, 8, 0.5), (200_000, 30, 1.0), (20, 30, 2.0)])
+def test_statistical_outlier_removal_equals_oracle(ctx, n, mean_k, mul):
+    """Bit-equal mean-distance vector (ascending k-NN distances, double square roots summed in that order) and the same
+    survivors as the oracle; non-finite points pass (PCL quirk); fewer points than mean_k + 1 handled like the oracle."""
+    rng = np.random.default_rng(n + mean_k)
+    surf = synth.model_surface(max(n - n // 10, 1), 3)
+    fog = rng.uniform(-0.15, 0.15, (n - len(surf), 3)).astype(np.float32)
+    x = np.concatenate([surf, fog])[rng.permutation(n)]
+    if n >= 100:
+        x[::97] = np.nan
+    got, gd = ctx.statistical_outlier_removal(ctx.upload(x), mean_k, mul, return_distances=True)
+    want, wd = oracle.statistical_outlier_removal(x, mean_k, mul, return_distances=True)
+    np.testing.assert_array_equal(gd, wd)
+    np.testing.assert_array_equal(got, want)
+    if n >= 5000:
+        assert 0.5 * n < len(got) < n          # the fog goes, the surface stays
