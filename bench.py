@@ -50,6 +50,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-coarse", action="store_true", help="skip the FPFH + SAC-IA initial alignment (identity start)")
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--steady", type=int, default=100, help="iterations timed after the K steps, in the converged regime (reported, not `value`)")
     args = ap.parse_args()
     # Everything libraries print through fd 1 (RCCL's version banner, for one) goes to stderr; the one JSON line is
     # written to the real stdout at the end.
@@ -122,38 +123,65 @@ def main() -> int:
             sums = torch.zeros(ope.NUM_SUMS, dtype=torch.float64, device="cuda")   # SVD estimator: exactly OPE_NUM_SUMS doubles are used
             ctx.icp_set_sums_buffer(sums.data_ptr())
 
-    # ---- coarse stage (the "FPFH init" of config C3), as estimateCoarsePose runs it (poseestimator.cpp:16-73):
-    # uniform keypoints (leaf 0.01) -> normals (k=30) -> FPFH (r=0.03) on both clouds -> SAC-IA (400 x 5 x 5).
+    # ---- what the reference does with a captured frame before and during estimateCoarsePose:
+    #   ProcessingPcd::getPassThrough with the -l limits (rosinterface.cpp:212)  -> the workspace crop
+    #   [plane segmentation + clustering, rosinterface.cpp:213: out of scope; the synthetic frame has no table.  What it
+    #    does for the pose estimator — hand over the object's points without the surroundings — is done here by the
+    #    reference's own ProcessingPcd::getOutlierRemove (StatisticalOutlierRemoval, meanK 30, processingpcd.cpp:62-77):
+    #    at 1.4 clutter points per cm^3 EVERY 1 cm keypoint voxel of the crop box is occupied, and FPFH / SAC-IA see fog]
+    #   estimateCoarsePose (poseestimator.cpp:16-73): uniform keypoints (leaf 0.01) -> normals (k=30) -> FPFH (r=0.03)
+    #   on both clouds -> SAC-IA (400 x 5 x 5).
     # Every rank computes the initial pose (rank 0's is broadcast and used); it is reported, not part of `value`.
     coarse = None
     guess = None
+    cluster = None
+    gt_inv = np.linalg.inv(synth.ground_truth_pose())
     if not args.no_coarse:
+        ctx.profile_kernels(True)
         t_c = time.perf_counter()
         stage = {}
+        frame = ctx.upload(scene)
+        lo_w, hi_w = synth.workspace_limits(0.01)
+        t1 = time.perf_counter(); crop = ctx.pass_through(frame, lo_w, hi_w); cluster = scene[crop]
+        t2 = time.perf_counter(); inl = ctx.statistical_outlier_removal(ctx.upload(cluster), 30, 1.0); cluster = cluster[inl]
+        t3 = time.perf_counter()
+        stage["frame"] = {"points": int(len(scene)), "pass_through_kept": int(len(crop)), "pass_through_ms": (t2 - t1) * 1e3,
+                          "outlier_removal_kept": int(len(inl)), "outlier_removal_ms": (t3 - t2) * 1e3}
         feats, kclouds = [], []
-        for name, cloud in (("scene", scene), ("model", model)):
+        for name, cloud in (("cluster", cluster), ("model", model)):
             t1 = time.perf_counter(); full = ctx.upload(cloud); keep = ctx.uniform_sampling(full, 0.01)
             t2 = time.perf_counter(); kc = ctx.upload(cloud[keep]); ctx.normals(kc, 30)
             t3 = time.perf_counter(); feats.append(ctx.fpfh(kc, 0.03))
             t4 = time.perf_counter()
-            stage[name] = {"keypoints": int(len(keep)), "uniform_sampling_ms": (t2 - t1) * 1e3, "normals_ms": (t3 - t2) * 1e3,
-                           "fpfh_ms": (t4 - t3) * 1e3}
+            stage[name] = {"points": int(len(cloud)), "keypoints": int(len(keep)), "uniform_sampling_ms": (t2 - t1) * 1e3,
+                           "normals_ms": (t3 - t2) * 1e3, "fpfh_ms": (t4 - t3) * 1e3}
             kclouds.append(kc)
         t5 = time.perf_counter()
-        # SAC-IA in the reference's direction: source = the model, target = the scene (rosinterface.cpp:250 hands
+        # SAC-IA in the reference's direction: source = the model, target = the scene cluster (rosinterface.cpp:250 hands
         # estimateFinalPose the loaded model as source); the ICP below runs scene -> model, so it starts from the inverse
         kix = ctx.build_index(kclouds[0])
         m2s, sac_err, sac_it = ctx.sacia(kclouds[1], feats[1], kclouds[0], kix, feats[0], ope.default_sacia_params(seed=1))
         guess = np.linalg.inv(np.asarray(m2s, np.float64)).astype(np.float32)
         t6 = time.perf_counter()
-        gt = np.linalg.inv(synth.ground_truth_pose())
+        ktimes = ctx.profile_kernels_read()
+        ctx.profile_kernels(False)
+        kroof = {}
+        for kname, rec in sorted(ktimes.items()):
+            gbs = rec["algorithmic_bytes"] / (rec["ms"] * 1e-3) / 1e9 if rec["ms"] > 0 else 0.0
+            kroof[kname] = {"bound": "hbm", "ms": rec["ms"], "launches": rec["launches"],
+                            "algorithmic_bytes": rec["algorithmic_bytes"], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": gbs / HBM_PEAK_GBS}
+        n_kp = stage["cluster"]["keypoints"] + stage["model"]["keypoints"]
+        fp_ms = ktimes.get("spfh_kernel", {}).get("ms", 0.0) + ktimes.get("fpfh_kernel", {}).get("ms", 0.0)
+        sa_ms = ktimes.get("sacia_error_kernel", {}).get("ms", 0.0)
         coarse = {"total_ms": (t6 - t_c) * 1e3, "sacia_ms": (t6 - t5) * 1e3, "sacia_hypotheses": 400,
                   "sacia_best_iteration": int(sac_it), "sacia_error": float(sac_err),
-                  "pose_error_vs_ground_truth_frobenius": float(np.linalg.norm(guess.astype(np.float64) - gt)),
-                  "stages": stage,
-                  "note": "host wall-clock incl. uploads, device index builds and read-backs; not part of value. The synthetic "
-                          "model is nearly symmetric under a half turn: SAC-IA may land on the mirrored fit "
-                          "(Frobenius 2.83 from the generator's pose, same residual to 1%)"}
+                  "pose_error_vs_ground_truth_frobenius": float(np.linalg.norm(guess.astype(np.float64) - gt_inv)),
+                  "fpfh_points_per_s": n_kp / (fp_ms * 1e-3) if fp_ms > 0 else None,
+                  "sacia_hypotheses_per_s": 400 / (sa_ms * 1e-3) if sa_ms > 0 else None,
+                  "stages": stage, "kernels": kroof,
+                  "note": "stage times are host wall-clock incl. uploads, device index builds and read-backs; `kernels` are "
+                          "HIP-event times of the launches with the algorithmic bytes of SURVEY 8d; none of it is part of value"}
 
     if launched and guess is not None:
         # one initial pose for the whole job: every rank computed it from the same inputs, but the ranks must not
@@ -162,7 +190,10 @@ def main() -> int:
         dist.broadcast(g, src=0)
         guess = g.cpu().numpy()
 
-    params = ope.default_icp_params(max_iterations=W + K + 1, transformation_epsilon=0.0,
+    # W warm-up + K timed iterations from the coarse pose (`value`), then S more in the converged regime (reported
+    # separately: an iteration is cheaper once the scene has settled on the model)
+    S = args.steady
+    params = ope.default_icp_params(max_iterations=W + K + S + 1, transformation_epsilon=0.0,
                                     euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0, check_every=0)
     ctx.icp_set_global_sizes(n_scene, n_model)
     ctx.icp_begin(cs, ix, params, guess)
@@ -179,32 +210,46 @@ def main() -> int:
         ctx.sync()
         torch.cuda.synchronize()
 
+    def timed(n, profile):
+        """n steps bracketed by a barrier + synchronize on both sides; (seconds, kernel ms per launch)."""
+        sync()
+        if launched:
+            dist.barrier()
+        if profile:
+            ctx.icp_profile(n)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        sync()
+        if launched:
+            dist.barrier()
+        sync()
+        dt = time.perf_counter() - t0
+        km, kn = ctx.icp_profile_read() if profile else (0.0, 0)
+        if profile:
+            ctx.icp_profile(0)
+        return dt, (km / max(kn, 1)), kn
+
     for _ in range(W):
         step()
-    sync()
-    if launched:
-        dist.barrier()
-    ctx.icp_profile(K)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        step()
-    sync()
-    if launched:
-        dist.barrier()
-    sync()
-    elapsed = time.perf_counter() - t0
-    kern_ms, kern_n = ctx.icp_profile_read()
-    ctx.icp_profile(0)
+    elapsed, kern_avg_ms, kern_n = timed(K, True)
+    T_timed = ctx.icp_current_transform()
+    steady = None
+    if S > 0:
+        s_elapsed, s_kern_ms, _ = timed(S, True)
+        steady = {"steps": S, "ms_per_step": s_elapsed / S * 1e3, "iterations_per_s": S / s_elapsed, "kernel_ms": s_kern_ms}
     out = ctx.icp_end()
-    assert out.iterations == W + K, (out.iterations, W, K)
+    assert out.iterations == W + K + S, (out.iterations, W, K, S)
 
     if launched:
-        t = torch.tensor([elapsed, kern_ms / max(kern_n, 1)], dtype=torch.float64, device="cuda")
+        vals = [elapsed, kern_avg_ms] + ([steady["ms_per_step"], steady["kernel_ms"]] if steady else [])
+        t = torch.tensor(vals, dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_avg_ms = float(t[0]), float(t[1])
-    else:
-        kern_avg_ms = kern_ms / max(kern_n, 1)
+        if steady:
+            steady["ms_per_step"], steady["kernel_ms"] = float(t[2]), float(t[3])
+            steady["iterations_per_s"] = 1e3 / steady["ms_per_step"]
 
     rc = 0
     if rank == 0:
@@ -213,15 +258,37 @@ def main() -> int:
         # + 12 B per target point, per launch of the accumulate kernel on this rank
         algo_bytes = 36.0 * n_local + 12.0 * n_model
         achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        traffic, traffic_source = None, None
+        tf = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
         if world == 1 and os.path.exists(tf):
             try:
                 rec = json.load(open(tf)).get(args.workload)
                 if rec:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = rec.get("source")
             except Exception:
                 traffic = None
+        # pose of the timed run: the 1 M-point frame INCLUDING its 10 % clutter against the model, no correspondence
+        # distance limit (the reference leaves it at PCL's default, poseestimator.cpp:314-316): the clutter's pull is part
+        # of the result, so this lands in the right basin but not on the generator's pose
+        err_timed = float(np.linalg.norm(np.asarray(T_timed, np.float64) - gt_inv))
+        err_final = float(np.linalg.norm(out.T.astype(np.float64) - gt_inv))
+        checks = {"timed_run_pose_error_vs_ground_truth_frobenius": err_timed, "final_pose_error_vs_ground_truth_frobenius": err_final,
+                  "timed_run_bound": 0.25}
+        ok = err_final < 0.25
+        # the reference's own flow end to end: crop -> outlier removal -> coarse pose -> ICP of the CLUSTER (what
+        # estimateFinalPose receives, rosinterface.cpp:250), 100 iterations: this one must land on the generator's pose
+        if cluster is not None and world == 1:
+            t0 = time.perf_counter()
+            cc = ctx.upload(cluster)
+            p2 = ope.default_icp_params(max_iterations=100, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0,
+                                        mse_threshold_absolute=-1.0, check_every=0)
+            o2 = ctx.icp(cc, ix, p2, guess)
+            e2 = float(np.linalg.norm(o2.T.astype(np.float64) - gt_inv))
+            checks.update({"cluster_icp_pose_error_vs_ground_truth_frobenius": e2, "cluster_icp_bound": 1e-2,
+                           "cluster_points": int(len(cluster)), "cluster_icp_ms_100_iterations_incl_upload": (time.perf_counter() - t0) * 1e3})
+            ok = ok and e2 < 1e-2
+        checks["passed"] = bool(ok)
         line = {
             "metric": "ICP iterations/sec (1M scene pts vs 100k model pts) at 1/2/4/8 GPU" if args.workload == "C3"
                       else "ICP iterations/sec (100k scene pts vs 20k model pts)",
@@ -239,11 +306,15 @@ def main() -> int:
             "config": {"workload": desc, "n_scene": n_scene, "n_model": n_model, "scene_shard_per_gpu": n_local,
                        "parallelism": f"scene-sharded x{world}, model index replicated, 17xfp64 all-reduce/iter"
                                       + (f" ({args.comm})" if launched else ""),
+                       "start": "identity" if guess is None else "FPFH + SAC-IA coarse pose",
                        "final_mse": out.last_mse, "n_corr": int(out.n_corr)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "icp_accumulate_kernel", "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
                          "algorithmic_bytes_per_launch": algo_bytes},
+            "phases": {"from_coarse_pose": {"steps": K, "after_warmup": W, "ms_per_step": elapsed / K * 1e3, "kernel_ms": kern_avg_ms},
+                       "steady_state": steady},
+            "pose_check": checks,
         }
         if coarse is not None:
             line["coarse_stage"] = coarse
@@ -256,6 +327,9 @@ def main() -> int:
             pass
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        if not ok:
+            print(f"bench.py: pose check FAILED: {checks}", file=sys.stderr)
+            rc = 4
     ctx.close()
     if launched:
         dist.barrier()

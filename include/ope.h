@@ -64,6 +64,20 @@ int ope_ctx_sync(ope_ctx *ctx);
 int ope_ctx_set_tracing(ope_ctx *ctx, int on);
 const char *ope_last_error(const ope_ctx *ctx);
 
+/* Measurement hook for the coarse-stage and filter kernels (normals_kernel, spfh_kernel, fpfh_kernel, feature_knn_kernel,
+ * sacia_error_kernel, sor_mean_distance_kernel): while on, every launch is bracketed by HIP events on the launch stream and
+ * recorded with its ALGORITHMIC bytes (normals N(12+12k+16); SPFH N(24+24m+132); FPFH N(136m+132); SAC-IA
+ * 24 N_s per hypothesis; SOR N(12+12k+4)).  ope_profile_kernels_read synchronises and returns one record per kernel name,
+ * summed over its launches since ope_profile_kernels(ctx, 1). */
+typedef struct {
+  char name[32];
+  double ms;
+  int launches;
+  double algorithmic_bytes;
+} ope_kernel_time;
+int ope_profile_kernels(ope_ctx *ctx, int on);
+int ope_profile_kernels_read(ope_ctx *ctx, ope_kernel_time *out, size_t cap, size_t *n_out);
+
 /* ---------------- clouds ---------------- */
 /* Upload n points from an array of structs: xyz floats at base + i*stride + xyz_off,
  * optional normal floats at normal_off (pass -1 for none).  Works directly on
@@ -210,6 +224,18 @@ int ope_icp_profile_read(ope_ctx *ctx, double *total_ms, int *n_launches);
  * run on this context, or its source cloud has been freed since. */
 int ope_icp_correspondences(ope_ctx *ctx, int32_t *index_query, int32_t *index_match, float *distance, size_t cap,
                             size_t *n);
+
+/* getLastIncrementalTransformation() (transformation_, registration_mod.h): the incremental transform of the last
+ * iteration of the run that ope_icp_end / ope_icp_poll last read back. */
+int ope_icp_last_incremental(ope_ctx *ctx, float out_T[16]);
+
+/* CorrespondenceRejector::getRemainingCorrespondences for n GIVEN correspondences (stand-alone use; inside the ICP loop the
+ * same predicates are fused into the search kernel).  a, b: n packed float triples.
+ *   OPE_REJ_SURFACE_NORMAL: a = source normal, b = matched target normal; keep iff a . b > threshold
+ *                           (correspondence_rejection_mod.h:368-376)
+ *   OPE_REJ_SELF_OCCLUDED:  a = source normal, b = source point; keep iff a . (-b / |b|) > threshold (:382-391) */
+enum { OPE_REJ_SURFACE_NORMAL = 0, OPE_REJ_SELF_OCCLUDED = 1 };
+int ope_reject_pairs(ope_ctx *ctx, int kind, const float *a, const float *b, size_t n, double threshold, unsigned char *keep);
 
 /* Registration::getFitnessScore(max_range), registration_mod.hpp:131-165.
  * sum_out/n_out (optional) expose the partial sums for sharded runs. */

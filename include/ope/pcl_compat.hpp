@@ -24,6 +24,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <memory>
 #include <string>
 #include <vector>
@@ -129,47 +130,186 @@ template <class PointT> inline void transformPointCloud(const PointCloud<PointT>
   }
 }
 
+// pcl::transformPointCloudWithNormals: xyz by T, the normal by T's rotation block (what
+// IterativeClosestPointWithNormals::transformCloud applies to its working cloud, vPCL impl/icp_mod.hpp:311-318).
+template <class PointT> inline void transformPointCloudWithNormals(const PointCloud<PointT> &in, PointCloud<PointT> &out, const Matrix4f &T) {
+  static_assert(point_traits<PointT>::normal_offset >= 0, "transformPointCloudWithNormals needs a point type with normals");
+  transformPointCloud(in, out, T);
+  for (auto &p : out.points) {
+    float *n = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(&p) + point_traits<PointT>::normal_offset);
+    const float x = n[0], y = n[1], z = n[2];
+    n[0] = T.m[0] * x + T.m[4] * y + T.m[8] * z;
+    n[1] = T.m[1] * x + T.m[5] * y + T.m[9] * z;
+    n[2] = T.m[2] * x + T.m[6] * y + T.m[10] * z;
+  }
+}
+
+// pcl::ScopeTime: wall-clock of a scope, printed to stderr as "<title> took <ms>ms." when the scope ends.  The reference
+// wraps its two stages in ScopeTime t("Initial Alignment") / ("Final Alignment") (poseestimator.cpp:61,349).
+class ScopeTime {
+ public:
+  explicit ScopeTime(const char *title) : title_(title) { clock_gettime(CLOCK_MONOTONIC, &t0_); }
+  double getTime() const {
+    timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (t1.tv_sec - t0_.tv_sec) * 1e3 + (t1.tv_nsec - t0_.tv_nsec) * 1e-6;
+  }
+  ~ScopeTime() { std::fprintf(stderr, "%s took %gms.\n", title_.c_str(), getTime()); }
+ private:
+  std::string title_;
+  timespec t0_;
+};
+
 // ------------------------------------------------------------------------------------------ strategies
 namespace registration {
 
-struct CorrespondenceEstimationBase {
+// CorrespondenceEstimationBase (vPCL correspondence_estimation_mod.h:286-299).  Inside ICP the estimation is fused into
+// the search kernel and the object only selects the mode; called stand-alone (poseestimator.cpp:242-247 does, once, and
+// throws the result away) determineCorrespondences runs ONE search pass of the same kernel through the C ABI
+// (ope_icp_begin -> ope_icp_accumulate -> ope_icp_correspondences) and returns pcl::Correspondences in query order with
+// squared distances.
+template <class PointSource, class PointTarget> struct CorrespondenceEstimationBase {
+  typedef std::shared_ptr<CorrespondenceEstimationBase> Ptr;
   virtual ~CorrespondenceEstimationBase() {}
   virtual int mode() const { return OPE_CORR_NEAREST; }
   virtual int k() const { return 1; }
+  void setInputSource(const typename PointCloud<PointSource>::ConstPtr &c) { input_ = c; }
+  void setInputCloud(const typename PointCloud<PointSource>::ConstPtr &c) { input_ = c; }
+  void setInputTarget(const typename PointCloud<PointTarget>::ConstPtr &c) { target_ = c; }
+  // max_distance: 1-NN keeps d2 <= max_distance^2 (correspondence_estimation_mod.hpp:171); normal shooting compares the
+  // SQUARED point-to-line distance with the unsquared max_distance (quirk Q2, ...normal_shooting_weighted.hpp:136)
+  virtual void determineCorrespondences(Correspondences &correspondences, double max_distance = std::sqrt(DBL_MAX)) {
+    run_pass(correspondences, max_distance, false);
+  }
+  virtual void determineReciprocalCorrespondences(Correspondences &correspondences, double max_distance = std::sqrt(DBL_MAX)) {
+    run_pass(correspondences, max_distance, true);
+  }
+ protected:
+  void run_pass(Correspondences &out, double max_distance, bool reciprocal) {
+    out.clear();
+    ope_ctx *ctx = default_context();
+    if (!ctx || !input_ || !target_ || target_->empty()) return;
+    const bool nrm = mode() == OPE_CORR_NORMAL_SHOOTING;
+    auto src = upload(*input_, nrm), tgt = upload(*target_, false);
+    IndexHandle ix;
+    if (!src->h || !tgt->h || ope_index_build(ctx, tgt->h, nullptr, &ix.h) != OPE_OK) { log_error("determineCorrespondences", ctx); return; }
+    ope_icp_params p;
+    ope_icp_default_params(&p);
+    p.max_iterations = 1;
+    p.max_corr_dist = max_distance;
+    p.corr_mode = mode();
+    p.k_normal_shooting = k();
+    p.use_reciprocal = reciprocal ? 1 : 0;
+    std::vector<int32_t> q(input_->size()), m(input_->size());
+    std::vector<float> d(input_->size());
+    size_t n = 0;
+    if (ope_icp_begin(ctx, src->h, ix.h, nullptr, &p) != OPE_OK || ope_icp_accumulate(ctx) != OPE_OK ||
+        ope_icp_correspondences(ctx, q.data(), m.data(), d.data(), q.size(), &n) != OPE_OK) {
+      log_error("determineCorrespondences", ctx);
+      return;
+    }
+    ope_icp_end(ctx, nullptr, nullptr);
+    out.resize(n);
+    for (size_t i = 0; i < n; ++i) { out[i].index_query = q[i]; out[i].index_match = m[i]; out[i].distance = d[i]; }
+  }
+  typename PointCloud<PointSource>::ConstPtr input_;
+  typename PointCloud<PointTarget>::ConstPtr target_;
 };
-template <class S, class T, class Scalar = float> struct CorrespondenceEstimation : CorrespondenceEstimationBase {
+template <class S, class T, class Scalar = float> struct CorrespondenceEstimation : CorrespondenceEstimationBase<S, T> {
   typedef std::shared_ptr<CorrespondenceEstimation> Ptr;
 };
-template <class S, class T, class N, class Scalar = float> struct CorrespondenceEstimationNormalShooting : CorrespondenceEstimationBase {
+template <class S, class T, class N, class Scalar = float> struct CorrespondenceEstimationNormalShooting : CorrespondenceEstimationBase<S, T> {
   typedef std::shared_ptr<CorrespondenceEstimationNormalShooting> Ptr;
-  int k_ = 10;
+  int k_ = 10;   // the class default (vPCL correspondence_estimation_normal_shooting_weighted.h:117)
   void setKSearch(int k) { k_ = k; }
   int mode() const override { return OPE_CORR_NORMAL_SHOOTING; }
   int k() const override { return k_; }
-  // the reference also calls these on the stand-alone object (poseestimator.cpp:243-245); the ICP
-  // object re-feeds source/target every iteration, so they are accepted and not needed here
-  template <class P> void setInputSource(const P &) {}
+  // the source normals travel inside the source point type (PointXYZRGBNormal at poseestimator.cpp:244)
   template <class P> void setSourceNormals(const P &) {}
-  template <class P> void setInputTarget(const P &) {}
 };
 
+// CorrespondenceRejector (vPCL correspondence_rejection_mod.h:108-110,138-183).  Inside ICP the predicates are fused into
+// the search kernel (`apply`); stand-alone, getRemainingCorrespondences evaluates the same predicate for the given
+// correspondences on the device (ope_reject_pairs).
 struct CorrespondenceRejector {
   typedef std::shared_ptr<CorrespondenceRejector> Ptr;
   virtual ~CorrespondenceRejector() {}
   virtual void apply(ope_icp_params &p) const = 0;
+  virtual void getRemainingCorrespondences(const Correspondences &original, Correspondences &remaining) = 0;
+  void setInputCorrespondences(const std::shared_ptr<const Correspondences> &c) { input_correspondences_ = c; }
+  void getCorrespondences(Correspondences &out) {
+    out.clear();
+    if (input_correspondences_) getRemainingCorrespondences(*input_correspondences_, out);
+  }
+ protected:
+  std::shared_ptr<const Correspondences> input_correspondences_;
+  // packed xyz / normal triples of a cloud, pulled out of whatever point type it has
+  struct Triples { std::vector<float> v; bool set = false; };
+  template <class P> static void take_xyz(const PointCloud<P> &c, Triples &t) {
+    t.v.resize(3 * c.size());
+    for (size_t i = 0; i < c.size(); ++i) { t.v[3 * i] = c[i].x; t.v[3 * i + 1] = c[i].y; t.v[3 * i + 2] = c[i].z; }
+    t.set = true;
+  }
+  template <class N> static void take_normals(const PointCloud<N> &c, Triples &t) {
+    static_assert(point_traits<N>::normal_offset >= 0, "point type carries no normal");
+    t.v.resize(3 * c.size());
+    for (size_t i = 0; i < c.size(); ++i)
+      std::memcpy(&t.v[3 * i], reinterpret_cast<const unsigned char *>(&c[i]) + point_traits<N>::normal_offset, 12);
+    t.set = true;
+  }
+  static void filter(int kind, double thr, const Triples &a, bool a_by_query, const Triples &b, bool b_by_query,
+                     const Correspondences &in, Correspondences &out) {
+    out.clear();
+    ope_ctx *ctx = default_context();
+    if (!ctx || in.empty()) return;
+    if (!a.set || !b.set) { std::fprintf(stderr, "[ope::CorrespondenceRejector] input clouds / normals were not set\n"); return; }
+    std::vector<float> pa(3 * in.size()), pb(3 * in.size());
+    for (size_t i = 0; i < in.size(); ++i) {
+      const size_t ia = (size_t)(a_by_query ? in[i].index_query : in[i].index_match), ib = (size_t)(b_by_query ? in[i].index_query : in[i].index_match);
+      if (3 * ia + 2 >= a.v.size() || 3 * ib + 2 >= b.v.size()) return;
+      std::memcpy(&pa[3 * i], &a.v[3 * ia], 12);
+      std::memcpy(&pb[3 * i], &b.v[3 * ib], 12);
+    }
+    std::vector<unsigned char> keep(in.size());
+    if (ope_reject_pairs(ctx, kind, pa.data(), pb.data(), in.size(), thr, keep.data()) != OPE_OK) { log_error("getRemainingCorrespondences", ctx); return; }
+    for (size_t i = 0; i < in.size(); ++i)
+      if (keep[i]) out.push_back(in[i]);
+  }
 };
+// keep a correspondence if n_src . n_tgt > threshold (score: correspondence_rejection_mod.h:368-376; poseestimator.cpp:264-273)
 struct CorrespondenceRejectorSurfaceNormal : CorrespondenceRejector {
   typedef std::shared_ptr<CorrespondenceRejectorSurfaceNormal> Ptr;
   double threshold_ = 1.0;
   void setThreshold(double t) { threshold_ = t; }
+  double getThreshold() const { return threshold_; }
   template <class P, class N> void initializeDataContainer() {}
+  template <class P> void setInputSource(const typename PointCloud<P>::ConstPtr &) {}
+  template <class P> void setInputTarget(const typename PointCloud<P>::ConstPtr &) {}
+  template <class P, class N> void setInputNormals(const typename PointCloud<N>::ConstPtr &n) { if (n) take_normals(*n, src_n_); }
+  template <class P, class N> void setTargetNormals(const typename PointCloud<N>::ConstPtr &n) { if (n) take_normals(*n, tgt_n_); }
   void apply(ope_icp_params &p) const override { p.use_surface_normal_rej = 1; p.surface_normal_thr = threshold_; }
+  void getRemainingCorrespondences(const Correspondences &original, Correspondences &remaining) override {
+    filter(OPE_REJ_SURFACE_NORMAL, threshold_, src_n_, true, tgt_n_, false, original, remaining);
+  }
+ private:
+  Triples src_n_, tgt_n_;
 };
+// keep a correspondence if n_src . (-p_src / |p_src|) > threshold (vPCL correspondence_rejection_mod.h:382-391,
+// impl/correspondence_rejection_self_occluded_normal.cpp:43-64); opt-in, see SURVEY Q3
 struct CorrespondenceRejectorSelfOccludedNormal : CorrespondenceRejector {
   typedef std::shared_ptr<CorrespondenceRejectorSelfOccludedNormal> Ptr;
   double threshold_ = 1.0;
   void setThreshold(double t) { threshold_ = t; }
+  double getThreshold() const { return threshold_; }
+  template <class P, class N> void initializeDataContainer() {}
+  template <class P> void setInputSource(const typename PointCloud<P>::ConstPtr &c) { if (c) take_xyz(*c, src_p_); }
+  template <class P, class N> void setInputNormals(const typename PointCloud<N>::ConstPtr &n) { if (n) take_normals(*n, src_n_); }
   void apply(ope_icp_params &p) const override { p.use_self_occluded_rej = 1; p.self_occluded_thr = threshold_; }
+  void getRemainingCorrespondences(const Correspondences &original, Correspondences &remaining) override {
+    filter(OPE_REJ_SELF_OCCLUDED, threshold_, src_n_, true, src_p_, true, original, remaining);
+  }
+ private:
+  Triples src_n_, src_p_;
 };
 
 template <class S, class T, class Scalar = float> struct TransformationEstimationSVD {
@@ -231,7 +371,9 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
   IterativeClosestPoint() { ope_icp_default_params(&params_); criteria_ = std::make_shared<registration::DefaultConvergenceCriteria>(); }
   virtual ~IterativeClosestPoint() {}
 
-  void setInputSource(const typename PointCloudSource::ConstPtr &cloud) { input_ = cloud; src_dev_.reset(); }
+  void setInputSource(const typename PointCloudSource::ConstPtr &cloud) { input_ = cloud; src_dev_.reset(); correspondences_.clear(); }
+  typename PointCloudSource::ConstPtr const getInputSource() const { return input_; }
+  typename PointCloudTarget::ConstPtr const getInputTarget() const { return target_; }
   void setInputCloud(const typename PointCloudSource::ConstPtr &cloud) { setInputSource(cloud); }
   void setInputTarget(const typename PointCloudTarget::ConstPtr &cloud) {
     if (!cloud || cloud->points.empty()) {  // registration_mod.hpp:60-64
@@ -247,7 +389,8 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
   void setMaxCorrespondenceDistance(double d) { params_.max_corr_dist = d; }
   void setRANSACOutlierRejectionThreshold(double) {}  // accepted and unused, as in the reference (poseestimator.cpp:319)
   void setUseReciprocalCorrespondences(bool b) { params_.use_reciprocal = b ? 1 : 0; }
-  void setCorrespondenceEstimation(const std::shared_ptr<registration::CorrespondenceEstimationBase> &ce) { corr_est_ = ce; }
+  typedef registration::CorrespondenceEstimationBase<PointSource, PointTarget> CorrespondenceEstimation;
+  void setCorrespondenceEstimation(const std::shared_ptr<CorrespondenceEstimation> &ce) { corr_est_ = ce; }
   void addCorrespondenceRejector(const registration::CorrespondenceRejector::Ptr &r) { rejectors_.push_back(r); }
   template <class TE> void setTransformationEstimation(const std::shared_ptr<TE> &) { params_.estimator = TE::ope_estimator; }
   std::shared_ptr<registration::DefaultConvergenceCriteria> getConvergeCriteria() { return criteria_; }
@@ -256,8 +399,10 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
   void align(PointCloudSource &output, const Matrix4f &guess) {
     converged_ = false;
     final_ = Matrix4f::Identity();
+    last_incremental_ = Matrix4f::Identity();
     nr_iterations_ = 0;
     n_corr_ = 0;
+    correspondences_.clear();
     ope_ctx *ctx = default_context();
     if (!ctx) return;
     if (!target_) {  // registration_mod.hpp:73-77
@@ -274,8 +419,12 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
     p.failure_after_max_iter = criteria_->failure_after_max_iter_ ? 1 : 0;
     const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej ||
                      p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
+    // uploads are cached between align() calls on the same clouds; a cache made without normals is of no use once a
+    // rejector, normal shooting or the point-to-plane estimator has been added
+    if (nrm && !uploaded_with_normals_) { src_dev_.reset(); tgt_dev_.reset(); tgt_index_.reset(); }
     if (!src_dev_) src_dev_ = upload(*input_, nrm);
     if (!tgt_index_) {
+      uploaded_with_normals_ = nrm;
       tgt_dev_ = upload(*target_, nrm);
       tgt_index_ = std::make_shared<IndexHandle>();
       if (tgt_dev_->h && ope_index_build(ctx, tgt_dev_->h, nullptr, &tgt_index_->h) != OPE_OK) log_error("align", ctx);
@@ -291,11 +440,23 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
     nr_iterations_ = res.iterations;
     n_corr_ = res.n_corr;
     criteria_->state_ = (registration::DefaultConvergenceCriteria::ConvergenceState)res.state;
-    output = *input_;  // icp_mod.hpp:269-271
-    transformPointCloud(*input_, output, final_);
+    if (ope_icp_last_incremental(ctx, last_incremental_.m) != OPE_OK) last_incremental_ = Matrix4f::Identity();
+    // correspondences_ is a member of the reference's object too (icp_mod.h:249-260 reads it): fetched now, while the
+    // context still holds THIS object's run
+    {
+      std::vector<int32_t> q(input_->size()), m(input_->size());
+      std::vector<float> d(input_->size());
+      size_t n = 0;
+      if (ope_icp_correspondences(ctx, q.data(), m.data(), d.data(), q.size(), &n) == OPE_OK) {
+        correspondences_.resize(n);
+        for (size_t i = 0; i < n; ++i) { correspondences_[i].index_query = q[i]; correspondences_[i].index_match = m[i]; correspondences_[i].distance = d[i]; }
+      }
+    }
+    transformOutput(output);  // icp_mod.hpp:269-271
   }
 
   Matrix4f getFinalTransformation() const { return final_; }
+  Matrix4f getLastIncrementalTransformation() const { return last_incremental_; }   // transformation_, registration_mod.h
   bool hasConverged() const { return converged_; }
   int getNumberOfIterations() const { return nr_iterations_; }
   double getFitnessScore(double max_range = DBL_MAX) {
@@ -312,26 +473,20 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
     return denom > 0 ? (double)n_corr_ / denom : 0.0;
   }
   // pcl::Correspondences of the last iteration (post-rejection), query order
-  Correspondences getCorrespondences() const {
-    Correspondences out;
-    ope_ctx *ctx = default_context();
-    if (!ctx || !input_) return out;
-    std::vector<int32_t> q(input_->size()), m(input_->size());
-    std::vector<float> d(input_->size());
-    size_t n = 0;
-    if (ope_icp_correspondences(ctx, q.data(), m.data(), d.data(), q.size(), &n) != OPE_OK) return out;
-    out.resize(n);
-    for (size_t i = 0; i < n; ++i) { out[i].index_query = q[i]; out[i].index_match = m[i]; out[i].distance = d[i]; }
-    return out;
-  }
+  Correspondences getCorrespondences() const { return correspondences_; }
 
  protected:
+  // Registration::transformCloud of the final result: xyz only here, xyz + normals in IterativeClosestPointWithNormals
+  virtual void transformOutput(PointCloudSource &output) const { transformPointCloud(*input_, output, final_); }
   typename PointCloudSource::ConstPtr input_;
   typename PointCloudTarget::ConstPtr target_;
+  bool uploaded_with_normals_ = false;
+  Matrix4f last_incremental_ = Matrix4f::Identity();
+  Correspondences correspondences_;
   std::shared_ptr<CloudHandle> src_dev_, tgt_dev_;
   std::shared_ptr<IndexHandle> tgt_index_;
   ope_icp_params params_;
-  std::shared_ptr<registration::CorrespondenceEstimationBase> corr_est_;
+  std::shared_ptr<CorrespondenceEstimation> corr_est_;
   std::vector<registration::CorrespondenceRejector::Ptr> rejectors_;
   std::shared_ptr<registration::DefaultConvergenceCriteria> criteria_;
   Matrix4f final_ = Matrix4f::Identity();
@@ -340,10 +495,13 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
   int64_t n_corr_ = 0;
 };
 
-// Transforms the normals too (the kernels always do) and starts from the point-to-plane LLS estimator (icp_mod.h:355).
+// Transforms the normals too (vPCL impl/icp_mod.hpp:311-318; the kernels always do) and starts from the point-to-plane
+// LLS estimator (icp_mod.h:355).
 template <class S, class T, class Scalar = float> class IterativeClosestPointWithNormals : public IterativeClosestPoint<S, T, Scalar> {
  public:
   IterativeClosestPointWithNormals() { this->params_.estimator = OPE_EST_POINT_TO_PLANE_LLS; }
+ protected:
+  void transformOutput(PointCloud<S> &output) const override { transformPointCloudWithNormals(*this->input_, output, this->final_); }
 };
 
 // ------------------------------------------------------------------------------------------ features
@@ -525,6 +683,32 @@ template <class PointT> class VoxelGrid {
  private:
   typename PointCloud<PointT>::ConstPtr input_;
   float leaf_[3] = {0.01f, 0.01f, 0.01f};
+};
+
+// pcl::StatisticalOutlierRemoval (ProcessingPcd::getOutlierRemove, DetectAndLocalize processingpcd.cpp:62-77)
+template <class PointT> class StatisticalOutlierRemoval {
+ public:
+  void setInputCloud(const typename PointCloud<PointT>::ConstPtr &c) { input_ = c; }
+  void setMeanK(int k) { mean_k_ = k; }
+  void setStddevMulThresh(double m) { mul_ = m; }
+  void filter(PointCloud<PointT> &out) {
+    PointCloud<PointT> tmp;
+    ope_ctx *ctx = default_context();
+    if (ctx && input_ && !input_->empty()) {
+      auto dev = upload(*input_, false);
+      std::vector<int32_t> idx(input_->size());
+      size_t n = 0;
+      if (dev->h && ope_statistical_outlier_removal(ctx, dev->h, mean_k_, mul_, idx.data(), &n, nullptr) != OPE_OK) { log_error("StatisticalOutlierRemoval", ctx); n = 0; }
+      tmp.points.reserve(n);
+      for (size_t i = 0; i < n; ++i) tmp.points.push_back(input_->points[idx[i]]);
+      tmp.width = (uint32_t)n;
+    }
+    out = std::move(tmp);
+  }
+ private:
+  typename PointCloud<PointT>::ConstPtr input_;
+  int mean_k_ = 1;      // PCL's defaults
+  double mul_ = 0.0;
 };
 
 template <class PointSource, class PointTarget, class FeatureT> class SampleConsensusInitialAlignment {

@@ -80,6 +80,10 @@ class IcpResult(C.Structure):
     ]
 
 
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("ms", C.c_double), ("launches", C.c_int), ("algorithmic_bytes", C.c_double)]
+
+
 class IndexParams(C.Structure):
     _fields_ = [("leaf_size", C.c_int)]
 
@@ -110,6 +114,8 @@ ABI = [
     ("ope_ctx_sync", C.c_int, [_vp]),
     ("ope_ctx_set_tracing", C.c_int, [_vp, C.c_int]),
     ("ope_last_error", C.c_char_p, [_vp]),
+    ("ope_profile_kernels", C.c_int, [_vp, C.c_int]),
+    ("ope_profile_kernels_read", C.c_int, [_vp, C.POINTER(KernelTime), C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ope_cloud_upload", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_ssize_t, C.POINTER(_vp)]),
     ("ope_cloud_set_normals", C.c_int, [_vp, _vp, _fp]),
     ("ope_cloud_size", C.c_size_t, [_vp]),
@@ -135,6 +141,8 @@ ABI = [
     ("ope_icp_end", C.c_int, [_vp, _fp, C.POINTER(IcpResult)]),
     ("ope_icp_set_global_sizes", C.c_int, [_vp, C.c_int64, C.c_int64]),
     ("ope_icp_correspondences", C.c_int, [_vp, _ip, _ip, _fp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("ope_icp_last_incremental", C.c_int, [_vp, _fp]),
+    ("ope_reject_pairs", C.c_int, [_vp, C.c_int, _fp, _fp, C.c_size_t, C.c_double, C.POINTER(C.c_ubyte)]),
     ("ope_fitness", C.c_int, [_vp, _vp, _vp, _fp, C.c_double, _dp, _dp, C.POINTER(C.c_int64)]),
     ("ope_rigid_transform_svd", C.c_int, [_vp, _fp, _fp, C.c_size_t, _fp]),
     ("ope_transform_cloud", C.c_int, [_vp, _vp, _fp, _fp]),
@@ -249,6 +257,18 @@ class Context:
 
     def sync(self):
         self._chk(lib().ope_ctx_sync(self.h))
+
+    def profile_kernels(self, on: bool):
+        """HIP-event brackets around every coarse-stage / filter kernel launch (ope_profile_kernels)."""
+        self._chk(lib().ope_profile_kernels(self.h, int(on)))
+
+    def profile_kernels_read(self) -> dict:
+        """{kernel name: {"ms", "launches", "algorithmic_bytes"}} summed since profile_kernels(True)."""
+        buf = (KernelTime * 32)()
+        n = C.c_size_t(0)
+        self._chk(lib().ope_profile_kernels_read(self.h, buf, 32, C.byref(n)))
+        return {buf[i].name.decode(): {"ms": buf[i].ms, "launches": buf[i].launches, "algorithmic_bytes": buf[i].algorithmic_bytes}
+                for i in range(min(n.value, 32))}
 
     def set_tracing(self, on: bool):
         self._chk(lib().ope_ctx_set_tracing(self.h, int(on)))
@@ -370,6 +390,18 @@ class Context:
         self._chk(lib().ope_icp_correspondences(self.h, _p(q, _ip), _p(m, _ip), _p(d, _fp), cap, C.byref(n)))
         k = min(n.value, cap)
         return q[:k], m[:k], d[:k]
+
+    def icp_last_incremental(self) -> np.ndarray:
+        T = np.empty(16, np.float32)
+        self._chk(lib().ope_icp_last_incremental(self.h, _p(T, _fp)))
+        return from_colmajor(T)
+
+    def reject_pairs(self, kind: int, a, b, threshold: float) -> np.ndarray:
+        """CorrespondenceRejector predicates on given pairs (0: surface normal a.b, 1: self-occluded a.(-b/|b|)): bool mask."""
+        a, b = _f32(a, 3), _f32(b, 3)
+        keep = np.zeros(len(a), np.uint8)
+        self._chk(lib().ope_reject_pairs(self.h, kind, _p(a, _fp), _p(b, _fp), len(a), threshold, keep.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        return keep.astype(bool)
 
     def fitness(self, src: "Cloud", tgt: "Index", T, max_range: float = float(np.finfo(np.float64).max)):
         t = colmajor(T)

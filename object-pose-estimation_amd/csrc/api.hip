@@ -181,6 +181,8 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   ope_comm_destroy(ctx);
   if (ctx->run_src_index) ope_index_free(ctx->run_src_index);
   for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+  for (auto &k : ctx->kstamps) { (void)hipEventDestroy(k.e0); (void)hipEventDestroy(k.e1); }
+  for (hipEvent_t e : ctx->kevent_pool) (void)hipEventDestroy(e);
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
   if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
@@ -792,6 +794,12 @@ int ope_icp_end(ope_ctx *ctx, float out_T[16], ope_icp_result *result) {
     for (int i = 0; i < 16; ++i) out_T[i] = (float)ctx->h_state->F[i];
   ctx->run_active = false;
   ctx->n_src_total = ctx->n_tgt_total = 0;
+  return OPE_OK;
+}
+
+int ope_icp_last_incremental(ope_ctx *ctx, float out_T[16]) {
+  if (!ctx || !out_T || !ctx->h_state) return set_err(ctx, OPE_EINVAL, "ope_icp_last_incremental: bad argument");
+  for (int i = 0; i < 16; ++i) out_T[i] = (float)ctx->h_state->Tk[i];
   return OPE_OK;
 }
 

@@ -601,6 +601,8 @@ static int normals_impl(ope_ctx *ctx, ope_cloud *cloud, const ope_index *index, 
     }
     const int nblocks = (int)std::min<size_t>((n + kKnnBlock - 1) / kKnnBlock, 4096);
     TraceRange r_n(ctx, "normals");
+    // B_nrm = N (12 + 12 k + 16)
+    KernelTimer kt(ctx, "normals_kernel", (double)cloud->n_valid * (12.0 + 12.0 * k + 16.0));
     if (k == 12)
       hipLaunchKernelGGL(normals_kernel<12>, dim3(nblocks), dim3(kKnnBlock), 0, ctx->stream, cloud->view(), index->view(), k, v[0], v[1],
                          v[2], cloud->d_nrm);
@@ -610,6 +612,7 @@ static int normals_impl(ope_ctx *ctx, ope_cloud *cloud, const ope_index *index, 
     else
       hipLaunchKernelGGL(normals_kernel<0>, dim3(nblocks), dim3(kKnnBlock), kKnnLdsBytes, ctx->stream, cloud->view(), index->view(), k,
                          v[0], v[1], v[2], cloud->d_nrm);
+    kt.stop();
     hipError_t e = hipSuccess;
     if (want_host) e = hipMemcpyAsync(packed.data(), cloud->d_nrm, sizeof(float4) * n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -665,18 +668,31 @@ int ope_fpfh(ope_ctx *ctx, const ope_cloud *cloud, float radius, float *out33) {
   if (e == hipSuccess) {
     const int nblocks = (int)std::min<size_t>((n + kFeatBlock - 1) / kFeatBlock, 4096);
     const float r2 = radius * radius;
+    KernelTimer kt_s(ctx, "spfh_kernel", 0.0), kt_w(ctx, "fpfh_kernel", 0.0, /*start_now=*/false);
     {
       TraceRange r_s(ctx, "fpfh_spfh");
       hipLaunchKernelGGL(spfh_kernel, dim3(nblocks), dim3(kFeatBlock), 0, ctx->stream, cloud->view(), ix->view(), r2, d_spfh,
                          d_self, d_total);
     }
+    kt_s.stop();
+    kt_w.start();
     {
       TraceRange r_w(ctx, "fpfh_weight");
       hipLaunchKernelGGL(fpfh_kernel, dim3(nblocks), dim3(kFeatBlock), 0, ctx->stream, cloud->view(), ix->view(), r2, d_spfh,
                          d_out);
     }
+    kt_w.stop();
+    unsigned long long total_nb = 0;
     e = hipMemcpyAsync(out33, d_out, sizeof(float) * 33 * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&total_nb, d_total, sizeof total_nb, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    {
+      // pass 1 N (24 + 24 m + 132), pass 2 N (136 m + 132), m = measured mean neighbours in the radius
+      const double N = (double)cloud->n_valid, m = N > 0 ? (double)total_nb / N : 0.0;
+      kt_s.set_bytes(N * (24.0 + 24.0 * m + 132.0));
+      kt_w.set_bytes(N * (136.0 * m + 132.0));
+      ctx->last_fpfh_mean_neighbours = m;
+    }
   }
   if (d_spfh) (void)hipFree(d_spfh);
   if (d_out) (void)hipFree(d_out);
@@ -764,7 +780,11 @@ int ope_sacia(ope_ctx *ctx, const ope_cloud *src, const float *src_feat33, const
     if (e == hipSuccess) e = hipMemcpyAsync(d_qf, qf.data(), sizeof(float) * qf.size(), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&d_nn, sizeof(int32_t) * nn.size());
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(feature_knn_kernel, dim3((unsigned)uniq.size()), dim3(256), 0, ctx->stream, d_tf, nt, d_qf, K, d_nn);
+      {
+        // every query descriptor is compared with every target descriptor: 132 B of each, the target set once per query
+        KernelTimer kt(ctx, "feature_knn_kernel", 132.0 * ((double)uniq.size() * (double)nt + (double)uniq.size()));
+        hipLaunchKernelGGL(feature_knn_kernel, dim3((unsigned)uniq.size()), dim3(256), 0, ctx->stream, d_tf, nt, d_qf, K, d_nn);
+      }
       e = hipMemcpyAsync(nn.data(), d_nn, sizeof(int32_t) * nn.size(), hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
@@ -801,8 +821,12 @@ int ope_sacia(ope_ctx *ctx, const ope_cloud *src, const float *src_feat33, const
   if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows.data(), sizeof(float) * rows.size(), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMalloc((void **)&d_part, sizeof(double) * part.size());
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(sacia_error_kernel, dim3(bx, H), dim3(256), 0, ctx->stream, src->view(), tgt_index->view(), d_rows,
-                       (float)p.max_corr_dist, d_part);
+    {
+      // 24 N_s per hypothesis (read the source point, gather its nearest target point)
+      KernelTimer kt(ctx, "sacia_error_kernel", 24.0 * (double)src->n_valid * (double)H);
+      hipLaunchKernelGGL(sacia_error_kernel, dim3(bx, H), dim3(256), 0, ctx->stream, src->view(), tgt_index->view(), d_rows,
+                         (float)p.max_corr_dist, d_part);
+    }
     e = hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }

@@ -131,6 +131,24 @@ __global__ __launch_bounds__(kKnnBlock) void sor_mean_distance_kernel(CloudView 
   }
 }
 
+// CorrespondenceRejector predicates on given pairs, same arithmetic as the fused versions in icp_accumulate_kernel
+__global__ __launch_bounds__(256) void reject_pairs_kernel(int kind, const float *__restrict__ a, const float *__restrict__ b, uint32_t n,
+                                                           double thr, unsigned char *__restrict__ keep) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float ax = a[3 * i], ay = a[3 * i + 1], az = a[3 * i + 2], bx = b[3 * i], by = b[3 * i + 1], bz = b[3 * i + 2];
+  bool ok;
+  if (kind == OPE_REJ_SURFACE_NORMAL) {
+    const float score = __fadd_rn(__fadd_rn(__fmul_rn(ax, bx), __fmul_rn(ay, by)), __fmul_rn(az, bz));
+    ok = (double)score > thr;
+  } else {
+    const double sl = sqrt((double)__fadd_rn(__fadd_rn(__fmul_rn(bx, bx), __fmul_rn(by, by)), __fmul_rn(bz, bz)));
+    const double score = (double)ax * (-(double)bx / sl) + (double)ay * (-(double)by / sl) + (double)az * (-(double)bz / sl);
+    ok = score > thr;
+  }
+  keep[i] = ok ? 1 : 0;
+}
+
 static int box_filter(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], int32_t *out_idx,
                       size_t *n_out, const char *who) {
   *n_out = 0;
@@ -261,11 +279,14 @@ extern "C" int ope_statistical_outlier_removal(ope_ctx *ctx, const ope_cloud *cl
     hipError_t e = hipMalloc((void **)&d_dist, 4 * n);
     if (e == hipSuccess) {
       const int nblocks = (int)std::min<size_t>((n + kKnnBlock - 1) / kKnnBlock, 8192);
+      // algorithmic bytes, by analogy with the normals: read the point, gather k neighbours, write one float
+      KernelTimer kt(ctx, "sor_mean_distance_kernel", (double)cloud->n_valid * (12.0 + 12.0 * (mean_k + 1) + 4.0));
       if (mean_k == 30)
         hipLaunchKernelGGL(sor_mean_distance_kernel<31>, dim3(nblocks), dim3(kKnnBlock), 0, ctx->stream, cloud->view(), ix->view(), mean_k, d_dist);
       else
         hipLaunchKernelGGL(sor_mean_distance_kernel<0>, dim3(nblocks), dim3(kKnnBlock), kKnnLdsBytes, ctx->stream, cloud->view(), ix->view(),
                            mean_k, d_dist);
+      kt.stop();
       e = hipMemcpyAsync(dist.data(), d_dist, 4 * n, hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
@@ -286,5 +307,28 @@ extern "C" int ope_statistical_outlier_removal(ope_ctx *ctx, const ope_cloud *cl
     if (!((double)dist[i] > thr)) out_idx[m++] = (int32_t)i;   // non-finite points carry distance 0 and pass (PCL quirk)
   *n_out = m;
   if (out_mean_dist) std::memcpy(out_mean_dist, dist.data(), 4 * n);
+  return OPE_OK;
+}
+
+extern "C" int ope_reject_pairs(ope_ctx *ctx, int kind, const float *a, const float *b, size_t n, double threshold, unsigned char *keep) {
+  if (!ctx || (n && (!a || !b || !keep)) || (kind != OPE_REJ_SURFACE_NORMAL && kind != OPE_REJ_SELF_OCCLUDED) || n > (size_t)0x7fffffff)
+    return set_err(ctx, OPE_EINVAL, "ope_reject_pairs: bad argument");
+  if (n == 0) return OPE_OK;
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  float *d_a = nullptr, *d_b = nullptr;
+  unsigned char *d_k = nullptr;
+  hipError_t e = hipMalloc((void **)&d_a, 12 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_b, 12 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_k, n);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_a, a, 12 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_b, b, 12 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(reject_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, kind, d_a, d_b, (uint32_t)n, threshold, d_k);
+    e = hipMemcpyAsync(keep, d_k, n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  for (void *p : {(void *)d_a, (void *)d_b, (void *)d_k})
+    if (p) (void)hipFree(p);
+  if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_reject_pairs: ") + hipGetErrorString(e));
   return OPE_OK;
 }

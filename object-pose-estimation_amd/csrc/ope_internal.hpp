@@ -132,6 +132,14 @@ struct ope_ctx {
   void *nccl_comm = nullptr;
   int comm_nranks = 1, comm_rank = 0;
 
+  // per-kernel timing of the coarse-stage / filter kernels (ope_profile_kernels): HIP events on the launch stream
+  bool ktime_on = false;
+  struct KernelStamp { const char *name; hipEvent_t e0, e1; double bytes; };
+  std::vector<KernelStamp> kstamps;
+  std::vector<hipEvent_t> kevent_pool;
+
+  double last_fpfh_mean_neighbours = 0.0;
+
   bool tracing = false;   // roctx ranges around the host side of the path (ope_ctx_set_tracing)
 
   // scratch
@@ -169,6 +177,25 @@ struct ope_index {
 namespace ope {
 
 int set_err(ope_ctx *ctx, int code, const std::string &msg);
+
+// RAII HIP-event bracket around ONE kernel launch on the context stream, recorded under `name` together with the
+// launch's algorithmic bytes (SURVEY.md §8d formulas) when ope_profile_kernels(ctx, 1) is on; otherwise a no-op.
+class KernelTimer {
+ public:
+  KernelTimer(ope_ctx *ctx, const char *name, double algorithmic_bytes, bool start_now = true);
+  ~KernelTimer() { stop(); }
+  KernelTimer(const KernelTimer &) = delete;
+  KernelTimer &operator=(const KernelTimer &) = delete;
+  void start();
+  void stop();
+  void set_bytes(double b);   // for byte counts only known after the launch (FPFH: the measured neighbour count)
+ private:
+  ope_ctx *ctx_;
+  const char *name_;
+  double bytes_;
+  int slot_;
+  bool open_;
+};
 
 // RAII roctx range (trace.cpp); a no-op unless ope_ctx_set_tracing(ctx, 1) was called and a roctx library loads.
 class TraceRange {

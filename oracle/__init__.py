@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OPE_ORACLE_LIB: load another build of the same sources (tests/test_oracle_sanitizers.py points it at the
 # AddressSanitizer/UBSan build)
 _LIB_PATH = os.environ.get("OPE_ORACLE_LIB") or os.path.join(_HERE, "libope_oracle.so")
-_SRCS = ["kdtree.c", "icp.c", "features.c", "filters.c", "ope_oracle.h", "Makefile"]
+_SRCS = ["kdtree.c", "icp.c", "features.c", "filters.c", "pose.c", "ope_oracle.h", "Makefile"]
 
 
 def build(force: bool = False) -> str:
@@ -93,6 +93,22 @@ class Convergence(C.Structure):
     ]
 
 
+class PoseEstimatorState(C.Structure):
+    _fields_ = [
+        ("first_time_pose", C.c_int),
+        ("fitness_score_fine", C.c_double), ("aligned_strength", C.c_double),
+        ("final_pose", C.c_float * 16),
+        ("aligned_source", C.POINTER(C.c_float)), ("n_aligned", C.c_int),
+        ("cloud_model", C.POINTER(C.c_float)), ("n_model", C.c_int),
+        ("sacia_seed", C.c_uint64),
+        ("coarse_calls", C.c_int), ("use_self_occluded", C.c_int), ("acc_mode", C.c_int), ("transform_mode", C.c_int),
+        ("last_coarse", C.c_float * 16), ("last_fine", C.c_float * 16), ("last_rigid", C.c_float * 16),
+        ("last_sacia_error", C.c_double), ("last_sacia_best", C.c_int),
+        ("last_n_src_keys", C.c_int), ("last_n_tgt_keys", C.c_int), ("last_n_fine_src", C.c_int), ("last_n_fine_tgt", C.c_int),
+        ("last_icp_iterations", C.c_int), ("last_icp_state", C.c_int), ("last_icp_n_corr", C.c_int),
+    ]
+
+
 CONV_NAMES = ["NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE", "NO_CORRESPONDENCES"]
 
 _fp = C.POINTER(C.c_float)
@@ -148,6 +164,14 @@ def _declare(L):
     L.orc_sacia.argtypes = [_fp, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                             C.c_float, C.c_uint64, _ip, _fp, _dp, _ip]
     L.orc_feature_knn.argtypes = [_fp, C.c_int, _fp, C.c_int, C.c_int, _ip, _fp]
+    L.orc_pose_estimator_init.argtypes = [C.POINTER(PoseEstimatorState)]
+    L.orc_pose_estimator_free.argtypes = [C.POINTER(PoseEstimatorState)]
+    L.orc_estimate_coarse_pose.restype = C.c_int
+    L.orc_estimate_coarse_pose.argtypes = [C.POINTER(PoseEstimatorState), _fp, C.c_int, _fp, C.c_int, _fp]
+    L.orc_estimate_fine_pose.restype = C.c_int
+    L.orc_estimate_fine_pose.argtypes = [C.POINTER(PoseEstimatorState), _fp, C.c_int, _fp, C.c_int, _fp]
+    L.orc_estimate_final_pose.restype = C.c_int
+    L.orc_estimate_final_pose.argtypes = [C.POINTER(PoseEstimatorState), _fp, C.c_int, _fp, C.c_int, _fp, _dp, _dp]
 
 
 def _f32(a, cols=None):
@@ -401,3 +425,44 @@ def sacia(src, src_feat, tgt, tgt_feat, n_iter=400, nr_samples=5, k_corr=5, max_
     if rc != 0:
         raise ValueError(f"orc_sacia rc={rc}")
     return T.reshape(4, 4).T.copy(), err.value, bi.value
+
+
+class PoseEstimator:
+    """The reference's PoseEstimator (poseestimator.cpp:3-448) on the oracle's primitives: state crosses frames."""
+
+    def __init__(self, sacia_seed: int = 1, use_self_occluded: bool = False, as_device: bool = True):
+        self.st = PoseEstimatorState()
+        lib().orc_pose_estimator_init(C.byref(self.st))
+        self.st.sacia_seed = sacia_seed
+        self.st.use_self_occluded = int(use_self_occluded)
+        self.st.acc_mode = 1 if as_device else 0
+        self.st.transform_mode = 1 if as_device else 0
+
+    def __del__(self):
+        try:
+            lib().orc_pose_estimator_free(C.byref(self.st))
+        except Exception:
+            pass
+
+    @staticmethod
+    def _m(a16):
+        return np.asarray(list(a16), np.float32).reshape(4, 4).T.copy()
+
+    def estimate_final_pose(self, source, target):
+        """Returns (finalPose (4,4), fitnessScore, alignStrength, source overwritten with alignedSource, info dict)."""
+        src = _f32(source, 3).copy()
+        tgt = _f32(target, 3)
+        T = np.empty(16, np.float32)
+        fit = C.c_double(0); strength = C.c_double(0)
+        rc = lib().orc_estimate_final_pose(C.byref(self.st), _p(src, _fp), len(src), _p(tgt, _fp), len(tgt), _p(T, _fp),
+                                           C.byref(fit), C.byref(strength))
+        if rc != 0:
+            raise ValueError(f"orc_estimate_final_pose rc={rc}")
+        st = self.st
+        info = {"coarse": self._m(st.last_coarse), "fine": self._m(st.last_fine), "rigid": self._m(st.last_rigid),
+                "sacia_error": st.last_sacia_error, "sacia_best": st.last_sacia_best,
+                "n_src_keys": st.last_n_src_keys, "n_tgt_keys": st.last_n_tgt_keys,
+                "n_fine_src": st.last_n_fine_src, "n_fine_tgt": st.last_n_fine_tgt,
+                "icp_iterations": st.last_icp_iterations, "icp_state": st.last_icp_state, "icp_n_corr": st.last_icp_n_corr,
+                "coarse_calls": st.coarse_calls}
+        return T.reshape(4, 4).T.copy(), fit.value, strength.value, src, info

@@ -234,6 +234,38 @@ int orc_sacia(const float *src_xyz, const float *src_feat33, int ns,
 /* 33-D feature k-NN (brute force), used by SAC-IA findSimilarFeatures. */
 void orc_feature_knn(const float *feat33, int n, const float *q33, int nq, int k, int32_t *idx, float *d2);
 
+/* ------------------------------------------------------------------ */
+/* The L2 composite: PoseEstimator (poseestimator.cpp:3-448), pose.c.  */
+/* ------------------------------------------------------------------ */
+typedef struct {
+  /* state that crosses frames (poseestimator.h:50-53) */
+  int first_time_pose;
+  double fitness_score_fine, aligned_strength;
+  float final_pose[16];
+  float *aligned_source; int n_aligned;
+  float *cloud_model;    int n_model;
+  /* knobs of the restatement */
+  uint64_t sacia_seed;   /* the k-th coarse call uses the stream sacia_seed + k (PCL: unseeded rand()) */
+  int coarse_calls;
+  int use_self_occluded; /* CorrespondenceRejectorSelfOccludedNormal 0.6 (poseestimator.cpp:290-291,336); default 0, SURVEY Q3 */
+  int acc_mode;          /* umeyama accumulation (orc_umeyama): 1 = double, as the device; 0 = float, as PCL */
+  int transform_mode;    /* orc_icp_params.transform_mode: 1 = as the device, 0 = as PCL */
+  /* diagnostics of the last call */
+  float last_coarse[16], last_fine[16], last_rigid[16];
+  double last_sacia_error; int last_sacia_best;
+  int last_n_src_keys, last_n_tgt_keys, last_n_fine_src, last_n_fine_tgt;
+  int last_icp_iterations, last_icp_state, last_icp_n_corr;
+} orc_pose_estimator;
+
+void orc_pose_estimator_init(orc_pose_estimator *pe);
+void orc_pose_estimator_free(orc_pose_estimator *pe);
+/* subSampleAndCalculateNormals (:131-158); outputs malloc'ed, caller frees; returns the number of key points */
+int orc_sub_sample_and_normals(const float *xyz, int n, float leaf, float **out_xyz, float **out_nrm, float **out_curv);
+int orc_estimate_coarse_pose(orc_pose_estimator *pe, const float *src, int ns, const float *tgt, int nt, float out_T[16]);
+int orc_estimate_fine_pose(orc_pose_estimator *pe, float *src_inout, int ns, const float *tgt, int nt, float out_T[16]);
+int orc_estimate_final_pose(orc_pose_estimator *pe, float *src_inout, int ns, const float *tgt, int nt, float out_pose[16],
+                            double *fitness_score, double *align_strength);
+
 #ifdef __cplusplus
 }
 #endif
