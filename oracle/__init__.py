@@ -466,3 +466,21 @@ class PoseEstimator:
                 "icp_iterations": st.last_icp_iterations, "icp_state": st.last_icp_state, "icp_n_corr": st.last_icp_n_corr,
                 "coarse_calls": st.coarse_calls}
         return T.reshape(4, 4).T.copy(), fit.value, strength.value, src, info
+
+
+def estimate_coarse_pose(source, target, sacia_seed: int = 1, call_index: int = 0):
+    """PoseEstimator::estimateCoarsePose (poseestimator.cpp:16-73) as the `call_index`-th coarse call of an estimator
+    seeded with `sacia_seed`: returns (pose (4,4), info)."""
+    st = PoseEstimatorState()
+    lib().orc_pose_estimator_init(C.byref(st))
+    st.sacia_seed = sacia_seed
+    st.coarse_calls = call_index
+    src, tgt = _f32(source, 3), _f32(target, 3)
+    T = np.empty(16, np.float32)
+    rc = lib().orc_estimate_coarse_pose(C.byref(st), _p(src, _fp), len(src), _p(tgt, _fp), len(tgt), _p(T, _fp))
+    info = {"sacia_error": st.last_sacia_error, "sacia_best": st.last_sacia_best, "n_src_keys": st.last_n_src_keys,
+            "n_tgt_keys": st.last_n_tgt_keys}
+    lib().orc_pose_estimator_free(C.byref(st))
+    if rc != 0:
+        raise ValueError(f"orc_estimate_coarse_pose rc={rc}")
+    return T.reshape(4, 4).T.copy(), info

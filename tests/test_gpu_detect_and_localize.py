@@ -92,13 +92,15 @@ def _check(frames, model, scenes, seed, tol_coarse=2e-5, tol=1e-4, band=3e-2):
     src_dev = model.copy()      # the façade's chain, replayed from its printed transforms
     aligned_dev = None
     for k, (fr, scene) in enumerate(zip(frames, scenes)):
-        T, fit, strength, src, info = pe.estimate_final_pose(src, scene)
-        # ---- coarse stage: same SAC-IA stream, same winner
-        assert fr["coarse_calls"] == info["coarse_calls"], (k, fr["coarse_calls"], info)
-        assert _frob(fr["coarse"], info["coarse"]) < tol_coarse, (k, fr["coarse"], info["coarse"])
-        # ---- fine stage on identical inputs
-        if fr["coarse_calls"] > (frames[k - 1]["coarse_calls"] if k else 0):
+        # ---- coarse stage on the façade's own incoming source: same SAC-IA stream, same winner
+        calls_before = frames[k - 1]["coarse_calls"] if k else 0
+        if fr["coarse_calls"] > calls_before:
+            Tc, _ = oracle.estimate_coarse_pose(src_dev, scene, sacia_seed=seed, call_index=calls_before)
+            assert _frob(fr["coarse"], Tc) < tol_coarse, (k, fr["coarse"], Tc)
             aligned_dev = _transform_f32(fr["coarse"], src_dev)      # alignedSource = coarsePose * source (:66-70)
+        else:
+            assert _frob(fr["coarse"], np.eye(4)) == 0.0
+        # ---- fine stage on identical inputs
         sk, sn = _fine_inputs_on_gpu(ctx, aligned_dev)
         tk, tn = _fine_inputs_on_gpu(ctx, scene)
         ref = _oracle_fine(sk, sn, tk, tn)
@@ -111,9 +113,13 @@ def _check(frames, model, scenes, seed, tol_coarse=2e-5, tol=1e-4, band=3e-2):
         assert _frob(fr["final"], want_final) < 1e-5
         rigid_ref = oracle.umeyama(model, src_dev, 1)
         assert _frob(fr["rigid"], rigid_ref) < 2e-5
-        # ---- end to end, each side through its own stages
-        assert _frob(fr["final"], T) < band and _frob(fr["fine"], info["fine"]) < band
-        assert fr["fitness"] == pytest.approx(fit, rel=0.15) and fr["strength"] == pytest.approx(strength, abs=0.03)
+        # ---- end to end, each side through its own stages (first frame: later frames start from states that already
+        # differ by the band, and SAC-IA on different inputs is a different draw)
+        if k == 0:
+            T, fit, strength, src, info = pe.estimate_final_pose(src, scene)
+            assert fr["coarse_calls"] == info["coarse_calls"]
+            assert _frob(fr["final"], T) < band and _frob(fr["fine"], info["fine"]) < band
+            assert fr["fitness"] == pytest.approx(fit, rel=0.15) and fr["strength"] == pytest.approx(strength, abs=0.03)
         aligned_dev = _transform_f32(fr["fine"], aligned_dev)         # :358-360
         src_dev = aligned_dev.copy()                                  # :441
     ctx.close()
