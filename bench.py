@@ -47,6 +47,7 @@ def main() -> int:
                     help="under torch.distributed.run: all-reduce through the library's own RCCL communicator (whole loop in "
                          "C++, default) or through torch.distributed; 'native' falls back to 'torch' if RCCL init fails")
     ap.add_argument("--leaf", type=int, default=0, help="index leaf size override (0 = library default)")
+    ap.add_argument("--no-grid", action="store_true", help="OBB tree only (A/B against the bucketed search)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-coarse", action="store_true", help="skip the FPFH + SAC-IA initial alignment (identity start)")
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -98,7 +99,7 @@ def main() -> int:
         # launch on torch's current stream so torch.distributed orders the collective with our kernels
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     cs = ctx.upload(shard)
-    ix = ctx.build_index(ctx.upload(model), leaf_size=args.leaf or None)
+    ix = ctx.build_index(ctx.upload(model), leaf_size=args.leaf or None, grid=not args.no_grid)
     sums = None
     if use_torch_comm:
         sums = torch.zeros(ope.NUM_SUMS, dtype=torch.float64, device="cuda")   # SVD estimator: exactly OPE_NUM_SUMS doubles are used

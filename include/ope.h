@@ -96,7 +96,14 @@ void ope_cloud_free(ope_cloud *cloud);
 
 /* ---------------- search index over a target cloud ---------------- */
 typedef struct {
-  int leaf_size; /* max points per leaf bucket (default 16) */
+  int leaf_size; /* max points per leaf bucket of the OBB tree (default 16) */
+  int grid;      /* 1 (default): 1-NN ICP runs also use a uniform grid over the points ("radix-bucketed" search): queries
+                    whose previous match is close are answered from a few cell runs, all others by the tree.  A run whose
+                    source turns out to hold more than 3 % of queries far from the target (measured on the device after
+                    the first iterations) continues on the tree-only kernel, which is faster for that mix.
+                    0: tree only.  2: grid kernel always. */
+  float grid_fill;      /* target number of points per occupied grid cell (0 = default) */
+  int grid_max_cells;   /* upper bound on the number of grid cells, 4 B each (0 = default: the table must stay L2-resident) */
 } ope_index_params;
 void ope_index_default_params(ope_index_params *p);
 /* Replaces the kd-tree build of Registration::initCompute (registration_mod.hpp:80-84)
@@ -132,8 +139,11 @@ enum { /* DefaultConvergenceCriteria::ConvergenceState, default_convergence_crit
 enum { OPE_CORR_NEAREST = 0, OPE_CORR_NORMAL_SHOOTING = 1 };
 /* transformation estimation: SVD/Umeyama (poseestimator.cpp:306,341), or the linearised point-to-plane
  * estimator that IterativeClosestPointWithNormals defaults to (icp_mod.h:352-357; needs TARGET normals).
- * BuildModel selects the LM point-to-plane estimator (regmeshpcd.cpp:162,193): same cost, non-linear solve. */
-enum { OPE_EST_SVD = 0, OPE_EST_POINT_TO_PLANE_LLS = 1 };
+ * OPE_EST_POINT_TO_PLANE_LM: pcl::registration::TransformationEstimationPointToPlane, the Levenberg-Marquardt estimator
+ * BuildModel installs (regmeshpcd.cpp:162,193): same cost, minimised over (t, quaternion) with Eigen's LM logic on a
+ * forward-difference Jacobian and float tolerances; one device reduction per functor evaluation, the host is
+ * synchronised every iteration (ope_icp_run / ope_icp_iterate only; needs TARGET normals). */
+enum { OPE_EST_SVD = 0, OPE_EST_POINT_TO_PLANE_LLS = 1, OPE_EST_POINT_TO_PLANE_LM = 2 };
 #define OPE_NUM_SUMS 17     /* {n, Σs, Σt, Σ t sᵀ, Σd²} */
 #define OPE_NUM_SUMS_MAX 44 /* + upper triangle of AᵀA (21) and Aᵀb (6) for point-to-plane */
 

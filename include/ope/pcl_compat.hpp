@@ -337,11 +337,11 @@ template <class S, class T, class Scalar = float> struct TransformationEstimatio
   typedef std::shared_ptr<TransformationEstimationPointToPlaneLLS> Ptr;
   static constexpr int ope_estimator = OPE_EST_POINT_TO_PLANE_LLS;
 };
-// PCL's class of this name minimises the same error with Levenberg-Marquardt (regmeshpcd.cpp:162,193); here it
-// maps to the LLS solve, which has the same fixed points ("BuildModel loop").
+// PCL's class of this name minimises the same error with Levenberg-Marquardt over (t, quaternion)
+// (BuildModel regmeshpcd.cpp:162,193): OPE_EST_POINT_TO_PLANE_LM, csrc/lm.hip.
 template <class S, class T, class Scalar = float> struct TransformationEstimationPointToPlane {
   typedef std::shared_ptr<TransformationEstimationPointToPlane> Ptr;
-  static constexpr int ope_estimator = OPE_EST_POINT_TO_PLANE_LLS;
+  static constexpr int ope_estimator = OPE_EST_POINT_TO_PLANE_LM;
 };
 
 // DefaultConvergenceCriteria knobs the reference can reach through getConvergeCriteria()
@@ -418,7 +418,7 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
     p.mse_threshold_absolute = criteria_->mse_threshold_absolute_;
     p.failure_after_max_iter = criteria_->failure_after_max_iter_ ? 1 : 0;
     const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej ||
-                     p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
+                     p.estimator == OPE_EST_POINT_TO_PLANE_LLS || p.estimator == OPE_EST_POINT_TO_PLANE_LM;
     // uploads are cached between align() calls on the same clouds; a cache made without normals is of no use once a
     // rejector, normal shooting or the point-to-plane estimator has been added
     if (nrm && !uploaded_with_normals_) { src_dev_.reset(); tgt_dev_.reset(); tgt_index_.reset(); }

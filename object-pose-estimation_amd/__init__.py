@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "libope_hip.so")
 OPE_OK, OPE_EINVAL, OPE_ENODEV, OPE_EHIP, OPE_ENOMEM, OPE_ESTATE, OPE_ECOMM, OPE_EEMPTY, OPE_ERANGE = 0, -1, -2, -3, -4, -5, -6, -7, -8
 CONV_NAMES = ["NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE", "NO_CORRESPONDENCES"]
 CORR_NEAREST, CORR_NORMAL_SHOOTING = 0, 1
-EST_SVD, EST_POINT_TO_PLANE_LLS = 0, 1
+EST_SVD, EST_POINT_TO_PLANE_LLS, EST_POINT_TO_PLANE_LM = 0, 1, 2
 NUM_SUMS, NUM_SUMS_MAX = 17, 44
 COMM_ID_BYTES = 128
 
@@ -85,7 +85,7 @@ class KernelTime(C.Structure):
 
 
 class IndexParams(C.Structure):
-    _fields_ = [("leaf_size", C.c_int)]
+    _fields_ = [("leaf_size", C.c_int), ("grid", C.c_int), ("grid_fill", C.c_float), ("grid_max_cells", C.c_int)]
 
 
 class SaciaParams(C.Structure):
@@ -291,11 +291,16 @@ class Context:
         self._chk(lib().ope_cloud_upload(self.h, buf.ctypes.data_as(_vp), n, stride, xyz_off, normal_off, C.byref(h)))
         return Cloud(self, h, n)
 
-    def build_index(self, cloud: "Cloud", leaf_size: int | None = None) -> "Index":
+    def build_index(self, cloud: "Cloud", leaf_size: int | None = None, grid: bool | None = None, grid_fill: float = 0.0,
+                    grid_max_cells: int = 0) -> "Index":
         p = IndexParams()
         lib().ope_index_default_params(C.byref(p))
         if leaf_size:
             p.leaf_size = leaf_size
+        if grid is not None:
+            p.grid = int(grid)
+        p.grid_fill = grid_fill
+        p.grid_max_cells = grid_max_cells
         h = _vp()
         self._chk(lib().ope_index_build(self.h, cloud.h, C.byref(p), C.byref(h)))
         return Index(self, h, cloud)

@@ -5,12 +5,11 @@ Host-side mirror of `RegMeshPcd::getIcpNormal` (BuildModel/src/regmeshpcd.cpp:63
 stage is a C-ABI call into libope_hip.so (normals, index build, ICP loop, transform).  Meshing
 (`generateMesh`, :273-343) is out of scope.
 
-Differences a maintainer must know about, all recorded in DESIGN.md:
-  * the reference installs `TransformationEstimationPointToPlane` (Levenberg-Marquardt, :162,:193);
-    this path solves the same point-to-plane objective with the linear least-squares estimator
-    (`OPE_EST_POINT_TO_PLANE_LLS`, the `IterativeClosestPointWithNormals` default).  The two share
-    their fixed points; per-iteration increments differ, so parity for this row is against the oracle
-    run with the LLS estimator, not against the LM trajectory.
+Things a maintainer must know about, all recorded in DESIGN.md:
+  * the estimator is the reference's: `TransformationEstimationPointToPlane` (Levenberg-Marquardt, :162,:193) =
+    `OPE_EST_POINT_TO_PLANE_LM` (csrc/lm.hip: one device reduction per functor evaluation, Eigen's LM logic on the host).
+    `estimator="lls"` selects the linearised solve (`IterativeClosestPointWithNormals`' own default) instead: same
+    objective, no host synchronisation per iteration, but its increments are NOT within 1e-4 of LM's.
   * `p_maxCorrDist` only reaches the stand-alone `determineCorrespondences` call (:145) whose result
     the reference discards; the ICP object itself keeps PCL's default correspondence distance
     (sqrt(DBL_MAX)).  `use_max_corr_dist_in_icp=False` reproduces that.
@@ -39,7 +38,7 @@ class RegistrationResult:
     rgb: np.ndarray | None = None          # packed colours of `cloud`, when the frames came with colours
 
 
-def icp_params_with_normals(ope, corr_rej_thresh: float, max_iterations: int, max_corr_dist: float | None = None):
+def icp_params_with_normals(ope, corr_rej_thresh: float, max_iterations: int, max_corr_dist: float | None = None, estimator: str = "lm"):
     """The parameter block of getIcpNormal (regmeshpcd.cpp:142-194)."""
     kw = dict(max_iterations=int(max_iterations),            # :179
               transformation_epsilon=1e-8,                  # :182
@@ -48,14 +47,14 @@ def icp_params_with_normals(ope, corr_rej_thresh: float, max_iterations: int, ma
               k_normal_shooting=20,                         # :144
               use_surface_normal_rej=1,                     # :148-158,:190
               surface_normal_thr=float(corr_rej_thresh),    # :158
-              estimator=ope.EST_POINT_TO_PLANE_LLS)         # :162,:193 (LLS in place of LM, see module doc)
+              estimator=ope.EST_POINT_TO_PLANE_LM if estimator == "lm" else ope.EST_POINT_TO_PLANE_LLS)   # :162,:193
     if max_corr_dist is not None:
         kw["max_corr_dist"] = float(max_corr_dist)
     return ope.default_icp_params(**kw)
 
 
 def get_icp_normal(ope, ctx, source_xyz, target_xyz, corr_rej_thresh: float = 0.7, max_iterations: int = 500,
-                   max_corr_dist: float = 0.005, use_max_corr_dist_in_icp: bool = False, k_normals: int = 12):
+                   max_corr_dist: float = 0.005, use_max_corr_dist_in_icp: bool = False, k_normals: int = 12, estimator: str = "lm"):
     """One frame pair: normals(k=12) on both clouds -> ICP with normals -> aligned source.
 
     Returns (aligned_xyz, PairResult).  regmeshpcd.cpp:63-206.
@@ -68,7 +67,7 @@ def get_icp_normal(ope, ctx, source_xyz, target_xyz, corr_rej_thresh: float = 0.
         index = ctx.build_index(tgt)
         try:
             p = icp_params_with_normals(ope, corr_rej_thresh, max_iterations,
-                                        max_corr_dist if use_max_corr_dist_in_icp else None)
+                                        max_corr_dist if use_max_corr_dist_in_icp else None, estimator)
             out = ctx.icp(src, index, p)        # :196
             fit, _, _ = ctx.fitness(src, index, out.T)   # :198
             aligned = ctx.transform_cloud(src, out.T)    # :203
@@ -180,7 +179,9 @@ def get_icp_normal_sharded(ope, ctx, source_xyz, target_xyz, corr_rej_thresh: fl
         ctx.normals(tgt, k_normals, fetch=False)                       # :86-90
         index = ctx.build_index(tgt)
         try:
-            p = icp_params_with_normals(ope, corr_rej_thresh, max_iterations)
+            # the stepwise (torch.distributed) driver exchanges one fixed set of sums per iteration: the linearised
+            # estimator; the LM estimator shards through the library's own communicator (ope_icp_iterate)
+            p = icp_params_with_normals(ope, corr_rej_thresh, max_iterations, estimator="lls")
             eng = engine_cls(ope, ctx, src, index, p, None, len(source_xyz), len(target_xyz))
             out = sharded.run_sharded_icp(eng, max_iterations, check_every=p.check_every, group=group)   # :196
             aligned = ctx.transform_cloud(src_all, out.T)             # :203

@@ -22,8 +22,18 @@ void fill_iota(hipStream_t, uint32_t *, uint32_t);
 hipError_t morton_order_device(hipStream_t, const float *, size_t, const float[3], const float[3], float4 *, int32_t *);
 hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t, int, const float[3], const float[3], int *, float4 **,
                             float4 **, float4 **, float4 **);
+void launch_icp_accumulate_grid(hipStream_t, int, bool, const CloudView &, const BvhView &, const GridView &, const IcpState *, double *, int32_t *,
+                                float *, uint32_t *, uint32_t *, const uint32_t *, unsigned char *, const uint32_t *, uint32_t *, const uint32_t *,
+                                double *);
+int grid_plan(hipStream_t, bool, const unsigned char *, uint32_t, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, const uint32_t *,
+              uint32_t *, uint32_t, uint32_t, float, void *, size_t);
+size_t grid_plan_tmp_bytes(uint32_t, uint32_t);
+hipError_t build_grid_device(hipStream_t, const float4 *, const float4 *, size_t, const float[3], const float[3], double, uint32_t, GridView *,
+                             float4 **, float4 **, uint32_t **, uint32_t **);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
-void launch_icp_update(hipStream_t, IcpState *, double *, int);
+void launch_icp_update(hipStream_t, IcpState *, double *, int, const float *);
+int lm_point_to_plane(ope_ctx *, const CloudView &, const BvhView &, const int32_t *, double *, long long, float[16], int *);
+void launch_lm_pos_to_orig(hipStream_t, const BvhView &, int32_t *, uint32_t);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
 void launch_knn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int, int32_t *, float *);
 void launch_fitness(hipStream_t, int, const CloudView &, const BvhView &, const float *, double, double *);
@@ -32,6 +42,8 @@ void launch_pairs_svd(hipStream_t, const float *, const float *, uint32_t, doubl
 int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count);
 
 static thread_local std::string g_global_err;
+
+constexpr double kGridMaxTreeShare = 0.03;
 
 // Developer A/B switches and sweeps (tools/*.py) read the environment only in builds made with -DOPE_DEVELOPER
 // (`make DEVELOPER=1`); the product library has no environment-dependent behaviour on its launch path.
@@ -94,6 +106,56 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   const int it_done = ctx->acc_launches++;
   const uint32_t nch = (uint32_t)((ctx->run_src->n_valid + 63) / 64);
   static const int plan_every = [] { const char *e = dev_env("OPE_PLAN_EVERY"); return e ? std::max(1, atoi(e)) : 32; }();  // developer sweep
+  if (ctx->use_grid) {
+    // GRID instantiation (1-NN, no reciprocal check, device-built index).  Plan steps at the same launches as below;
+    // the query order is re-partitioned by class at launches 1, 2, 4 and then with every plan step.
+    const ope_icp_params &p = ctx->run_params;
+    const bool nrm = p.use_surface_normal_rej || p.use_self_occluded_rej || p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
+    const bool plan_step = !no_plan && nch > 1 && it_done >= 1 && (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0);
+    // Which path a run is better served by is measured, not guessed: the share of TREE-class queries (far from the
+    // surface: the grid cannot answer them and each is a long private walk) is read back asynchronously after the plan
+    // steps.  Above kGridMaxTreeShare the run continues on the tree kernel, whose packet / per-lane / group scheduling
+    // is built around exactly that mix (C3 frame, 9 % clutter: 269 us per iteration against 283 us here; the
+    // clutter-free cluster of the same frame: 110 us on the tree kernel, 78 us here).
+    if (ctx->grid_probe_pending && hipEventQuery(ctx->grid_probe_event) == hipSuccess) {
+      ctx->grid_probe_pending = false;
+      const uint32_t n_grid_q = *ctx->h_grid_probe;
+      const double tree_share = 1.0 - (double)n_grid_q / (double)std::max<size_t>(ctx->run_src->n_valid, 1);
+      if (tree_share > kGridMaxTreeShare && ctx->run_tgt->grid_mode != 2) {
+        ctx->use_grid = false;
+        ctx->plan_valid = false;   // chunk ids mean something else to the tree kernel
+        OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * (size_t)(nch + 1), ctx->stream));
+        OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 8, 0, 8, ctx->stream));
+        --ctx->acc_launches;
+        return enqueue_accumulate(ctx, atomic_sums);
+      }
+    }
+    if (plan_step) {
+      static const float heavy_env = [] { const char *e = dev_env("OPE_HEAVY_FACTOR"); return e ? (float)atof(e) : -1.0f; }();
+      const bool repart = it_done <= 4 || it_done % plan_every == 0;
+      if (grid_plan(ctx->stream, repart, ctx->d_qclass, (uint32_t)ctx->run_src->n_valid, ctx->d_qorder, ctx->d_work_counter + 8, ctx->d_chunk_cost,
+                    ctx->d_chunk_keys, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
+                    (uint32_t)ctx->acc_blocks * (kAccBlock / 64), heavy_env, ctx->d_part_tmp, ctx->part_tmp_bytes) != 0)
+        return set_err(ctx, OPE_EHIP, "grid plan step failed");
+      ctx->plan_valid = true;
+      if (repart && it_done >= 2 && !ctx->grid_probe_pending && ctx->grid_probe_event) {
+        OPE_HIP(ctx, hipMemcpyAsync(ctx->h_grid_probe, ctx->d_work_counter + 9, 4, hipMemcpyDeviceToHost, ctx->stream));
+        OPE_HIP(ctx, hipEventRecord(ctx->grid_probe_event, ctx->stream));
+        ctx->grid_probe_pending = true;
+      }
+    }
+    const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
+    if (timed) OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], ctx->stream));
+    launch_icp_accumulate_grid(ctx->stream, ctx->acc_blocks, nrm, ctx->run_src->view(), ctx->run_tgt->view(), ctx->run_tgt->grid, ctx->d_state,
+                               ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_hint, ctx->d_ghint, ctx->d_qorder, ctx->d_qclass,
+                               ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8,
+                               atomic_sums ? sums_ptr(ctx) : nullptr);
+    if (timed) {
+      OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
+      ++ctx->prof_used;
+    }
+    return OPE_OK;
+  }
   if (!no_plan && nch > 1 && it_done >= 1 && (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0)) {
     size_t tb = ctx->plan_tmp_bytes;
     if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
@@ -112,7 +174,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   }
   const ope_icp_params &p = ctx->run_params;
   const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej ||
-                   p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
+                   p.estimator == OPE_EST_POINT_TO_PLANE_LLS;   // (LM reads the target normals in its own kernel)
   const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
   if (timed) OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], ctx->stream));
   const bool recip = p.use_reciprocal != 0;
@@ -189,6 +251,10 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
   if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
   if (ctx->d_hint) (void)hipFree(ctx->d_hint);
+  for (void *p : {(void *)ctx->d_ghint, (void *)ctx->d_qorder, (void *)ctx->d_qclass, ctx->d_part_tmp, (void *)ctx->d_chunk_keys})
+    if (p) (void)hipFree(p);
+  if (ctx->grid_probe_event) (void)hipEventDestroy(ctx->grid_probe_event);
+  if (ctx->h_grid_probe) (void)hipHostFree(ctx->h_grid_probe);
   for (void *p : {(void *)ctx->d_chunk_cost, (void *)ctx->d_chunk_cost_sorted, (void *)ctx->d_chunk_ids,
                   (void *)ctx->d_chunk_order, ctx->d_plan_tmp})
     if (p) (void)hipFree(p);
@@ -319,7 +385,7 @@ void ope_cloud_free(ope_cloud *cloud) {
 
 // ------------------------------------------------------------------------------------------ index
 void ope_index_default_params(ope_index_params *p) {
-  if (p) p->leaf_size = 16;
+  if (p) { p->leaf_size = 16; p->grid = 1; p->grid_fill = 0.f; p->grid_max_cells = 0; }
 }
 
 int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_params *params, ope_index **out) {
@@ -349,6 +415,12 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
       ope_index_free(ix);
       return set_err(ctx, OPE_EHIP, std::string("ope_index_build: ") + hipGetErrorString(e));
     }
+    // the bucketed side of the index (grid_build.hip) is built by the first 1-NN ICP run that uses this index: the
+    // indexes behind normals, FPFH and the filters never need it
+    ix->want_grid = dp.grid != 0;
+    ix->grid_mode = dp.grid;
+    ix->grid_fill = dp.grid_fill;
+    ix->grid_max_cells = dp.grid_max_cells;
     *out = ix;
     return OPE_OK;
   }
@@ -407,6 +479,8 @@ void ope_index_free(ope_index *index) {
   if (index->d_pts) (void)hipFree(index->d_pts);
   if (index->d_nrm) (void)hipFree(index->d_nrm);
   if (index->d_axis2) (void)hipFree(index->d_axis2);
+  for (void *p : {(void *)index->d_gpts, (void *)index->d_gnrm, (void *)index->d_cell_start, (void *)index->d_gpos})
+    if (p) (void)hipFree(p);
   delete index;
 }
 
@@ -518,6 +592,23 @@ int ope_icp_set_global_sizes(ope_ctx *ctx, int64_t n_src_total, int64_t n_tgt_to
 
 static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float *guess, const ope_icp_params *params);
 
+// The uniform grid over an index's points, built on first use (the handle is logically const for its callers: the grid
+// is a cache over the same points).
+static int ensure_grid(ope_ctx *ctx, const ope_index *cix) {
+  ope_index *ix = const_cast<ope_index *>(cix);
+  if (ix->has_grid || !ix->want_grid || !ix->d_pts) return OPE_OK;
+  TraceRange r(ctx, "grid_build");
+  const hipError_t eg = build_grid_device(ctx->stream, ix->d_pts, ix->d_nrm, ix->n, ix->bb_lo, ix->bb_hi, ix->grid_fill, (uint32_t)std::max(ix->grid_max_cells, 0), &ix->grid, &ix->d_gpts, &ix->d_gnrm,
+                                          &ix->d_cell_start, &ix->d_gpos);
+  if (eg != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_icp_begin(grid build): ") + hipGetErrorString(eg));
+  ix->grid.gpts = ix->d_gpts; ix->grid.gnrm = ix->d_gnrm; ix->grid.cell_start = ix->d_cell_start; ix->grid.gpos_of_bvhpos = ix->d_gpos;
+  float amax = 0.f;
+  for (int d = 0; d < 3; ++d) amax = std::max({amax, std::fabs(ix->bb_lo[d]), std::fabs(ix->bb_hi[d])});
+  ix->grid.eps = 4e-7f * amax + 1e-30f;
+  ix->has_grid = true;
+  return OPE_OK;
+}
+
 int ope_icp_begin(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const float *guess,
                   const ope_icp_params *params) {
   const int rc = icp_begin_impl(ctx, src, tgt, guess, params);
@@ -537,7 +628,9 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: reciprocal correspondences are defined for 1-NN estimation only");
   const bool need_src_nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej;
   if (need_src_nrm && !src->d_nrm) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: source normals required but absent");
-  if (p.estimator == OPE_EST_POINT_TO_PLANE_LLS && !tgt->d_nrm)
+  if (p.estimator != OPE_EST_SVD && p.estimator != OPE_EST_POINT_TO_PLANE_LLS && p.estimator != OPE_EST_POINT_TO_PLANE_LM)
+    return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown estimator");
+  if ((p.estimator == OPE_EST_POINT_TO_PLANE_LLS || p.estimator == OPE_EST_POINT_TO_PLANE_LM) && !tgt->d_nrm)
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: the point-to-plane estimator needs target normals (build the index from a cloud with normals)");
   if (p.use_surface_normal_rej && !tgt->d_nrm)
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: target normals required (build the index from a cloud with normals)");
@@ -563,6 +656,34 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_hint, sizeof(uint32_t) * std::max<size_t>(src->n, 1)));
     ctx->corr_cap = std::max<size_t>(src->n, 1);
   }
+  ctx->use_grid = false;
+  if (p.corr_mode == OPE_CORR_NEAREST && !p.use_reciprocal && tgt->want_grid && src->n_valid > 0 && p.estimator != OPE_EST_POINT_TO_PLANE_LM) {
+    const int rcg = ensure_grid(ctx, tgt);
+    if (rcg != OPE_OK) return rcg;
+    ctx->use_grid = tgt->has_grid;
+  }
+  if (ctx->use_grid) {
+    const size_t cap = std::max<size_t>(src->n, 1);
+    if (ctx->grid_cap < cap) {
+      for (void *q : {(void *)ctx->d_ghint, (void *)ctx->d_qorder, (void *)ctx->d_qclass, ctx->d_part_tmp})
+        if (q) (void)hipFree(q);
+      ctx->d_ghint = ctx->d_qorder = nullptr; ctx->d_qclass = nullptr; ctx->d_part_tmp = nullptr; ctx->grid_cap = 0;
+      OPE_HIP(ctx, hipMalloc((void **)&ctx->d_ghint, 4 * cap));
+      OPE_HIP(ctx, hipMalloc((void **)&ctx->d_qorder, 4 * cap));
+      OPE_HIP(ctx, hipMalloc((void **)&ctx->d_qclass, cap));
+      ctx->part_tmp_bytes = grid_plan_tmp_bytes((uint32_t)cap, (uint32_t)(cap / 64 + 2));
+      OPE_HIP(ctx, hipMalloc(&ctx->d_part_tmp, ctx->part_tmp_bytes));
+      ctx->grid_cap = cap;
+    }
+    if (!ctx->grid_probe_event) {
+      OPE_HIP(ctx, hipEventCreateWithFlags(&ctx->grid_probe_event, hipEventDisableTiming));
+      OPE_HIP(ctx, hipHostMalloc((void **)&ctx->h_grid_probe, 64));
+    }
+    ctx->grid_probe_pending = false;
+    OPE_HIP(ctx, hipMemsetAsync(ctx->d_ghint, 0, 4 * cap, ctx->stream));
+    OPE_HIP(ctx, hipMemsetAsync(ctx->d_qclass, 0, cap, ctx->stream));
+    fill_iota(ctx->stream, ctx->d_qorder, (uint32_t)cap);
+  }
   // every slot starts as "no correspondence" (non-finite points never get written)
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_corr_match, 0xff, sizeof(int32_t) * std::max<size_t>(src->n, 1), ctx->stream));
   {
@@ -576,6 +697,9 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
       ctx->chunk_cap = 0;
       OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_cost, 4 * nch));
       OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_cost_sorted, 4 * nch));
+      if (ctx->d_chunk_keys) (void)hipFree(ctx->d_chunk_keys);
+      ctx->d_chunk_keys = nullptr;
+      OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_keys, 4 * nch));
       OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_ids, 4 * nch));
       OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_order, 4 * nch));
       size_t tb = 0;
@@ -666,6 +790,8 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
 
 int ope_icp_accumulate(ope_ctx *ctx) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_accumulate: no run in progress");
+  if (ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LM)
+    return set_err(ctx, OPE_EINVAL, "ope_icp_accumulate: the LM estimator iterates inside ope_icp_iterate / ope_icp_run (it reduces over the correspondences several times per iteration)");
   const bool atomic = atomic_sums(ctx);
   int rc = enqueue_accumulate(ctx, atomic);
   if (rc != OPE_OK) return rc;
@@ -705,17 +831,44 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
     }
     if (rc != OPE_OK) return rc;
     TraceRange r_red(ctx, "reduce");
+    if (ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LM) {
+      // correspondences are in place (corr_match = index positions); their 17 sums give n and the MSE
+      if (!atomic)
+        launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
+      if (sharded) {
+        rc = comm_allreduce_sums(ctx, sums_ptr(ctx), kNumSums);
+        if (rc != OPE_OK) return rc;
+      }
+      double n_corr = 0;
+      int done = 0;
+      OPE_HIP(ctx, hipMemcpyAsync(&n_corr, sums_ptr(ctx), sizeof n_corr, hipMemcpyDeviceToHost, ctx->stream));
+      OPE_HIP(ctx, hipMemcpyAsync(&done, reinterpret_cast<unsigned char *>(ctx->d_state) + offsetof(IcpState, done), sizeof done, hipMemcpyDeviceToHost, ctx->stream));
+      OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (done) continue;   // the accumulate launch was a no-op: the run has ended
+      float Tk[16];
+      int nfev = 0;
+      rc = ensure_scratch(ctx, 1 << 16);
+      if (rc != OPE_OK) return rc;
+      double *d_lm = reinterpret_cast<double *>(static_cast<unsigned char *>(ctx->d_scratch) + 1024);
+      float *d_Tk = reinterpret_cast<float *>(static_cast<unsigned char *>(ctx->d_scratch) + 2048);
+      rc = lm_point_to_plane(ctx, ctx->run_src->view(), ctx->run_tgt->view(), ctx->d_corr_match, d_lm, (long long)n_corr, Tk, &nfev);
+      if (rc != OPE_OK) return rc;
+      OPE_HIP(ctx, hipMemcpyAsync(d_Tk, Tk, sizeof Tk, hipMemcpyHostToDevice, ctx->stream));
+      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), kNumSums, d_Tk);
+      OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));   // Tk lives on this stack frame until the copy has been issued and consumed
+      continue;
+    }
     if (sharded) {
       if (!atomic)
         launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
       rc = comm_allreduce_sums(ctx, sums_ptr(ctx), ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LLS ? kNumSumsMax : kNumSums);
       if (rc != OPE_OK) return rc;
-      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx));
+      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx), nullptr);
     } else if (atomic) {
-      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx));
+      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx), nullptr);
     } else if (split_update) {
       launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
-      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx));
+      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx), nullptr);
     } else {
       launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, true, ctx->d_work_counter);
     }
@@ -754,7 +907,7 @@ int ope_icp_profile_read(ope_ctx *ctx, double *total_ms, int *n_launches) {
 
 int ope_icp_update(ope_ctx *ctx) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_update: no run in progress");
-  launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx));
+  launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx), nullptr);
   OPE_HIP(ctx, hipGetLastError());
   ++ctx->iters_enqueued;
   return OPE_OK;
@@ -838,7 +991,17 @@ int ope_icp_correspondences(ope_ctx *ctx, int32_t *index_query, int32_t *index_m
   std::vector<float> hd(n);
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   if (n) {
-    OPE_HIP(ctx, hipMemcpyAsync(hm.data(), ctx->d_corr_match, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    int32_t *d_match = ctx->d_corr_match;
+    int32_t *d_tmp_match = nullptr;
+    if (ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LM && ctx->run_tgt) {
+      // LM runs keep index positions in corr_match: translate a copy to original target indices
+      OPE_HIP(ctx, hipMalloc((void **)&d_tmp_match, sizeof(int32_t) * n));
+      OPE_HIP(ctx, hipMemcpyAsync(d_tmp_match, ctx->d_corr_match, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, ctx->stream));
+      launch_lm_pos_to_orig(ctx->stream, ctx->run_tgt->view(), d_tmp_match, (uint32_t)src->n_valid);
+      d_match = d_tmp_match;
+    }
+    struct FreeTmp { int32_t *p; ~FreeTmp() { if (p) (void)hipFree(p); } } free_tmp{d_tmp_match};
+    OPE_HIP(ctx, hipMemcpyAsync(hm.data(), d_match, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
     OPE_HIP(ctx, hipMemcpyAsync(hd.data(), ctx->d_corr_d2, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
     OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }

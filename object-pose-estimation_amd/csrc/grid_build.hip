@@ -14,6 +14,7 @@
 // occupancy), and grown until the table has at most kGridMaxCells cells (it must stay L2-resident: 4 B per cell).
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include <rocprim/rocprim.hpp>
 
@@ -21,8 +22,8 @@
 
 namespace ope {
 
-constexpr double kGridTargetFill = 6.0;
-constexpr uint32_t kGridMaxCells = 1u << 20;   // 4 MB of cell starts at most
+constexpr double kGridDefaultFill = 6.0;
+constexpr uint32_t kGridDefaultMaxCells = 1u << 20;   // 4 MB of cell starts at most
 
 __device__ __forceinline__ uint32_t grid_cell_of(const GridView &g, float x, float y, float z) {
   // the same expression, in the same order, as the query side uses for its cell ranges (monotone in x, y, z)
@@ -80,7 +81,7 @@ static hipError_t grid_sort(hipStream_t stream, const GridView &g, const float4 
   return e;
 }
 
-static void grid_dims(GridView &g, const float lo[3], const float hi[3], double cell) {
+static void grid_dims(GridView &g, const float lo[3], const float hi[3], double cell, uint32_t kGridMaxCells) {
   for (;;) {
     g.inv = (float)(1.0 / cell);
     unsigned long long cells = 1;
@@ -96,10 +97,12 @@ static void grid_dims(GridView &g, const float lo[3], const float hi[3], double 
 
 // d_pts: the index's points in BVH order (n entries, w = original index), d_nrm optional.
 hipError_t build_grid_device(hipStream_t stream, const float4 *d_pts, const float4 *d_nrm, size_t n_, const float bb_lo[3],
-                             const float bb_hi[3], GridView *out, float4 **out_gpts, float4 **out_gnrm, uint32_t **out_cell_start,
+                             const float bb_hi[3], double fill_target, uint32_t max_cells, GridView *out, float4 **out_gpts, float4 **out_gnrm, uint32_t **out_cell_start,
                              uint32_t **out_gpos) {
   const uint32_t n = (uint32_t)n_;
   *out_gpts = nullptr; *out_gnrm = nullptr; *out_cell_start = nullptr; *out_gpos = nullptr;
+  const double kGridTargetFill = fill_target > 0 ? fill_target : kGridDefaultFill;
+  const uint32_t kGridMaxCells = max_cells > 0 ? max_cells : kGridDefaultMaxCells;
   GridView g{};
   // first guess: a surface sample — n points over an area of about (bbox diagonal)^2 / 3
   const double ex = (double)bb_hi[0] - bb_lo[0], ey = (double)bb_hi[1] - bb_lo[1], ez = (double)bb_hi[2] - bb_lo[2];
@@ -122,7 +125,7 @@ hipError_t build_grid_device(hipStream_t stream, const float4 *d_pts, const floa
   if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16));
   uint32_t occupied = 0;
   for (int pass = 0; e == hipSuccess && pass < 3; ++pass) {
-    grid_dims(g, bb_lo, bb_hi, cell);
+    grid_dims(g, bb_lo, bb_hi, cell, kGridMaxCells);
     e = grid_sort(stream, g, d_pts, n, d_keys, d_keys2, d_vals, d_vals2, d_count, d_tmp, tmp_bytes, &occupied);
     if (e != hipSuccess || pass == 2) break;
     const double fill = (double)n / std::max<uint32_t>(occupied, 1);
@@ -131,7 +134,7 @@ hipError_t build_grid_device(hipStream_t stream, const float4 *d_pts, const floa
     const double want = std::sqrt(kGridTargetFill / fill);
     const double next = (double)(1.0 / g.inv) * std::min(4.0, std::max(0.25, want));
     GridView t{};
-    grid_dims(t, bb_lo, bb_hi, next);
+    grid_dims(t, bb_lo, bb_hi, next, kGridMaxCells);
     if (t.inv == g.inv) break;   // the table-size cap decides
     cell = next;
   }

@@ -23,6 +23,63 @@ namespace ope {
 
 typedef const __attribute__((address_space(3))) float *lds_cfloat_ptr;   // a pointer that stays an LDS pointer
 
+// One query's contribution to the wave's running sums {n, Σs, Σt, Σ t sᵀ, Σd²} (+ 27 normal-equation sums with the
+// point-to-plane estimator): 16-lane row sums by DPP, then one ds_add_f64 per row and component into `acc` (LDS).
+// t: the matched target point, tn: its normal (point-to-plane only); lanes with ok == false contribute zeros.
+template <bool NRM>
+__device__ __forceinline__ void add_query_sums(double *acc, lds_cfloat_ptr cs2, uint32_t lane_id, bool ok, bool p2p, float x, float y, float z,
+                                               const float4 t, const float4 tn, float d2) {
+    {
+      // fp64 terms: differences and products of fp32 values are exact in fp64, so the 17 sums do not
+      // depend (beyond 1e-16) on how queries are grouped into lanes, chunks, waves or ranks
+      asm volatile("" : "+v"(cs2));
+      const float psx = cs2[12], psy = cs2[13], psz = cs2[14];
+      const double sx = (double)x - (double)psx, sy = (double)y - (double)psy, sz = (double)z - (double)psz;
+      const double tx = (double)t.x - (double)psx, ty = (double)t.y - (double)psy, tz = (double)t.z - (double)psz;
+      // 16-lane row sums by DPP (pure VALU), then one ds_add_f64 per row and component into the wave's
+      // 17 LDS slots (a full 64-lane fp64 butterfly cost ~200 dependent ds_bpermutes per chunk)
+      const double w = ok ? 1.0 : 0.0;
+      double term[kNumSums];
+      term[0] = w;
+      term[1] = w * sx; term[2] = w * sy; term[3] = w * sz;
+      term[4] = w * tx; term[5] = w * ty; term[6] = w * tz;
+      term[7] = w * (tx * sx); term[8] = w * (tx * sy); term[9] = w * (tx * sz);
+      term[10] = w * (ty * sx); term[11] = w * (ty * sy); term[12] = w * (ty * sz);
+      term[13] = w * (tz * sx); term[14] = w * (tz * sy); term[15] = w * (tz * sz);
+      term[16] = ok ? (double)d2 : 0.0;
+#pragma unroll
+      for (int k = 0; k < kNumSums; ++k) {
+        const double r = row16_sum(term[k]);
+        if ((lane_id & 15u) == 0u) unsafeAtomicAdd(acc + k, r);
+      }
+      if (NRM && p2p) {
+        // TransformationEstimationPointToPlaneLLS: row v = (s x n, n), right-hand side d = n . (t - s);
+        // the reference forms these products in float (operands are const float&), sums in double
+        const float v0 = __fsub_rn(__fmul_rn(tn.z, y), __fmul_rn(tn.y, z));
+        const float v1 = __fsub_rn(__fmul_rn(tn.x, z), __fmul_rn(tn.z, x));
+        const float v2 = __fsub_rn(__fmul_rn(tn.y, x), __fmul_rn(tn.x, y));
+        const float dd = __fsub_rn(__fsub_rn(__fsub_rn(__fadd_rn(__fadd_rn(__fmul_rn(tn.x, t.x), __fmul_rn(tn.y, t.y)), __fmul_rn(tn.z, t.z)),
+                                                         __fmul_rn(tn.x, x)), __fmul_rn(tn.y, y)), __fmul_rn(tn.z, z));
+        const double v[6] = {w * (double)v0, w * (double)v1, w * (double)v2, w * (double)tn.x, w * (double)tn.y, w * (double)tn.z};
+        int slot = kNumSums;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = r; c < 6; ++c) {
+            const double sum = row16_sum(v[r] * v[c]);
+            if ((lane_id & 15u) == 0u) unsafeAtomicAdd(acc + slot, sum);
+            ++slot;
+          }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          const double sum = row16_sum(v[r] * (double)dd);
+          if ((lane_id & 15u) == 0u) unsafeAtomicAdd(acc + slot, sum);
+          ++slot;
+        }
+      }
+    }
+}
+
 // MODE 0: 1-NN correspondences.  MODE 1: normal shooting over the k nearest (list in LDS, any k <= 32).
 // MODE 2: the same for k = 20, the value the reference uses (poseestimator.cpp:246, regmeshpcd.cpp:144): list in
 // registers, walk started at last iteration's leaf.  MODE 3: the same for k = 10, the class default
@@ -65,6 +122,8 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   __syncthreads();
   const bool rej_sn = NRM && st->use_surface_normal_rej;
   const bool rej_so = NRM && st->use_self_occluded_rej;
+  // the LM estimator (lm.hip) re-reads the matched target points: corr_match then holds their POSITION in the index
+  const bool store_pos = st->estimator == OPE_EST_POINT_TO_PLANE_LM;
   const double thr_sn = st->surface_normal_thr, thr_so = st->self_occluded_thr;
   const double max_dist_unsq = st->max_corr_dist;
   const int kk = st->k_normal_shooting;
@@ -139,7 +198,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       ok = found && !((double)v.best > max_d2);
       d2 = found ? v.best : INFINITY;
       pos = found ? v.pos : 0;
-      match = found ? __float_as_int(tgt.pts[pos].w) : -1;
+      match = found ? (store_pos ? (int)pos : __float_as_int(tgt.pts[pos].w)) : -1;
       if (RECIP) {
         float G[12];
 #pragma unroll
@@ -176,7 +235,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       }
       // quirk Q2: squared line distance against the UNSQUARED max distance (:136)
       ok = active && v.count > 0 && !(min_dist > max_dist_unsq);
-      match = v.count > 0 ? __float_as_int(tgt.pts[pos].w) : -1;
+      match = v.count > 0 ? (store_pos ? (int)pos : __float_as_int(tgt.pts[pos].w)) : -1;
     } else {
       float *ld = reinterpret_cast<float *>(s_dyn) + threadIdx.x;
       uint32_t *lp = reinterpret_cast<uint32_t *>(s_dyn + sizeof(float) * BLOCK * kKnnMaxK) + threadIdx.x;
@@ -199,7 +258,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       ok = active && v.count > 0 && !(min_dist > max_dist_unsq);
       d2 = v.count > 0 ? ld[min_j * BLOCK] : INFINITY;
       pos = v.count > 0 ? lp[min_j * BLOCK] : 0;
-      match = v.count > 0 ? __float_as_int(tgt.pts[pos].w) : -1;
+      match = v.count > 0 ? (store_pos ? (int)pos : __float_as_int(tgt.pts[pos].w)) : -1;
     }
     if (NRM && ok && rej_sn) {
       const float4 tn = tgt.nrm[pos];
@@ -216,59 +275,8 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       __builtin_nontemporal_store(ok ? match : -1, corr_match + i);   // streamed out: nothing re-reads them in this launch
       __builtin_nontemporal_store(d2, corr_d2 + i);
     }
-    {
-      // fp64 terms: differences and products of fp32 values are exact in fp64, so the 17 sums do not
-      // depend (beyond 1e-16) on how queries are grouped into lanes, chunks, waves or ranks
-      const float4 t = tgt.pts[ok ? pos : 0];
-      lds_cfloat_ptr cs2 = (lds_cfloat_ptr)s_const;
-      asm volatile("" : "+v"(cs2));
-      const float psx = cs2[12], psy = cs2[13], psz = cs2[14];
-      const double sx = (double)x - (double)psx, sy = (double)y - (double)psy, sz = (double)z - (double)psz;
-      const double tx = (double)t.x - (double)psx, ty = (double)t.y - (double)psy, tz = (double)t.z - (double)psz;
-      // 16-lane row sums by DPP (pure VALU), then one ds_add_f64 per row and component into the wave's
-      // 17 LDS slots (a full 64-lane fp64 butterfly cost ~200 dependent ds_bpermutes per chunk)
-      const double w = ok ? 1.0 : 0.0;
-      double term[kNumSums];
-      term[0] = w;
-      term[1] = w * sx; term[2] = w * sy; term[3] = w * sz;
-      term[4] = w * tx; term[5] = w * ty; term[6] = w * tz;
-      term[7] = w * (tx * sx); term[8] = w * (tx * sy); term[9] = w * (tx * sz);
-      term[10] = w * (ty * sx); term[11] = w * (ty * sy); term[12] = w * (ty * sz);
-      term[13] = w * (tz * sx); term[14] = w * (tz * sy); term[15] = w * (tz * sz);
-      term[16] = ok ? (double)d2 : 0.0;
-      double *acc = s_red[threadIdx.x >> 6];
-#pragma unroll
-      for (int k = 0; k < kNumSums; ++k) {
-        const double r = row16_sum(term[k]);
-        if ((lane_id & 15u) == 0u) unsafeAtomicAdd(acc + k, r);
-      }
-      if (NRM && p2p) {
-        // TransformationEstimationPointToPlaneLLS: row v = (s x n, n), right-hand side d = n . (t - s);
-        // the reference forms these products in float (operands are const float&), sums in double
-        const float4 tn = tgt.nrm[ok ? pos : 0];
-        const float v0 = __fsub_rn(__fmul_rn(tn.z, y), __fmul_rn(tn.y, z));
-        const float v1 = __fsub_rn(__fmul_rn(tn.x, z), __fmul_rn(tn.z, x));
-        const float v2 = __fsub_rn(__fmul_rn(tn.y, x), __fmul_rn(tn.x, y));
-        const float dd = __fsub_rn(__fsub_rn(__fsub_rn(__fadd_rn(__fadd_rn(__fmul_rn(tn.x, t.x), __fmul_rn(tn.y, t.y)), __fmul_rn(tn.z, t.z)),
-                                                         __fmul_rn(tn.x, x)), __fmul_rn(tn.y, y)), __fmul_rn(tn.z, z));
-        const double v[6] = {w * (double)v0, w * (double)v1, w * (double)v2, w * (double)tn.x, w * (double)tn.y, w * (double)tn.z};
-        int slot = kNumSums;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-          for (int c = r; c < 6; ++c) {
-            const double sum = row16_sum(v[r] * v[c]);
-            if ((lane_id & 15u) == 0u) unsafeAtomicAdd(acc + slot, sum);
-            ++slot;
-          }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          const double sum = row16_sum(v[r] * (double)dd);
-          if ((lane_id & 15u) == 0u) unsafeAtomicAdd(acc + slot, sum);
-          ++slot;
-        }
-      }
-    }
+    add_query_sums<NRM>(s_red[threadIdx.x >> 6], (lds_cfloat_ptr)s_const, lane_id, ok, p2p, x, y, z, tgt.pts[ok ? pos : 0],
+                        (NRM && p2p) ? tgt.nrm[ok ? pos : 0] : make_float4(0.f, 0.f, 0.f, 0.f), d2);
     if (lane_id == 0 && !oct) chunk_cost[chunk] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
   }
 
@@ -281,6 +289,226 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     // One-GPU runs keep one row per block and reduce the rows in a fixed tree (bit-reproducible for a launch
     // geometry).  Sharded runs add straight into the 17 (44) sums that the all-reduce takes next: one launch and one
     // kernel boundary less per iteration, at the price of an addition order that varies from run to run (1e-16).
+    if (S_atomic != nullptr) unsafeAtomicAdd(S_atomic + threadIdx.x, v);
+    else partials[threadIdx.x * kAccMaxBlocks + blockIdx.x] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// GRID instantiation of the 1-NN accumulate step (north_star's "radix-bucketed nearest neighbour").
+//
+// The typical ICP query is a scene point whose previous match t_prev is still (nearly) its nearest neighbour.  Then
+// every model point that can beat it lies in the ball |x - q| <= |q - t_prev|, and the ball overlaps only a handful of
+// cells of the uniform grid over the model (grid_build.hip): at most kGridMaxRows x-runs of at most kGridMaxX cells,
+// each ONE contiguous run of the cell-sorted points.  Exact by construction: the cell range of the ball is computed with
+// the same monotone fp32 expression that assigned the points to cells, from a radius inflated past every rounding, and
+// every point of those runs is tested with the oracle's unfused distance.  Two dependent fetches (cell bounds, points)
+// instead of the ~15 of a tree walk, ~20-60 distance evaluations, no LDS.
+// Queries the grid cannot answer (no previous match yet, or a ball that spans more cells: clutter far from the surface)
+// take the OBB-tree walk of bvh_traverse.hpp, seeded with the previous match's distance.  So that those few do not hold
+// up whole waves of grid queries, the launch works through a query ORDER (qorder) that lists the grid-class queries
+// first and the tree-class queries after them, re-partitioned from the per-query class flags at the plan steps; a query
+// whose class has changed since is simply served by the other path, in place.
+constexpr int kGridMaxRows = 4;   // (y, z) rows of cells a query may touch
+constexpr int kGridMaxX = 3;      // cells per row
+
+__device__ __forceinline__ void grid_axis_range(float c, float r, float lo, float inv, int dim, int &a, int &b) {
+  // same expression as grid_cell_of (grid_build.hip): floor((x - lo) * inv), monotone in x
+  a = max((int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(c, r), lo), inv)), 0);
+  b = min((int)floorf(__fmul_rn(__fsub_rn(__fadd_rn(c, r), lo), inv)), dim - 1);
+}
+
+// best / gpos come in holding the previous match (distance, sorted position) and go out holding the nearest neighbour.
+// Returns false, having changed nothing, if the ball spans more cells than the scan is built for.
+__device__ __forceinline__ bool grid_scan(const GridView &g, float qx, float qy, float qz, float &best, uint32_t &gpos) {
+  const float r = __fadd_rn(__fmul_rn(__fsqrt_rn(best), 1.0005f), g.eps);
+  int ax, bx, ay, by, az, bz;
+  grid_axis_range(qx, r, g.lo[0], g.inv, g.dim[0], ax, bx);
+  grid_axis_range(qy, r, g.lo[1], g.inv, g.dim[1], ay, by);
+  grid_axis_range(qz, r, g.lo[2], g.inv, g.dim[2], az, bz);
+  const int ny = by - ay + 1, nz = bz - az + 1, nrow = ny * nz;
+  if (ny <= 0 || nz <= 0 || bx < ax) return true;   // the ball misses the box: the previous match stands
+  if (nrow > kGridMaxRows || bx - ax + 1 > kGridMaxX) return false;
+  // bounds of every row first (independent fetches), then the runs; rows in (y fastest, z) order, rows past nrow repeat
+  // the last one (their runs are not scanned)
+  uint32_t rs[kGridMaxRows], re[kGridMaxRows];
+  {
+    int iy = ay, iz = az;
+#pragma unroll
+    for (int k = 0; k < kGridMaxRows; ++k) {
+      const uint32_t row = ((uint32_t)iz * (uint32_t)g.dim[1] + (uint32_t)iy) * (uint32_t)g.dim[0];
+      rs[k] = g.cell_start[row + (uint32_t)ax];
+      re[k] = g.cell_start[row + (uint32_t)bx + 1u];
+      if (k + 1 < nrow) {
+        const bool wrap = iy == by;
+        iy = wrap ? ay : iy + 1;
+        iz += wrap ? 1 : 0;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kGridMaxRows; ++k) {
+    if (k < nrow) {
+      for (uint32_t p = rs[k]; p < re[k]; p += 4) {
+        // four 16-byte loads from one base; a batch may run past the run (guarded) and, at the very end of the array,
+        // into the kPtsPad zeroed entries
+        const float4 *pb = g.gpts + p;
+        const v4f p0 = ld16(pb), p1 = ld16(pb + 1), p2 = ld16(pb + 2), p3 = ld16(pb + 3);
+        const float d0 = sq_dist3(__fsub_rn(qx, p0.x), __fsub_rn(qy, p0.y), __fsub_rn(qz, p0.z));
+        const float d1 = sq_dist3(__fsub_rn(qx, p1.x), __fsub_rn(qy, p1.y), __fsub_rn(qz, p1.z));
+        const float d2 = sq_dist3(__fsub_rn(qx, p2.x), __fsub_rn(qy, p2.y), __fsub_rn(qz, p2.z));
+        const float d3 = sq_dist3(__fsub_rn(qx, p3.x), __fsub_rn(qy, p3.y), __fsub_rn(qz, p3.z));
+        const uint32_t e = re[k];
+        if (d0 < best) { best = d0; gpos = p; }
+        if (p + 1 < e && d1 < best) { best = d1; gpos = p + 1; }
+        if (p + 2 < e && d2 < best) { best = d2; gpos = p + 2; }
+        if (p + 3 < e && d3 < best) { best = d3; gpos = p + 3; }
+      }
+    }
+  }
+  return true;
+}
+
+template <bool NRM>
+__global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_grid_kernel(
+    CloudView src, BvhView tgt, GridView grid, const IcpState *__restrict__ st, double *__restrict__ partials,
+    int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ hint, uint32_t *__restrict__ ghint,
+    const uint32_t *__restrict__ qorder, unsigned char *__restrict__ qclass, const uint32_t *__restrict__ chunk_order,
+    uint32_t *__restrict__ chunk_cost, const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic) {
+  if (st->done) return;
+  constexpr int BLOCK = kAccBlock;
+  __shared__ double s_red[BLOCK / 64][kNumSumsMax];
+  __shared__ float s_stk[kMaxDepth + 1][BLOCK];
+  float *stk = &s_stk[0][threadIdx.x];
+  __shared__ __attribute__((aligned(16))) float s_const[16];   // F rows [0..11], pivot [12..14], best0 [15]
+  const double max_d2 = st->max_d2;
+  float best0 = INFINITY;
+  if (max_d2 < 3.0e38) {
+    float f = (float)max_d2;
+    if ((double)f < max_d2) f = nextafterf(f, INFINITY);
+    best0 = nextafterf(f, INFINITY);
+  }
+  if (threadIdx.x < 12) s_const[threadIdx.x] = st->Ff[threadIdx.x];
+  else if (threadIdx.x < 15) s_const[threadIdx.x] = (float)st->pivot[threadIdx.x - 12];
+  else if (threadIdx.x == 15) s_const[15] = best0;
+  __syncthreads();
+  const bool rej_sn = NRM && st->use_surface_normal_rej;
+  const bool rej_so = NRM && st->use_self_occluded_rej;
+  const double thr_sn = st->surface_normal_thr, thr_so = st->self_occluded_thr;
+  if ((threadIdx.x & 63u) < (uint32_t)kNumSumsMax) s_red[threadIdx.x >> 6][threadIdx.x & 63u] = 0.0;
+  const bool p2p = NRM && st->estimator == OPE_EST_POINT_TO_PLANE_LLS;
+
+  const uint32_t lane_id = threadIdx.x & 63u;
+  const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+  const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+  // the query order: n_grid_q grid-class queries, then the tree-class ones; before the first plan: all "tree-class",
+  // identity order (every query still tries the grid first if it has a previous match)
+  const uint32_t n_grid_q = min(plan_info[1], src.n_valid);
+  const uint32_t n_tree_q = src.n_valid - n_grid_q;
+  const uint32_t n_gc = (n_grid_q + 63u) / 64u, n_tc = (n_tree_q + 63u) / 64u;
+  const uint32_t n_heavy = chunk_order ? min(plan_info[0], n_tc) : 0u;
+  // slots, costliest first: 8 per heavy tree chunk (8-lane group walks), the other tree chunks, the grid chunks
+  const uint32_t n_slots = n_tc + 7u * n_heavy + n_gc;
+  for (uint32_t round = 0;; ++round) {
+    if (round * n_waves >= n_slots) break;
+    const uint32_t slot = round * n_waves + ((round & 1u) ? (n_waves - 1u - wave_id) : wave_id);
+    if (slot >= n_slots) continue;
+    const bool oct = slot < 8u * n_heavy;
+    const bool tree_part = slot < n_tc + 7u * n_heavy;
+    uint32_t chunk = 0, pos0, pos_end;
+    if (tree_part) {
+      const uint32_t ord = oct ? (slot >> 3) : (slot - 7u * n_heavy);
+      chunk = chunk_order ? min(chunk_order[ord], n_tc - 1u) : ord;
+      pos0 = n_grid_q + chunk * 64u;
+      pos_end = src.n_valid;
+    } else {
+      pos0 = (slot - (n_tc + 7u * n_heavy)) * 64u;
+      pos_end = n_grid_q;
+    }
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+    const uint32_t qpos = oct ? (pos0 + (slot & 7u) * 8u + (lane_id >> 3)) : (pos0 + lane_id);
+    const bool active = qpos < pos_end;
+    const uint32_t i = active ? qorder[qpos] : qorder[pos0];
+    const bool owner = active && (!oct || (lane_id & 7u) == 0u);
+    lds_cfloat_ptr cst = (lds_cfloat_ptr)s_const;
+    asm volatile("" : "+v"(cst));
+    float F[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) F[k] = cst[k];
+    const float4 s = src.xyzw[i];
+    const float x = xform_row(F + 0, s.x, s.y, s.z);
+    const float y = xform_row(F + 4, s.x, s.y, s.z);
+    const float z = xform_row(F + 8, s.x, s.y, s.z);
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (NRM && src.nrm != nullptr) {
+      const float4 n4 = src.nrm[i];
+      nx = rot_row(F + 0, n4.x, n4.y, n4.z);
+      ny = rot_row(F + 4, n4.x, n4.y, n4.z);
+      nz = rot_row(F + 8, n4.x, n4.y, n4.z);
+    }
+    // ---- the previous match, if any: it bounds the search
+    const uint32_t gh = active ? ghint[i] : 0u;
+    float best = active ? cst[15] : -INFINITY;   // +inf, or just above the largest admissible d2
+    uint32_t gpos = kNoPos;
+    bool by_grid = false;
+    if (gh != 0u) {
+      const v4f t0 = ld16(grid.gpts + (gh - 1u));
+      const float d0 = sq_dist3(__fsub_rn(x, t0.x), __fsub_rn(y, t0.y), __fsub_rn(z, t0.z));
+      if (d0 < best) { best = d0; gpos = gh - 1u; }
+      if (!oct && gpos != kNoPos) by_grid = grid_scan(grid, x, y, z, best, gpos);
+    }
+    // ---- everything else: the tree, seeded with what is known
+    const bool need_tree = active && !by_grid;
+    if (oct) {
+      if (active) {
+        NearestVisitor v{gpos != kNoPos ? nextafterf(best, INFINITY) : best, kNoPos, 0};
+        bvh_traverse_oct(tgt, x, y, z, v, &s_stk[0][threadIdx.x & ~7u], BLOCK, hint[i]);
+        if (v.pos != kNoPos) { best = v.best; gpos = grid.gpos_of_bvhpos[v.pos]; }
+        if (owner && v.leaf != 0u) hint[i] = v.leaf;
+      }
+    } else if (__ballot(need_tree) != 0ull) {
+      if (need_tree) {
+        const uint32_t h = hint[i];
+        NearestVisitor v{gpos != kNoPos ? nextafterf(best, INFINITY) : best, kNoPos, 0};
+        bvh_traverse(tgt, x, y, z, v, stk, BLOCK, h);
+        if (v.pos != kNoPos) { best = v.best; gpos = grid.gpos_of_bvhpos[v.pos]; }
+        if (v.leaf != 0u && v.leaf != h) hint[i] = v.leaf;
+      }
+    }
+    const bool found = active && gpos != kNoPos;
+    bool ok = found && !((double)best > max_d2);
+    const float d2 = found ? best : INFINITY;
+    const v4f tm = ld16(grid.gpts + (found ? gpos : 0u));
+    const int match = found ? __float_as_int(tm.w) : -1;
+    if (owner) {
+      if (found && gpos + 1u != gh) ghint[i] = gpos + 1u;
+      const unsigned char cls = by_grid ? 1 : 0;
+      if (cls != (tree_part ? 0 : 1) || !chunk_order) qclass[i] = cls;   // the partition's expectation is written at the plan step
+    }
+    if (NRM && ok && rej_sn) {
+      const float4 tn = grid.gnrm[gpos];
+      const float score = __fadd_rn(__fadd_rn(__fmul_rn(nx, tn.x), __fmul_rn(ny, tn.y)), __fmul_rn(nz, tn.z));
+      ok = (double)score > thr_sn;
+    }
+    if (NRM && ok && rej_so) {
+      const double sl = sqrt((double)__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+      const double score = (double)nx * (-(double)x / sl) + (double)ny * (-(double)y / sl) + (double)nz * (-(double)z / sl);
+      ok = score > thr_so;
+    }
+    ok = ok && owner;
+    if (owner) {
+      __builtin_nontemporal_store(ok ? match : -1, corr_match + i);
+      __builtin_nontemporal_store(d2, corr_d2 + i);
+    }
+    add_query_sums<NRM>(s_red[threadIdx.x >> 6], (lds_cfloat_ptr)s_const, lane_id, ok, p2p, x, y, z, make_float4(tm.x, tm.y, tm.z, tm.w),
+                        (NRM && p2p) ? grid.gnrm[ok ? gpos : 0u] : make_float4(0.f, 0.f, 0.f, 0.f), d2);
+    if (lane_id == 0 && tree_part && !oct) chunk_cost[chunk] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
+  }
+  __syncthreads();
+  if (threadIdx.x < (p2p ? kNumSumsMax : kNumSums)) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) v += s_red[w][threadIdx.x];
     if (S_atomic != nullptr) unsafeAtomicAdd(S_atomic + threadIdx.x, v);
     else partials[threadIdx.x * kAccMaxBlocks + blockIdx.x] = v;
   }
@@ -557,7 +785,8 @@ __device__ __forceinline__ bool point_to_plane_from_sums(const double *N, double
   return true;
 }
 
-__device__ __forceinline__ void icp_update_lane(IcpState *st, const double *S) {
+// Tk_ext: the incremental transform of an estimator that runs outside this kernel (LM, lm.hip), column-major float, or null
+__device__ __forceinline__ void icp_update_lane(IcpState *st, const double *S, const float *Tk_ext = nullptr) {
   const double n = S[0];
   st->n_corr = (long long)n;
   // icp_mod.hpp:232-240
@@ -568,7 +797,10 @@ __device__ __forceinline__ void icp_update_lane(IcpState *st, const double *S) {
     return;
   }
   double Tk[16];
-  if (st->estimator == OPE_EST_POINT_TO_PLANE_LLS) {
+  if (Tk_ext != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Tk[i] = (double)Tk_ext[i];
+  } else if (st->estimator == OPE_EST_POINT_TO_PLANE_LLS) {
     if (!point_to_plane_from_sums(S + kNumSums, Tk)) {
       // singular normal equations: no usable step (PCL would propagate NaNs); stop with what we have
       st->state = OPE_CONV_NO_CORRESPONDENCES;
@@ -708,14 +940,14 @@ __global__ __launch_bounds__(kRedBlock) void icp_reduce_update_kernel(IcpState *
 // The sums are consumed: they are left at zero, ready for the next accumulate launch to add into (sharded runs).
 // nsums: 17, or 44 with the point-to-plane estimator: a caller-owned sums buffer (ope_icp_set_sums_buffer) only has to hold
 // what the estimator uses, and nothing past that is read or written.
-__global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, double *S, int nsums) {
+__global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, double *S, int nsums, const float *Tk_ext) {
   if (st->done) return;
   __shared__ double s_S[kNumSumsMax];
   __shared__ IcpState s_st;
   state_to_lds(&s_st, st);
   if ((int)threadIdx.x < kNumSumsMax) s_S[threadIdx.x] = (int)threadIdx.x < nsums ? S[threadIdx.x] : 0.0;
   __syncthreads();
-  if (threadIdx.x == 0) icp_update_lane(&s_st, s_S);
+  if (threadIdx.x == 0) icp_update_lane(&s_st, s_S, Tk_ext);
   __syncthreads();
   if ((int)threadIdx.x < kNumSumsMax) s_st.S[threadIdx.x] = 0.0;   // S may be the state's own array
   __syncthreads();
@@ -909,14 +1141,26 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
 #undef OPE_LAUNCH_ACC
 }
 
+void launch_icp_accumulate_grid(hipStream_t stream, int nblocks, bool nrm, const CloudView &src, const BvhView &tgt, const GridView &grid,
+                                const IcpState *st, double *partials, int32_t *corr_match, float *corr_d2, uint32_t *hint, uint32_t *ghint,
+                                const uint32_t *qorder, unsigned char *qclass, const uint32_t *chunk_order, uint32_t *chunk_cost,
+                                const uint32_t *plan_info, double *S_atomic) {
+  if (nrm)
+    hipLaunchKernelGGL((icp_accumulate_grid_kernel<true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, grid, st, partials, corr_match,
+                       corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic);
+  else
+    hipLaunchKernelGGL((icp_accumulate_grid_kernel<false>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, grid, st, partials, corr_match,
+                       corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic);
+}
+
 void launch_icp_reduce_update(hipStream_t stream, IcpState *st, const double *partials, double *S, int nblocks,
                               bool do_update, uint32_t *work_counter) {
   hipLaunchKernelGGL(icp_reduce_update_kernel, dim3(1), dim3(kRedBlock), 0, stream, st, partials, S, nblocks,
                      do_update ? 1 : 0, work_counter);
 }
 
-void launch_icp_update(hipStream_t stream, IcpState *st, double *S, int nsums) {
-  hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(64), 0, stream, st, S, nsums);
+void launch_icp_update(hipStream_t stream, IcpState *st, double *S, int nsums, const float *Tk_ext) {
+  hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(64), 0, stream, st, S, nsums, Tk_ext);
 }
 
 void launch_nn_search(hipStream_t stream, const CloudView &q, const BvhView &tgt, const float *d_T, int32_t *out_idx,

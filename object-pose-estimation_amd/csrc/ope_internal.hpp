@@ -37,6 +37,20 @@ struct BvhView {
                         // are cheap, the per-lane cross product is not); null -> recomputed
 };
 
+// The uniform grid over the target (grid_build.hip): cell id = (iz * dim[1] + iy) * dim[0] + ix with
+// i = floor((p - lo) * inv), clamped to the table; gpts = the target points sorted by cell id.
+struct GridView {
+  const float4 *gpts;              // n (+ kPtsPad) points, w = ORIGINAL index
+  const float4 *gnrm;              // optional normals, same order
+  const uint32_t *cell_start;      // n_cells + 1
+  const uint32_t *gpos_of_bvhpos;  // n: sorted position of the point at BVH position p
+  float lo[3];
+  float inv;                       // 1 / cell size
+  float eps;                       // added to a query radius: covers the rounding of the cell expression (4e-7 x the largest coordinate)
+  int dim[3];
+  uint32_t n_cells, occupied;
+};
+
 // Device-side view of a (Morton-sorted) query cloud.
 struct CloudView {
   const float4 *xyzw;   // n points, sorted; w = ORIGINAL index (int bits); non-finite points last
@@ -110,6 +124,18 @@ struct ope_ctx {
   bool plan_valid = false;
   int acc_launches = 0;
   uint32_t *d_hint = nullptr;       // per sorted query: leaf (heap id) of the previous iteration's match, 0 = none
+  // grid path of the 1-NN search (icp_accumulate_grid_kernel)
+  uint32_t *d_ghint = nullptr;      // per sorted query: 1 + position of the previous match in the grid-sorted points, 0 = none
+  uint32_t *d_qorder = nullptr;     // query order of the launch: [grid-class queries | tree-class queries]
+  unsigned char *d_qclass = nullptr;  // per sorted query: 1 = answered by the grid in the last launch
+  void *d_part_tmp = nullptr;
+  size_t part_tmp_bytes = 0;
+  bool use_grid = false;
+  size_t grid_cap = 0;
+  uint32_t *d_chunk_keys = nullptr;      // sort keys of the tree chunks (plan step)
+  hipEvent_t grid_probe_event = nullptr;  // asynchronous read-back of the grid-class query count
+  uint32_t *h_grid_probe = nullptr;       // pinned
+  bool grid_probe_pending = false;
   size_t corr_cap = 0;
   ope::IcpState *h_state = nullptr;  // pinned
   const ope_cloud *run_src = nullptr;   // cleared by ope_cloud_free / ope_index_free of the handle they point at
@@ -171,6 +197,14 @@ struct ope_index {
   double pivot[3] = {0, 0, 0};
   float bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
   float4 *d_axis2 = nullptr;
+  // uniform grid over the same points (device-built indexes)
+  float4 *d_gpts = nullptr, *d_gnrm = nullptr;
+  uint32_t *d_cell_start = nullptr, *d_gpos = nullptr;
+  ope::GridView grid{};
+  bool has_grid = false, want_grid = false;
+  int grid_mode = 1;   // ope_index_params.grid: 0 off, 1 automatic (falls back to the tree kernel on clutter-heavy sources), 2 always
+  float grid_fill = 0.f;
+  int grid_max_cells = 0;
   ope::BvhView view() const { return ope::BvhView{d_nodes, d_pts, d_nrm, (uint32_t)n, depth, d_axis2}; }
 };
 

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 
+#include <algorithm>
 #include <rocprim/rocprim.hpp>
 
 #include <cfloat>
@@ -97,6 +98,74 @@ __global__ void plan_heavy_kernel(const uint32_t *cost_sorted_desc, uint32_t n, 
 
 void plan_heavy(hipStream_t stream, const uint32_t *cost_sorted_desc, uint32_t n, float factor, uint32_t *plan_info) {
   hipLaunchKernelGGL(plan_heavy_kernel, dim3(1), dim3(64), 0, stream, cost_sorted_desc, n, factor, plan_info);
+}
+
+// ---- plan step of the GRID accumulate kernel (icp_accumulate_grid_kernel): everything stays on the device
+// plan_info[0] = n_heavy, plan_info[1] = n_grid_q (written by the partition below)
+//
+// 1. query order: grid-class queries first (flag 1), tree-class after them (rocPRIM partition of 0..n-1 by the class
+//    flags; the rejected part comes out in reverse order, which keeps it spatially coherent all the same)
+// 2. sort keys of the tree chunks: chunk ids below the number of tree chunks carry max(cost, 1), all others 0, so that
+//    the first n_tc entries of the descending sort are exactly a permutation of the tree chunks
+// 3. the number of heavy chunks among them
+__global__ void grid_plan_keys_kernel(const uint32_t *__restrict__ cost, uint32_t nch, uint32_t n_valid, const uint32_t *__restrict__ plan_info,
+                                      uint32_t *__restrict__ keys) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= nch) return;
+  const uint32_t n_tc = (n_valid - min(plan_info[1], n_valid) + 63u) / 64u;
+  keys[c] = c < n_tc ? max(cost[c], 1u) : 0u;
+}
+
+__global__ void grid_plan_heavy_kernel(const uint32_t *cost_sorted_desc, uint32_t n_valid, uint32_t n_waves, float factor_override,
+                                       uint32_t *plan_info) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint32_t n = (n_valid - min(plan_info[1], n_valid) + 63u) / 64u;
+  // the fewer tree chunks there are per resident wave, the more the slowest one decides the launch (see enqueue_accumulate)
+  const float cpw = (float)n / (float)max(n_waves, 1u);
+  const float factor = factor_override >= 0.f ? factor_override : fminf(7.0f, fmaxf(2.0f, 1.2f + 1.5f * cpw));
+  uint32_t nh = 0;
+  if (factor_override < 0.f && 2u * n <= n_waves) {
+    // Tree-class queries are the ones far from the surface: long private walks.  While eight lanes per query still fit
+    // the launch (8 n_tc slots <= 4 per wave), all of them are walked by 8-lane groups (C3: 225 -> 1xx us with ~1.4 k
+    // tree chunks on 6144 waves); beyond that the costliest ones only.
+    nh = n;
+  } else if (factor > 0.f && n >= 8) {
+    const float thr = factor * (float)cost_sorted_desc[n / 2];
+    uint32_t lo = 0, hi = n / 4;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) / 2;
+      if ((float)cost_sorted_desc[mid] > thr) lo = mid + 1; else hi = mid;
+    }
+    nh = lo;
+  }
+  plan_info[0] = nh;
+}
+
+// d_keys: scratch of nch entries.  tmp sized by grid_plan_tmp_bytes.
+int grid_plan(hipStream_t stream, bool repartition, const unsigned char *qclass, uint32_t n_valid, uint32_t *qorder, uint32_t *plan_info,
+              const uint32_t *cost, uint32_t *keys, uint32_t *cost_sorted, const uint32_t *ids, uint32_t *order, uint32_t nch, uint32_t n_waves,
+              float factor_override, void *tmp, size_t tmp_bytes) {
+  hipError_t e = hipSuccess;
+  if (repartition) {
+    size_t tb = tmp_bytes;
+    e = rocprim::partition(tmp, tb, rocprim::counting_iterator<uint32_t>(0), qclass, qorder, plan_info + 1, (size_t)n_valid, stream);
+    if (e != hipSuccess) return -1;
+  }
+  hipLaunchKernelGGL(grid_plan_keys_kernel, dim3((nch + 255) / 256), dim3(256), 0, stream, cost, nch, n_valid, plan_info, keys);
+  size_t tb = tmp_bytes;
+  e = rocprim::radix_sort_pairs_desc(tmp, tb, keys, cost_sorted, ids, order, nch, 0, 32, stream);
+  if (e != hipSuccess) return -1;
+  hipLaunchKernelGGL(grid_plan_heavy_kernel, dim3(1), dim3(64), 0, stream, cost_sorted, n_valid, n_waves, factor_override, plan_info);
+  return 0;
+}
+
+size_t grid_plan_tmp_bytes(uint32_t n_valid, uint32_t nch) {
+  size_t a = 0, b = 0;
+  (void)rocprim::partition(nullptr, a, rocprim::counting_iterator<uint32_t>(0), (const unsigned char *)nullptr, (uint32_t *)nullptr,
+                           (uint32_t *)nullptr, (size_t)std::max<uint32_t>(n_valid, 1), (hipStream_t) nullptr);
+  (void)rocprim::radix_sort_pairs_desc(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                       (size_t)std::max<uint32_t>(nch, 1), 0, 32, (hipStream_t) nullptr);
+  return std::max<size_t>(std::max(a, b), 16);
 }
 
 void fill_iota(hipStream_t stream, uint32_t *v, uint32_t n) {

@@ -61,6 +61,7 @@ class IcpParams(C.Structure):
         ("failure_after_max_iter", C.c_int),
         ("acc_mode", C.c_int),
         ("estimator", C.c_int),
+        ("lm_precision", C.c_int),
         ("transform_mode", C.c_int),
     ]
 
@@ -132,6 +133,8 @@ def _declare(L):
     L.orc_svd3.argtypes = [_dp, _dp, _dp, _dp]
     L.orc_point_to_plane_lls.restype = C.c_int
     L.orc_point_to_plane_lls.argtypes = [_fp, _fp, _fp, C.c_int, _fp]
+    L.orc_point_to_plane_lm.restype = C.c_int
+    L.orc_point_to_plane_lm.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_convergence_init.argtypes = [C.POINTER(Convergence)]
     L.orc_convergence_step.restype = C.c_int
     L.orc_convergence_step.argtypes = [C.POINTER(Convergence), C.c_int, _fp, C.c_double]
@@ -239,6 +242,19 @@ def point_to_plane_lls(src, tgt, tgt_nrm) -> np.ndarray:
     rc = lib().orc_point_to_plane_lls(_p(src, _fp), _p(tgt, _fp), _p(tn, _fp), len(src), _p(T, _fp))
     assert rc == 0
     return T.reshape(4, 4).T.copy()
+
+
+def point_to_plane_lm(src, tgt, tgt_nrm, precision: int = 0):
+    """PCL's TransformationEstimationPointToPlane (LM).  Returns (T (4,4), x (6,), nfev, status)."""
+    src, tgt, tn = _f32(src, 3), _f32(tgt, 3), _f32(tgt_nrm, 3)
+    T = np.empty(16, np.float32)
+    x = np.zeros(6, np.float64)
+    nfev = C.c_int(0); status = C.c_int(0)
+    rc = lib().orc_point_to_plane_lm(_p(src, _fp), _p(tgt, _fp), _p(tn, _fp), len(src), precision, _p(T, _fp), _p(x, _dp),
+                                     C.byref(nfev), C.byref(status))
+    if rc != 0:
+        raise ValueError("orc_point_to_plane_lm needs at least 4 pairs")
+    return T.reshape(4, 4).T.copy(), x, nfev.value, status.value
 
 
 def umeyama_from_sums(S, pivot) -> np.ndarray:

@@ -454,7 +454,7 @@ int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt
   if (ns <= 0 || !src_xyz) return -2;
   if (!guess) guess = I4;
   int need_src_nrm = (p->corr_mode == 1) || p->use_surface_normal_rej || p->use_self_occluded_rej;
-  int need_tgt_nrm = p->use_surface_normal_rej || p->estimator == 1;
+  int need_tgt_nrm = p->use_surface_normal_rej || p->estimator == 1 || p->estimator == 2;
   if ((need_src_nrm && !src_nrm) || (need_tgt_nrm && !tgt_nrm)) return -3;
 
   orc_kdtree *tree = orc_kdtree_build(tgt_xyz, nt, 15);
@@ -467,7 +467,7 @@ int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt
   float *cd = (float *)malloc(sizeof(float) * (size_t)ns);
   float *ps = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
   float *pt = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
-  float *pn = (p->estimator == 1) ? (float *)malloc(sizeof(float) * 3 * (size_t)ns) : NULL;
+  float *pn = (p->estimator == 1 || p->estimator == 2) ? (float *)malloc(sizeof(float) * 3 * (size_t)ns) : NULL;
   int kk = p->k_normal_shooting > 0 ? p->k_normal_shooting : 1;
   int32_t *nn_i = (int32_t *)malloc(sizeof(int32_t) * (size_t)kk);
   float *nn_d = (float *)malloc(sizeof(float) * (size_t)kk);
@@ -567,6 +567,7 @@ int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt
       if (pn) memcpy(pn + 3 * c, tgt_nrm + 3 * cm[c], 3 * sizeof(float));
     }
     if (p->estimator == 1) orc_point_to_plane_lls(ps, pt, pn, ncorr, Tk);
+    else if (p->estimator == 2) orc_point_to_plane_lm(ps, pt, pn, ncorr, p->lm_precision, Tk, NULL, NULL, NULL);   /* regmeshpcd.cpp:162,193 */
     else orc_umeyama(ps, pt, ncorr, p->acc_mode, Tk);
     if (p->transform_mode == 0) {
       orc_transform_points(work, ns, Tk, work);

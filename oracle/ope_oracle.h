@@ -75,6 +75,13 @@ int orc_umeyama_from_sums(const double S[17], const double pivot[3], float T[16]
  * (tgt_nrm = normals of the matched target points).  Returns 0, or -1 if the 6x6 system is singular. */
 int orc_point_to_plane_lls(const float *src, const float *tgt, const float *tgt_nrm, int n, float T[16]);
 
+/* uPCL TransformationEstimationPointToPlane (Levenberg-Marquardt over WarpPointRigid6D; the estimator BuildModel
+ * installs, regmeshpcd.cpp:162,193) on n paired points: lm.c / lm_impl.inc.  precision 0 = float (the reference's
+ * MatScalar), 1 = double.  x_out: (tx, ty, tz, qx, qy, qz); nfev_out: functor evaluations; status_out: Eigen's
+ * LevenbergMarquardtSpace::Status.  Returns -1 (T = identity) for fewer than 4 pairs. */
+int orc_point_to_plane_lm(const float *src, const float *tgt, const float *tgt_nrm, int n, int precision, float T[16],
+                          double x_out[6], int *nfev_out, int *status_out);
+
 /* 3x3 SVD (two-sided Jacobi via A^T A eigen-decomposition refinement),
  * A = U diag(s) V^T, s descending, row-major 3x3 arrays. */
 void orc_svd3(const double A[9], double U[9], double s[3], double V[9]);
@@ -136,11 +143,14 @@ typedef struct {
   int failure_after_max_iter;      /* 0 */
   int acc_mode;                    /* umeyama accumulation, see orc_umeyama */
   int estimator;                   /* 0: TransformationEstimationSVD (poseestimator.cpp:306,341)
+                                      2: TransformationEstimationPointToPlane (LM, lm.c): BuildModel's estimator
+                                         (regmeshpcd.cpp:162,193); lm_precision 0 = float as PCL, 1 = double
                                       1: TransformationEstimationPointToPlaneLLS — the default estimator of
                                          IterativeClosestPointWithNormals (icp_mod.h:352-357), linearised
                                          point-to-plane; needs target normals.  (BuildModel selects the
                                          LM-based point-to-plane estimator, regmeshpcd.cpp:162,193: same cost
                                          function, non-linear solve — not restated.) */
+  int lm_precision;                /* estimator 2: 0 = float (PCL), 1 = double */
   int transform_mode;              /* 0: incremental float transform of the working cloud
                                          each iteration (reference, icp_mod.hpp:246);
                                       1: final_T (composed in double) applied to the

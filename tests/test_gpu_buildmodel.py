@@ -26,7 +26,7 @@ def env():
     c.close()
 
 
-def oracle_pair(source, target, thr, max_it):
+def oracle_pair(source, target, thr, max_it, estimator=2):
     ns, _ = oracle.normals_knn(source, 12)
     nt, _ = oracle.normals_knn(target, 12)
     p = oracle.default_icp_params()
@@ -37,7 +37,9 @@ def oracle_pair(source, target, thr, max_it):
     p.k_normal_shooting = 20
     p.use_surface_normal_rej = 1
     p.surface_normal_thr = thr
-    p.estimator = 1
+    p.estimator = estimator      # 2: TransformationEstimationPointToPlane (LM, float as PCL), regmeshpcd.cpp:162,193
+    p.lm_precision = 0
+    p.acc_mode = 1; p.transform_mode = 1
     out = oracle.icp(source, target, p, src_nrm=ns, tgt_nrm=nt)
     return oracle.transform_points(source, out.T), out
 

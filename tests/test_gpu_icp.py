@@ -405,6 +405,58 @@ def test_icp_point_to_plane_lls_matches_oracle(ctx):
     assert out.iterations <= svd.iterations
 
 
+@pytest.mark.parametrize("corr", ["nearest", "normal_shooting"])
+def test_icp_point_to_plane_lm_matches_oracle(ctx, corr):
+    """TransformationEstimationPointToPlane — the Levenberg-Marquardt estimator BuildModel installs
+    (regmeshpcd.cpp:162,193): device reductions + Eigen's LM logic in double against the oracle's restatement in
+    float (the reference's precision) and in double.  The float/double gap of the oracle is the resolution of this
+    comparison (tests/test_oracle_lm.py measures ~1e-5 per estimate)."""
+    ope = load_pkg()
+    P, nP = synth.model_surface(6000, 5, return_normals=True)
+    P = P + np.array([0, 0, 0.6], np.float32)
+    Tgt = rigid(2.0, -1.5, 3.0, [0.004, -0.003, 0.002])
+    Q = apply(Tgt, synth.model_surface(6000, 6) + np.array([0, 0, 0.6], np.float32))
+    _, nQ0 = synth.model_surface(6000, 6, return_normals=True)
+    nQ = (nQ0.astype(np.float64) @ Tgt[:3, :3].T).astype(np.float32)
+    kw = dict(max_iterations=12, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, max_corr_dist=0.01)
+    if corr == "normal_shooting":
+        kw.update(corr_mode=1, k_normal_shooting=20, use_surface_normal_rej=1, surface_normal_thr=0.7, max_corr_dist=float(np.sqrt(np.finfo(np.float64).max)))
+    cs = ctx.upload(P, nP); ct = ctx.upload(Q, nQ); ix = ctx.build_index(ct)
+    out = ctx.icp(cs, ix, ope.default_icp_params(estimator=ope.EST_POINT_TO_PLANE_LM, mse_threshold_absolute=-1.0, **kw))
+    refs = [oracle.icp(P, Q, orc_params(acc_mode=1, transform_mode=1, estimator=2, lm_precision=prec, mse_threshold_absolute=-1.0, **kw),
+                       src_nrm=nP, tgt_nrm=nQ) for prec in (0, 1)]
+    gap = frob(refs[0].T, refs[1].T)
+    assert out.iterations == refs[0].iterations == 12
+    assert frob(out.T, refs[0].T) < 1e-4 and frob(out.T, refs[1].T) < 1e-4, (frob(out.T, refs[0].T), frob(out.T, refs[1].T), gap)
+    assert abs(out.n_corr - refs[0].n_corr) <= 3
+    assert frob(out.T, Tgt) < 5e-3
+    # the linearised estimator takes a different path: after ONE iteration it is not within 1e-4 of LM
+    one = dict(kw, max_iterations=1)
+    lm1 = ctx.icp(cs, ix, ope.default_icp_params(estimator=ope.EST_POINT_TO_PLANE_LM, mse_threshold_absolute=-1.0, **one))
+    ref1 = oracle.icp(P, Q, orc_params(acc_mode=1, transform_mode=1, estimator=2, lm_precision=0, mse_threshold_absolute=-1.0, **one), src_nrm=nP, tgt_nrm=nQ)
+    assert frob(lm1.T, ref1.T) < 2e-5
+    # correspondences of an LM run come back in ORIGINAL target indices (the kernels keep index positions internally)
+    q, m, d = ctx.icp_correspondences(len(P))
+    common, ia, ib = np.intersect1d(q, refs[0].corr_q, return_indices=True)
+    assert len(common) > 0.95 * refs[0].n_corr and (m[ia] == refs[0].corr_m[ib]).mean() > 0.99
+
+
+def test_lm_estimator_is_refused_by_the_stepwise_api_and_without_target_normals(ctx):
+    ope = load_pkg()
+    P, nP = synth.model_surface(800, 5, return_normals=True)
+    cs = ctx.upload(P)
+    with pytest.raises(ope.OpeError) as e:
+        ctx.icp(cs, ctx.build_index(ctx.upload(P)), ope.default_icp_params(estimator=ope.EST_POINT_TO_PLANE_LM))
+    assert e.value.code == ope.OPE_EINVAL
+    ix = ctx.build_index(ctx.upload(P, nP))
+    ctx.icp_begin(cs, ix, ope.default_icp_params(estimator=ope.EST_POINT_TO_PLANE_LM))
+    with pytest.raises(ope.OpeError) as e:
+        ctx.icp_accumulate()
+    assert e.value.code == ope.OPE_EINVAL
+    ctx.icp_iterate(2)
+    assert ctx.icp_end().iterations == 2
+
+
 def test_point_to_plane_needs_target_normals(ctx):
     ope = load_pkg()
     P = synth.bumpy_torus(500)
