@@ -91,6 +91,12 @@ int ope_cloud_upload(ope_ctx *ctx, const void *base, size_t n, size_t stride_byt
                      ptrdiff_t normal_off, ope_cloud **out);
 /* Attach / replace normals (n*3 packed floats, original order). */
 int ope_cloud_set_normals(ope_ctx *ctx, ope_cloud *cloud, const float *normals_xyz);
+/* pcl::transformPointCloud(a, ., T_a) followed by operator+= (BuildModel regmeshpcd.cpp:203,254: cloudTemp = aligned + target),
+ * built on the device: out holds T_a * a (T_a may be NULL: identity) followed by b, ORIGINAL indices a's then b's.  Neither
+ * input travels through the host; normals are not carried (re-estimated per pair in the reference, :72-90). */
+int ope_cloud_concat(ope_ctx *ctx, const ope_cloud *a, const float T_a[16], const ope_cloud *b, ope_cloud **out);
+/* xyz of a cloud in ORIGINAL order (n*3 floats): the way out for clouds made by ope_cloud_concat. */
+int ope_cloud_download(ope_ctx *ctx, const ope_cloud *cloud, float *out_xyz);
 size_t ope_cloud_size(const ope_cloud *cloud);
 void ope_cloud_free(ope_cloud *cloud);
 

@@ -118,6 +118,8 @@ ABI = [
     ("ope_profile_kernels_read", C.c_int, [_vp, C.POINTER(KernelTime), C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ope_cloud_upload", C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_ssize_t, C.POINTER(_vp)]),
     ("ope_cloud_set_normals", C.c_int, [_vp, _vp, _fp]),
+    ("ope_cloud_concat", C.c_int, [_vp, _vp, _fp, _vp, C.POINTER(_vp)]),
+    ("ope_cloud_download", C.c_int, [_vp, _vp, _fp]),
     ("ope_cloud_size", C.c_size_t, [_vp]),
     ("ope_cloud_free", None, [_vp]),
     ("ope_index_default_params", None, [C.POINTER(IndexParams)]),
@@ -290,6 +292,18 @@ class Context:
         h = _vp()
         self._chk(lib().ope_cloud_upload(self.h, buf.ctypes.data_as(_vp), n, stride, xyz_off, normal_off, C.byref(h)))
         return Cloud(self, h, n)
+
+    def concat(self, a: "Cloud", T, b: "Cloud") -> "Cloud":
+        """[T * a ; b] built on the device (BuildModel's cloudTemp = aligned + target)."""
+        t = colmajor(T) if T is not None else None
+        h = _vp()
+        self._chk(lib().ope_cloud_concat(self.h, a.h, _p(t, _fp), b.h, C.byref(h)))
+        return Cloud(self, h, a.n + b.n)
+
+    def download(self, cloud: "Cloud") -> np.ndarray:
+        out = np.empty((cloud.n, 3), np.float32)
+        self._chk(lib().ope_cloud_download(self.h, cloud.h, _p(out, _fp)))
+        return out
 
     def build_index(self, cloud: "Cloud", leaf_size: int | None = None, grid: bool | None = None, grid_fill: float = 0.0,
                     grid_max_cells: int = 0) -> "Index":

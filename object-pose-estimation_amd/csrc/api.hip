@@ -20,6 +20,7 @@ void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, uint32_t *);
 int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t, void *, size_t &);
 void fill_iota(hipStream_t, uint32_t *, uint32_t);
 hipError_t morton_order_device(hipStream_t, const float *, size_t, const float[3], const float[3], float4 *, int32_t *);
+hipError_t concat_device(hipStream_t, const CloudView &, const float *, const CloudView &, float *, float[3], float[3]);
 hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t, int, const float[3], const float[3], int *, float4 **,
                             float4 **, float4 **, float4 **);
 void launch_icp_accumulate_grid(hipStream_t, int, bool, const CloudView &, const BvhView &, const GridView &, const IcpState *, double *, int32_t *,
@@ -44,6 +45,7 @@ int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count);
 static thread_local std::string g_global_err;
 
 constexpr double kGridMaxTreeShare = 0.03;
+constexpr float kHeavyMaxChunksPerWave = 1.8f;   // beyond this the launch is throughput-bound: no 8-lane group walks
 
 // Developer A/B switches and sweeps (tools/*.py) read the environment only in builds made with -DOPE_DEVELOPER
 // (`make DEVELOPER=1`); the product library has no environment-dependent behaviour on its launch path.
@@ -121,6 +123,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
       ctx->grid_probe_pending = false;
       const uint32_t n_grid_q = *ctx->h_grid_probe;
       const double tree_share = 1.0 - (double)n_grid_q / (double)std::max<size_t>(ctx->run_src->n_valid, 1);
+      if (dev_env("OPE_TRACE_GRID")) fprintf(stderr, "[ope] grid probe at launch %d: n_grid_q %u of %zu (tree share %.4f), mode %d\n", it_done, n_grid_q, ctx->run_src->n_valid, tree_share, ctx->run_tgt->grid_mode);
       if (tree_share > kGridMaxTreeShare && ctx->run_tgt->grid_mode != 2) {
         ctx->use_grid = false;
         ctx->plan_valid = false;   // chunk ids mean something else to the tree kernel
@@ -161,14 +164,16 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
                    ctx->d_plan_tmp, tb) != 0)
       return set_err(ctx, OPE_EHIP, "chunk plan sort failed");
-    // Chunks costlier than `factor` x the median chunk are walked by 8-lane groups.  The fewer chunks there are per
-    // resident wave, the more the slowest wave decides the launch and the more chunks deserve the 8x lane cost.
-    // Measured optimum (model 100 k; tools/heavy_sweep.py): 2 at 0.25-0.6 chunks per wave (C2: 115 -> 79 us), 2.5 at
-    // 1.0, 3 at 1.3 (500 k queries: 171 -> 142 us against a fixed 5), 4 at 1.9, 5 at 2.5 (C3), 6.5 at 3.8, 6-8 at 5
-    // (2 M queries: 362 -> 299 us) — the line below.
+    // Chunks costlier than `factor` x the median chunk are walked by 8-lane groups: a third of the dependent trips for
+    // ~2.7x the lane-cycles.  That trade pays while the launch is bound by its slowest wave, i.e. while there are few
+    // chunks per resident wave; once the waves are busy for several rounds the extra lane-cycles only lengthen the launch.
+    // Measured (tools/heavy_sweep4.py, model 100 k, steady state, kernel us at factor none / 2 / 3 / 5):
+    //   0.25 chunks per wave (C2)  98 / 62 / 62 / 80      0.3 (a 1/8 shard) 130 / 70 / 69 / 100      0.6  154 / 79 / 99 / 139
+    //   1.3 (500 k queries)       168 / 138 / 132 / 156   2.5 (C3)          177 / 261 / 232 / 254  <- none is best
     static const float heavy_env = [] { const char *e = dev_env("OPE_HEAVY_FACTOR"); return e ? (float)atof(e) : -1.0f; }();
     const float chunks_per_wave = (float)nch / (float)(ctx->n_cu * 4 * kAccWavesPerSimd);
-    const float heavy_factor = heavy_env >= 0.f ? heavy_env : std::min(7.0f, std::max(2.0f, 1.2f + 1.5f * chunks_per_wave));
+    const float heavy_factor = heavy_env >= 0.f ? heavy_env
+                               : (chunks_per_wave > kHeavyMaxChunksPerWave ? 0.0f : std::min(7.0f, std::max(2.0f, 1.2f + 1.5f * chunks_per_wave)));
     plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch, heavy_factor, ctx->d_work_counter + 8);
     ctx->plan_valid = true;
   }
@@ -356,6 +361,7 @@ int ope_cloud_upload(ope_ctx *ctx, const void *base, size_t n, size_t stride_byt
 
 int ope_cloud_set_normals(ope_ctx *ctx, ope_cloud *cloud, const float *normals_xyz) {
   if (!ctx || !cloud || !normals_xyz) return set_err(ctx, OPE_EINVAL, "ope_cloud_set_normals: bad argument");
+  { const int rch = cloud->ensure_host(); if (rch != OPE_OK) return rch; }
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   const size_t n = cloud->n;
   std::vector<float> packed(n * 4);
@@ -383,6 +389,76 @@ void ope_cloud_free(ope_cloud *cloud) {
   delete cloud;
 }
 
+int ope_cloud::ensure_host() const {
+  if (host_valid) return OPE_OK;
+  // sorted float4 {x, y, z, original index} -> original-order xyz + permutation
+  std::vector<float> sorted(4 * n);
+  if (n) {
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMemcpy(sorted.data(), d_xyzw, sizeof(float4) * n, hipMemcpyDeviceToHost) != hipSuccess)
+      return ope::set_err(ctx, OPE_EHIP, "ope_cloud: could not fetch a device-made cloud");
+  }
+  h_xyz.resize(3 * n);
+  perm.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    int32_t o;
+    std::memcpy(&o, &sorted[4 * i + 3], 4);
+    perm[i] = o;
+    std::memcpy(&h_xyz[3 * (size_t)o], &sorted[4 * i], 12);
+  }
+  host_valid = true;
+  return OPE_OK;
+}
+
+int ope_cloud_concat(ope_ctx *ctx, const ope_cloud *a, const float T_a[16], const ope_cloud *b, ope_cloud **out) {
+  if (!ctx || !a || !b || !out) return set_err(ctx, OPE_EINVAL, "ope_cloud_concat: bad argument");
+  *out = nullptr;
+  const size_t n = a->n + b->n;
+  if (n > (size_t)0x7fffffff) return set_err(ctx, OPE_EINVAL, "ope_cloud_concat: more than 2^31-1 points");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  ope_cloud *c = new ope_cloud();
+  c->ctx = ctx;
+  c->n = n;
+  c->n_valid = a->n_valid + b->n_valid;
+  c->host_valid = false;
+  float rows[12];
+  float *d_rows = nullptr, *d_raw = nullptr;
+  int32_t *d_perm = nullptr;
+  hipError_t e = hipMalloc((void **)&c->d_xyzw, sizeof(float4) * std::max<size_t>(n, 1));
+  if (e == hipSuccess && n) e = hipMalloc((void **)&d_raw, 12 * n);
+  if (e == hipSuccess && n) e = hipMalloc((void **)&d_perm, 4 * n);
+  if (e == hipSuccess && T_a) {
+    colmajor_to_rows(T_a, rows);
+    e = hipMalloc((void **)&d_rows, sizeof rows);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows, sizeof rows, hipMemcpyHostToDevice, ctx->stream);
+  }
+  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  if (e == hipSuccess && n) e = concat_device(ctx->stream, a->view(), d_rows, b->view(), d_raw, lo, hi);
+  if (e == hipSuccess && n) {
+    if (c->n_valid == 0) { for (int d = 0; d < 3; ++d) lo[d] = hi[d] = 0.f; }
+    std::memcpy(c->bb_lo, lo, sizeof lo);
+    std::memcpy(c->bb_hi, hi, sizeof hi);
+    float inv[3];
+    for (int d = 0; d < 3; ++d) inv[d] = (hi[d] > lo[d]) ? 1023.999f / (hi[d] - lo[d]) : 0.f;
+    e = morton_order_device(ctx->stream, d_raw, n, lo, inv, c->d_xyzw, d_perm);
+  }
+  for (void *p : {(void *)d_rows, (void *)d_raw, (void *)d_perm})
+    if (p) (void)hipFree(p);
+  if (e != hipSuccess) {
+    ope_cloud_free(c);
+    return set_err(ctx, OPE_EHIP, std::string("ope_cloud_concat: ") + hipGetErrorString(e));
+  }
+  *out = c;
+  return OPE_OK;
+}
+
+int ope_cloud_download(ope_ctx *ctx, const ope_cloud *cloud, float *out_xyz) {
+  if (!ctx || !cloud || (cloud->n && !out_xyz)) return set_err(ctx, OPE_EINVAL, "ope_cloud_download: bad argument");
+  const int rc = cloud->ensure_host();
+  if (rc != OPE_OK) return rc;
+  if (cloud->n) std::memcpy(out_xyz, cloud->h_xyz.data(), 12 * cloud->n);
+  return OPE_OK;
+}
+
 // ------------------------------------------------------------------------------------------ index
 void ope_index_default_params(ope_index_params *p) {
   if (p) { p->leaf_size = 16; p->grid = 1; p->grid_fill = 0.f; p->grid_max_cells = 0; }
@@ -400,6 +476,7 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
   if (params) dp = *params;
   const size_t n = target->n_valid;
   static const bool host_build = dev_env("OPE_HOST_BUILD") != nullptr;  // developer A/B switch: the host reference builder
+  if (host_build) { const int rch = target->ensure_host(); if (rch != OPE_OK) return rch; }
   if (!host_build) {
     // the finite points are the first n_valid records of the Morton-sorted device copy (w = original index)
     ope_index *ix = new ope_index();
@@ -500,6 +577,7 @@ static int upload_T(ope_ctx *ctx, const float *T, float **d_T) {
 int ope_nn_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *index, const float *T, int32_t *out_idx,
                   float *out_d2) {
   if (!ctx || !queries || !index || !out_idx || !out_d2) return set_err(ctx, OPE_EINVAL, "ope_nn_search: bad argument");
+  { const int rch = queries->ensure_host(); if (rch != OPE_OK) return rch; }
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   const size_t n = queries->n;
   if (n == 0) return OPE_OK;
@@ -532,6 +610,7 @@ int ope_knn_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *inde
                    int32_t *out_idx, float *out_d2) {
   if (!ctx || !queries || !index || !out_idx || !out_d2 || k < 1 || k > 32)
     return set_err(ctx, OPE_EINVAL, "ope_knn_search: bad argument (1 <= k <= 32)");
+  { const int rch = queries->ensure_host(); if (rch != OPE_OK) return rch; }
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   const size_t n = queries->n;
   if (n == 0) return OPE_OK;
@@ -987,6 +1066,7 @@ int ope_icp_correspondences(ope_ctx *ctx, int32_t *index_query, int32_t *index_m
     return set_err(ctx, OPE_ESTATE, "ope_icp_correspondences: no finished run whose source cloud is still alive");
   const ope_cloud *src = ctx->run_src;
   const size_t n = src->n;
+  { const int rch = src->ensure_host(); if (rch != OPE_OK) return rch; }
   std::vector<int32_t> hm(n);
   std::vector<float> hd(n);
   OPE_HIP(ctx, hipSetDevice(ctx->device));
@@ -1077,6 +1157,7 @@ int ope_rigid_transform_svd(ope_ctx *ctx, const float *src_xyz, const float *tgt
 
 int ope_transform_cloud(ope_ctx *ctx, const ope_cloud *cloud, const float T[16], float *out_xyz) {
   if (!ctx || !cloud || !T || !out_xyz) return set_err(ctx, OPE_EINVAL, "ope_transform_cloud: bad argument");
+  { const int rch = cloud->ensure_host(); if (rch != OPE_OK) return rch; }
   for (size_t i = 0; i < cloud->n; ++i) {
     const float *p = &cloud->h_xyz[3 * i];
     float *o = out_xyz + 3 * i;

@@ -545,6 +545,7 @@ int ope_radius_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *i
                       int32_t *counts, int32_t *out_idx, float *out_d2) {
   if (!ctx || !queries || !index || !counts || max_nn < 0 || max_nn > kKnnMaxK || (max_nn > 0 && (!out_idx || !out_d2)))
     return set_err(ctx, OPE_EINVAL, "ope_radius_search: bad argument (0 <= max_nn <= 32)");
+  { const int rch = queries->ensure_host(); if (rch != OPE_OK) return rch; }
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   const size_t n = queries->n;
   if (n == 0) return OPE_OK;
@@ -625,6 +626,7 @@ static int normals_impl(ope_ctx *ctx, ope_cloud *cloud, const ope_index *index, 
     if (want_host) packed = nan4;
   }
   if (!want_host) return OPE_OK;
+  { const int rch = cloud->ensure_host(); if (rch != OPE_OK) return rch; }
   for (size_t i = 0; i < n; ++i) {
     const size_t o = (size_t)cloud->perm[i];
     if (out_normals) { out_normals[3 * o] = packed[4 * i]; out_normals[3 * o + 1] = packed[4 * i + 1]; out_normals[3 * o + 2] = packed[4 * i + 2]; }
@@ -728,6 +730,8 @@ int ope_sacia(ope_ctx *ctx, const ope_cloud *src, const float *src_feat33, const
   const int ns = (int)src->n, nt = (int)tgt->n, S = p.nr_samples, K = p.k_correspondences, H = p.max_iterations;
   if (S < 1 || ns < S || nt < 1 || H < 1 || K < 1 || K > kFeatK)
     return set_err(ctx, OPE_EINVAL, "ope_sacia: need nr_samples <= |source|, 1 <= k_correspondences <= 8");
+  { const int rch = src->ensure_host(); if (rch != OPE_OK) return rch; }
+  { const int rch = tgt->ensure_host(); if (rch != OPE_OK) return rch; }
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   TraceRange r_sac(ctx, "sacia");
 

@@ -178,8 +178,12 @@ struct ope_cloud {
   size_t n = 0, n_valid = 0;
   float4 *d_xyzw = nullptr;
   float4 *d_nrm = nullptr;
-  std::vector<float, default_init_allocator<float>> h_xyz;   // original order, n*3
-  std::vector<int32_t, default_init_allocator<int32_t>> perm;   // sorted position -> original index
+  // Host mirrors (original order xyz; sorted position -> original index).  Clouds made on the device (ope_cloud_concat)
+  // materialise them on first use: ensure_host().
+  mutable std::vector<float, default_init_allocator<float>> h_xyz;   // original order, n*3
+  mutable std::vector<int32_t, default_init_allocator<int32_t>> perm;   // sorted position -> original index
+  mutable bool host_valid = true;
+  int ensure_host() const;   // api.hip; OPE_OK or an error code (message in ctx)
   float bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
   ope::CloudView view() const {
     return ope::CloudView{d_xyzw, d_nrm, (uint32_t)n, (uint32_t)n_valid};

@@ -124,11 +124,12 @@ __global__ void grid_plan_heavy_kernel(const uint32_t *cost_sorted_desc, uint32_
   const float cpw = (float)n / (float)max(n_waves, 1u);
   const float factor = factor_override >= 0.f ? factor_override : fminf(7.0f, fmaxf(2.0f, 1.2f + 1.5f * cpw));
   uint32_t nh = 0;
-  if (factor_override < 0.f && 2u * n <= n_waves) {
-    // Tree-class queries are the ones far from the surface: long private walks.  While eight lanes per query still fit
-    // the launch (8 n_tc slots <= 4 per wave), all of them are walked by 8-lane groups (C3: 225 -> 1xx us with ~1.4 k
-    // tree chunks on 6144 waves); beyond that the costliest ones only.
-    nh = n;
+  // 8-lane group walks trade lane-cycles for latency: only while the launch is latency-bound (see enqueue_accumulate).
+  // Here the load of a launch is its tree chunks (x8 if walked by groups) plus the grid chunks at about a third each.
+  const uint32_t n_gc = (min(plan_info[1], n_valid) + 63u) / 64u;
+  const float load = (8.0f * (float)n + 0.33f * (float)n_gc) / (float)max(n_waves, 1u);
+  if (factor_override < 0.f && load > 1.8f) {
+    nh = 0;
   } else if (factor > 0.f && n >= 8) {
     const float thr = factor * (float)cost_sorted_desc[n / 2];
     uint32_t lo = 0, hi = n / 4;
@@ -237,6 +238,68 @@ hipError_t morton_order_device(hipStream_t stream, const float *d_raw, size_t n,
   for (void *p : {(void *)d_keys, (void *)d_keys2, d_tmp})
     if (p) (void)hipFree(p);
   return e;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ope_cloud_concat: raw (original-order) xyz of [T * a ; b] and its bounding box, on the device.
+// pcl::transformPointCloud (float, ((r0 x + r1 y) + r2 z) + t, non-finite points passed through) followed by
+// operator+= (BuildModel regmeshpcd.cpp:203,254).
+__global__ __launch_bounds__(256) void concat_kernel(CloudView a, const float *__restrict__ T_rows, CloudView b, float *__restrict__ raw,
+                                                     uint32_t *__restrict__ mn, uint32_t *__restrict__ mx) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t n = a.n + b.n;
+  float x = 0.f, y = 0.f, z = 0.f;
+  bool fin = false;
+  if (i < n) {
+    const bool from_a = i < a.n;
+    const float4 p = from_a ? a.xyzw[i] : b.xyzw[i - a.n];
+    const uint32_t o = (uint32_t)__float_as_int(p.w) + (from_a ? 0u : a.n);
+    fin = from_a ? (i < a.n_valid) : (i - a.n < b.n_valid);
+    x = p.x; y = p.y; z = p.z;
+    if (from_a && fin && T_rows != nullptr) {
+      x = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T_rows[0], p.x), __fmul_rn(T_rows[1], p.y)), __fmul_rn(T_rows[2], p.z)), T_rows[3]);
+      y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T_rows[4], p.x), __fmul_rn(T_rows[5], p.y)), __fmul_rn(T_rows[6], p.z)), T_rows[7]);
+      z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T_rows[8], p.x), __fmul_rn(T_rows[9], p.y)), __fmul_rn(T_rows[10], p.z)), T_rows[11]);
+      fin = isfinite(x) && isfinite(y) && isfinite(z);
+    }
+    raw[3 * (size_t)o] = x; raw[3 * (size_t)o + 1] = y; raw[3 * (size_t)o + 2] = z;
+  }
+  // bounding box of the finite points: order-preserving integer keys, wave reduction, one atomic per wave and axis
+  const float v[3] = {x, y, z};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const uint32_t u = (uint32_t)__float_as_int(v[d]);
+    const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    uint32_t lo = fin ? key : 0xffffffffu, hi = fin ? key : 0u;
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+      hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+    }
+    if ((threadIdx.x & 63u) == 0) { atomicMin(mn + d, lo); atomicMax(mx + d, hi); }
+  }
+}
+
+hipError_t concat_device(hipStream_t stream, const CloudView &a, const float *d_T_rows, const CloudView &b, float *d_raw, float lo[3],
+                         float hi[3]) {
+  const uint32_t n = a.n + b.n;
+  uint32_t *d_mm = nullptr;
+  hipError_t e = hipMalloc((void **)&d_mm, 32);
+  uint32_t init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0u, 0u, 0u, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(d_mm, init, sizeof init, hipMemcpyHostToDevice, stream);
+  uint32_t res[8];
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(concat_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a, d_T_rows, b, d_raw, d_mm, d_mm + 4);
+    e = hipMemcpyAsync(res, d_mm, sizeof res, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  }
+  if (d_mm) (void)hipFree(d_mm);
+  if (e != hipSuccess) return e;
+  for (int d = 0; d < 3; ++d) {
+    auto unkey = [](uint32_t k) { const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; std::memcpy(&f, &u, 4); return f; };
+    lo[d] = unkey(res[d]);
+    hi[d] = unkey(res[4 + d]);
+  }
+  return hipSuccess;
 }
 
 }  // namespace ope

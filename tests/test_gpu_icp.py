@@ -418,7 +418,7 @@ def test_icp_point_to_plane_lm_matches_oracle(ctx, corr):
     Q = apply(Tgt, synth.model_surface(6000, 6) + np.array([0, 0, 0.6], np.float32))
     _, nQ0 = synth.model_surface(6000, 6, return_normals=True)
     nQ = (nQ0.astype(np.float64) @ Tgt[:3, :3].T).astype(np.float32)
-    kw = dict(max_iterations=12, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, max_corr_dist=0.01)
+    kw = dict(max_iterations=30, transformation_epsilon=1e-8, euclidean_fitness_epsilon=1e-8, max_corr_dist=0.01)   # regmeshpcd.cpp:179-184
     if corr == "normal_shooting":
         kw.update(corr_mode=1, k_normal_shooting=20, use_surface_normal_rej=1, surface_normal_thr=0.7, max_corr_dist=float(np.sqrt(np.finfo(np.float64).max)))
     cs = ctx.upload(P, nP); ct = ctx.upload(Q, nQ); ix = ctx.build_index(ct)
@@ -426,7 +426,9 @@ def test_icp_point_to_plane_lm_matches_oracle(ctx, corr):
     refs = [oracle.icp(P, Q, orc_params(acc_mode=1, transform_mode=1, estimator=2, lm_precision=prec, mse_threshold_absolute=-1.0, **kw),
                        src_nrm=nP, tgt_nrm=nQ) for prec in (0, 1)]
     gap = frob(refs[0].T, refs[1].T)
-    assert out.iterations == refs[0].iterations == 12
+    # near the fixed point LM in float keeps taking rounding-sized steps, in double it returns x = 0 (and the loop stops
+    # on the TRANSFORM criterion): the iteration counts may differ by a few, the transforms may not
+    assert abs(out.iterations - refs[0].iterations) <= 3 and abs(out.iterations - refs[1].iterations) <= 3
     assert frob(out.T, refs[0].T) < 1e-4 and frob(out.T, refs[1].T) < 1e-4, (frob(out.T, refs[0].T), frob(out.T, refs[1].T), gap)
     assert abs(out.n_corr - refs[0].n_corr) <= 3
     assert frob(out.T, Tgt) < 5e-3
@@ -444,7 +446,7 @@ def test_icp_point_to_plane_lm_matches_oracle(ctx, corr):
 def test_lm_estimator_is_refused_by_the_stepwise_api_and_without_target_normals(ctx):
     ope = load_pkg()
     P, nP = synth.model_surface(800, 5, return_normals=True)
-    cs = ctx.upload(P)
+    cs = ctx.upload(apply(rigid(2, -1, 3, [0.003, 0.001, -0.002]), P))
     with pytest.raises(ope.OpeError) as e:
         ctx.icp(cs, ctx.build_index(ctx.upload(P)), ope.default_icp_params(estimator=ope.EST_POINT_TO_PLANE_LM))
     assert e.value.code == ope.OPE_EINVAL

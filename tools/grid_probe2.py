@@ -6,8 +6,8 @@ ope = importlib.import_module("object-pose-estimation_amd")
 synth = importlib.import_module("object-pose-estimation_amd.synth")
 tgt = synth.model_surface(100_000, 1)
 guess = np.linalg.inv(synth.ground_truth_pose()).astype(np.float32)
-for frac in [float(a) for a in (sys.argv[1:] or ["0.10", "0.0"])]:
-    src = synth.scene_cloud(1_000_000, clutter_frac=frac)
+for frac, nq in [(0.10, 1_000_000), (0.0, 1_000_000), (0.10, 125_000), (0.0, 125_000)]:
+    src = synth.scene_cloud(1_000_000, clutter_frac=frac)[:nq]
     for name, kw in (("tree", dict(grid=0)), ("auto", dict(grid=1)), ("grid", dict(grid=2))):
         ctx = ope.Context(0)
         cs = ctx.upload(src); ix = ctx.build_index(ctx.upload(tgt), **kw)
@@ -18,5 +18,5 @@ for frac in [float(a) for a in (sys.argv[1:] or ["0.10", "0.0"])]:
         t0 = time.time(); ctx.icp_iterate(100); ctx.sync(); dt = time.time() - t0
         km, kn = ctx.icp_profile_read()
         out = ctx.icp_end()
-        print(f"clutter {frac:.2f} {name:6s}: {dt/100*1e6:7.1f} us/iteration  kernel {km/kn*1e3:7.1f} us  mse {out.last_mse:.4e}", flush=True)
+        print(f"clutter {frac:.2f} n {nq:8d} {name:6s}: {dt/100*1e6:7.1f} us/iteration  kernel {km/kn*1e3:7.1f} us  mse {out.last_mse:.4e}", flush=True)
         ctx.close()
