@@ -80,25 +80,57 @@ def get_icp_normal(ope, ctx, source_xyz, target_xyz, corr_rej_thresh: float = 0.
 
 
 def register_point_clouds(ope, ctx, frames, max_corr_dist: float = 0.005, corr_rej_thresh: float = 0.7,
-                          max_iterations: int = 500, colors=None, **kw) -> RegistrationResult:
+                          max_iterations: int = 500, colors=None, on_device: bool = True, k_normals: int = 12,
+                          estimator: str = "lm", use_max_corr_dist_in_icp: bool = False) -> RegistrationResult:
     """Sequential accumulate-and-register over N frames (regmeshpcd.cpp:210-271).
 
     cloudTemp = frame 0; for every next frame: align cloudTemp to it, then cloudTemp = aligned + frame.
     `colors` (one packed-rgb uint32 array per frame, the PointXYZRGB payload) ride along untouched, as the rgb
     field does through transformPointCloud and operator+= in the reference.
+
+    on_device (default): the accumulated cloud never leaves the GPU between pairs — every frame is uploaded once,
+    `aligned + target` is ope_cloud_concat (transform, append and re-sort on the device) and the result is fetched once
+    at the end.  on_device=False goes through get_icp_normal pair by pair (host clouds in and out, as the reference's
+    function signature has it); both give the same numbers.
     """
     if len(frames) == 0:
         raise ValueError("register_point_clouds: no frames")
     if colors is not None and (len(colors) != len(frames) or any(len(c) != len(f) for c, f in zip(colors, frames))):
         raise ValueError("register_point_clouds: colors must match the frames point for point")
-    acc = np.ascontiguousarray(frames[0], np.float32)
-    res = RegistrationResult(acc)
-    for i in range(len(frames) - 1):
-        target = np.ascontiguousarray(frames[i + 1], np.float32)
-        aligned, pr = get_icp_normal(ope, ctx, acc, target, corr_rej_thresh, max_iterations, max_corr_dist, **kw)
-        acc = np.concatenate([aligned, target], axis=0)   # :254-258
-        res.pairs.append(pr)
-    res.cloud = acc
+    res = RegistrationResult(np.ascontiguousarray(frames[0], np.float32))
+    if not on_device:
+        acc = res.cloud
+        for i in range(len(frames) - 1):
+            target = np.ascontiguousarray(frames[i + 1], np.float32)
+            aligned, pr = get_icp_normal(ope, ctx, acc, target, corr_rej_thresh, max_iterations, max_corr_dist,
+                                         use_max_corr_dist_in_icp, k_normals, estimator)
+            acc = np.concatenate([aligned, target], axis=0)   # :254-258
+            res.pairs.append(pr)
+        res.cloud = acc
+    else:
+        p = icp_params_with_normals(ope, corr_rej_thresh, max_iterations, max_corr_dist if use_max_corr_dist_in_icp else None, estimator)
+        acc = ctx.upload(res.cloud)
+        try:
+            for i in range(len(frames) - 1):
+                tgt = ctx.upload(np.ascontiguousarray(frames[i + 1], np.float32))
+                index = None
+                try:
+                    ctx.normals(acc, k_normals, fetch=False)     # :72-84
+                    ctx.normals(tgt, k_normals, fetch=False)     # :86-90
+                    index = ctx.build_index(tgt)
+                    out = ctx.icp(acc, index, p)                 # :196
+                    fit, _, _ = ctx.fitness(acc, index, out.T)   # :198
+                    res.pairs.append(PairResult(out.T, out.iterations, out.converged, fit, acc.n, tgt.n))
+                    nxt = ctx.concat(acc, out.T, tgt)            # :203 transformPointCloud, :254 += target
+                finally:
+                    if index is not None:
+                        index.free()
+                acc.free()
+                tgt.free()
+                acc = nxt
+            res.cloud = ctx.download(acc)
+        finally:
+            acc.free()
     if colors is not None:
         res.rgb = np.concatenate([np.ascontiguousarray(c, np.uint32) for c in colors])
     return res

@@ -29,6 +29,7 @@ void launch_icp_accumulate_grid(hipStream_t, int, bool, const CloudView &, const
 int grid_plan(hipStream_t, bool, const unsigned char *, uint32_t, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, const uint32_t *,
               uint32_t *, uint32_t, uint32_t, float, void *, size_t);
 size_t grid_plan_tmp_bytes(uint32_t, uint32_t);
+void grid_count_far(hipStream_t, const float *, uint32_t, float, uint32_t *);
 hipError_t build_grid_device(hipStream_t, const float4 *, const float4 *, size_t, const float[3], const float[3], double, uint32_t, GridView *,
                              float4 **, float4 **, uint32_t **, uint32_t **);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
@@ -45,6 +46,7 @@ int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count);
 static thread_local std::string g_global_err;
 
 constexpr double kGridMaxTreeShare = 0.03;
+constexpr size_t kGridMinQueries = 0;
 constexpr float kHeavyMaxChunksPerWave = 1.8f;   // beyond this the launch is throughput-bound: no 8-lane group walks
 
 // Developer A/B switches and sweeps (tools/*.py) read the environment only in builds made with -DOPE_DEVELOPER
@@ -114,21 +116,22 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     const ope_icp_params &p = ctx->run_params;
     const bool nrm = p.use_surface_normal_rej || p.use_self_occluded_rej || p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
     const bool plan_step = !no_plan && nch > 1 && it_done >= 1 && (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0);
-    // Which path a run is better served by is measured, not guessed: the share of TREE-class queries (far from the
-    // surface: the grid cannot answer them and each is a long private walk) is read back asynchronously after the plan
-    // steps.  Above kGridMaxTreeShare the run continues on the tree kernel, whose packet / per-lane / group scheduling
-    // is built around exactly that mix (C3 frame, 9 % clutter: 269 us per iteration against 283 us here; the
-    // clutter-free cluster of the same frame: 110 us on the tree kernel, 78 us here).
+    // Which kernel a run is better served by is measured, not guessed: the share of queries whose nearest model point is
+    // further away than one grid cell (clutter: the grid can never answer them, each is a long private walk) is counted
+    // on the device at the plan steps and read back asynchronously.  Above kGridMaxTreeShare the run continues on the tree
+    // kernel, whose packet / per-lane / group scheduling is built around exactly that mix (steady state, kernel us, tree /
+    // grid: C3 frame with 9 % clutter 174 / 214, its clutter-free cluster 110 / 88; a 1/8 shard 70 / 124 and 36 / 27).
     if (ctx->grid_probe_pending && hipEventQuery(ctx->grid_probe_event) == hipSuccess) {
       ctx->grid_probe_pending = false;
-      const uint32_t n_grid_q = *ctx->h_grid_probe;
-      const double tree_share = 1.0 - (double)n_grid_q / (double)std::max<size_t>(ctx->run_src->n_valid, 1);
-      if (dev_env("OPE_TRACE_GRID")) fprintf(stderr, "[ope] grid probe at launch %d: n_grid_q %u of %zu (tree share %.4f), mode %d\n", it_done, n_grid_q, ctx->run_src->n_valid, tree_share, ctx->run_tgt->grid_mode);
+      const uint32_t n_far = *ctx->h_grid_probe;
+      const double tree_share = (double)n_far / (double)std::max<size_t>(ctx->run_src->n_valid, 1);
+      if (dev_env("OPE_TRACE_GRID")) fprintf(stderr, "[ope] grid probe at launch %d: %u of %zu queries beyond one cell of the target (share %.4f), mode %d\n", it_done, n_far, ctx->run_src->n_valid, tree_share, ctx->run_tgt->grid_mode);
       if (tree_share > kGridMaxTreeShare && ctx->run_tgt->grid_mode != 2) {
         ctx->use_grid = false;
         ctx->plan_valid = false;   // chunk ids mean something else to the tree kernel
         OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * (size_t)(nch + 1), ctx->stream));
         OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 8, 0, 8, ctx->stream));
+        ctx->force_plan_at = it_done + 2;   // as soon as two launches have measured their chunks
         --ctx->acc_launches;
         return enqueue_accumulate(ctx, atomic_sums);
       }
@@ -141,8 +144,10 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
                     (uint32_t)ctx->acc_blocks * (kAccBlock / 64), heavy_env, ctx->d_part_tmp, ctx->part_tmp_bytes) != 0)
         return set_err(ctx, OPE_EHIP, "grid plan step failed");
       ctx->plan_valid = true;
-      if (repart && it_done >= 2 && !ctx->grid_probe_pending && ctx->grid_probe_event) {
-        OPE_HIP(ctx, hipMemcpyAsync(ctx->h_grid_probe, ctx->d_work_counter + 9, 4, hipMemcpyDeviceToHost, ctx->stream));
+      if (repart && it_done >= 2 && !ctx->grid_probe_pending && ctx->grid_probe_event && ctx->run_tgt->grid_mode != 2) {
+        const float cell = 1.0f / ctx->run_tgt->grid.inv;
+        grid_count_far(ctx->stream, ctx->d_corr_d2, (uint32_t)ctx->run_src->n_valid, cell * cell, ctx->d_work_counter + 8);
+        OPE_HIP(ctx, hipMemcpyAsync(ctx->h_grid_probe, ctx->d_work_counter + 10, 4, hipMemcpyDeviceToHost, ctx->stream));
         OPE_HIP(ctx, hipEventRecord(ctx->grid_probe_event, ctx->stream));
         ctx->grid_probe_pending = true;
       }
@@ -159,7 +164,8 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     }
     return OPE_OK;
   }
-  if (!no_plan && nch > 1 && it_done >= 1 && (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0)) {
+  if (!no_plan && nch > 1 && it_done >= 1 &&
+      (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0 || it_done == ctx->force_plan_at)) {
     size_t tb = ctx->plan_tmp_bytes;
     if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
                    ctx->d_plan_tmp, tb) != 0)
@@ -736,7 +742,9 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     ctx->corr_cap = std::max<size_t>(src->n, 1);
   }
   ctx->use_grid = false;
-  if (p.corr_mode == OPE_CORR_NEAREST && !p.use_reciprocal && tgt->want_grid && src->n_valid > 0 && p.estimator != OPE_EST_POINT_TO_PLANE_LM) {
+  ctx->force_plan_at = -1;
+  if (p.corr_mode == OPE_CORR_NEAREST && !p.use_reciprocal && tgt->want_grid && src->n_valid > 0 && p.estimator != OPE_EST_POINT_TO_PLANE_LM &&
+      (tgt->grid_mode == 2 || src->n_valid >= kGridMinQueries)) {
     const int rcg = ensure_grid(ctx, tgt);
     if (rcg != OPE_OK) return rcg;
     ctx->use_grid = tgt->has_grid;

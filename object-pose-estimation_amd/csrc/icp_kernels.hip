@@ -299,7 +299,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
 //
 // The typical ICP query is a scene point whose previous match t_prev is still (nearly) its nearest neighbour.  Then
 // every model point that can beat it lies in the ball |x - q| <= |q - t_prev|, and the ball overlaps only a handful of
-// cells of the uniform grid over the model (grid_build.hip): at most kGridMaxRows x-runs of at most kGridMaxX cells,
+// cells of the uniform grid over the model (grid_build.hip): at most 9 x-runs of at most kGridMaxSpan cells,
 // each ONE contiguous run of the cell-sorted points.  Exact by construction: the cell range of the ball is computed with
 // the same monotone fp32 expression that assigned the points to cells, from a radius inflated past every rounding, and
 // every point of those runs is tested with the oracle's unfused distance.  Two dependent fetches (cell bounds, points)
@@ -309,8 +309,8 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
 // up whole waves of grid queries, the launch works through a query ORDER (qorder) that lists the grid-class queries
 // first and the tree-class queries after them, re-partitioned from the per-query class flags at the plan steps; a query
 // whose class has changed since is simply served by the other path, in place.
-constexpr int kGridMaxRows = 4;   // (y, z) rows of cells a query may touch
-constexpr int kGridMaxX = 3;      // cells per row
+constexpr int kGridMaxSpan = 3;    // cells per axis a query's ball may span (27 cells, 9 rows of up to 3)
+constexpr int kGridRowBatch = 4;   // rows whose bounds are fetched together
 
 __device__ __forceinline__ void grid_axis_range(float c, float r, float lo, float inv, int dim, int &a, int &b) {
   // same expression as grid_cell_of (grid_build.hip): floor((x - lo) * inv), monotone in x
@@ -328,41 +328,42 @@ __device__ __forceinline__ bool grid_scan(const GridView &g, float qx, float qy,
   grid_axis_range(qz, r, g.lo[2], g.inv, g.dim[2], az, bz);
   const int ny = by - ay + 1, nz = bz - az + 1, nrow = ny * nz;
   if (ny <= 0 || nz <= 0 || bx < ax) return true;   // the ball misses the box: the previous match stands
-  if (nrow > kGridMaxRows || bx - ax + 1 > kGridMaxX) return false;
-  // bounds of every row first (independent fetches), then the runs; rows in (y fastest, z) order, rows past nrow repeat
-  // the last one (their runs are not scanned)
-  uint32_t rs[kGridMaxRows], re[kGridMaxRows];
-  {
-    int iy = ay, iz = az;
+  if (ny > kGridMaxSpan || nz > kGridMaxSpan || bx - ax + 1 > kGridMaxSpan) return false;
+  // rows in (y fastest, z) order, kGridRowBatch at a time: the bounds of a batch first (independent fetches), then its runs.
+  // Most queries need one batch (<= 2 x 2 rows); a query with a larger ball (the tail of the sensor noise) takes up to three
+  // instead of a whole tree walk.
+  int iy = ay, iz = az;
+  for (int done = 0; done < nrow; done += kGridRowBatch) {
+    uint32_t rs[kGridRowBatch], re[kGridRowBatch];
 #pragma unroll
-    for (int k = 0; k < kGridMaxRows; ++k) {
+    for (int k = 0; k < kGridRowBatch; ++k) {
       const uint32_t row = ((uint32_t)iz * (uint32_t)g.dim[1] + (uint32_t)iy) * (uint32_t)g.dim[0];
       rs[k] = g.cell_start[row + (uint32_t)ax];
       re[k] = g.cell_start[row + (uint32_t)bx + 1u];
-      if (k + 1 < nrow) {
+      if (done + k + 1 < nrow) {   // rows past the last one repeat it (their runs are not scanned)
         const bool wrap = iy == by;
         iy = wrap ? ay : iy + 1;
         iz += wrap ? 1 : 0;
       }
     }
-  }
 #pragma unroll
-  for (int k = 0; k < kGridMaxRows; ++k) {
-    if (k < nrow) {
-      for (uint32_t p = rs[k]; p < re[k]; p += 4) {
-        // four 16-byte loads from one base; a batch may run past the run (guarded) and, at the very end of the array,
-        // into the kPtsPad zeroed entries
-        const float4 *pb = g.gpts + p;
-        const v4f p0 = ld16(pb), p1 = ld16(pb + 1), p2 = ld16(pb + 2), p3 = ld16(pb + 3);
-        const float d0 = sq_dist3(__fsub_rn(qx, p0.x), __fsub_rn(qy, p0.y), __fsub_rn(qz, p0.z));
-        const float d1 = sq_dist3(__fsub_rn(qx, p1.x), __fsub_rn(qy, p1.y), __fsub_rn(qz, p1.z));
-        const float d2 = sq_dist3(__fsub_rn(qx, p2.x), __fsub_rn(qy, p2.y), __fsub_rn(qz, p2.z));
-        const float d3 = sq_dist3(__fsub_rn(qx, p3.x), __fsub_rn(qy, p3.y), __fsub_rn(qz, p3.z));
-        const uint32_t e = re[k];
-        if (d0 < best) { best = d0; gpos = p; }
-        if (p + 1 < e && d1 < best) { best = d1; gpos = p + 1; }
-        if (p + 2 < e && d2 < best) { best = d2; gpos = p + 2; }
-        if (p + 3 < e && d3 < best) { best = d3; gpos = p + 3; }
+    for (int k = 0; k < kGridRowBatch; ++k) {
+      if (done + k < nrow) {
+        for (uint32_t p = rs[k]; p < re[k]; p += 4) {
+          // four 16-byte loads from one base; a batch may run past the run (guarded) and, at the very end of the array,
+          // into the kPtsPad zeroed entries
+          const float4 *pb = g.gpts + p;
+          const v4f p0 = ld16(pb), p1 = ld16(pb + 1), p2 = ld16(pb + 2), p3 = ld16(pb + 3);
+          const float d0 = sq_dist3(__fsub_rn(qx, p0.x), __fsub_rn(qy, p0.y), __fsub_rn(qz, p0.z));
+          const float d1 = sq_dist3(__fsub_rn(qx, p1.x), __fsub_rn(qy, p1.y), __fsub_rn(qz, p1.z));
+          const float d2 = sq_dist3(__fsub_rn(qx, p2.x), __fsub_rn(qy, p2.y), __fsub_rn(qz, p2.z));
+          const float d3 = sq_dist3(__fsub_rn(qx, p3.x), __fsub_rn(qy, p3.y), __fsub_rn(qz, p3.z));
+          const uint32_t e = re[k];
+          if (d0 < best) { best = d0; gpos = p; }
+          if (p + 1 < e && d1 < best) { best = d1; gpos = p + 1; }
+          if (p + 2 < e && d2 < best) { best = d2; gpos = p + 2; }
+          if (p + 3 < e && d3 < best) { best = d3; gpos = p + 3; }
+        }
       }
     }
   }

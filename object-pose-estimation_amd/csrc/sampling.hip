@@ -142,6 +142,20 @@ __global__ void grid_plan_heavy_kernel(const uint32_t *cost_sorted_desc, uint32_
   plan_info[0] = nh;
 }
 
+// Share of queries the grid can never answer, whatever the pose: their nearest model point is further away than one
+// cell, so the ball around them spans more than the 27 cells the scan covers (clutter; a query that merely MOVED a lot
+// since the last iteration has a small d2 and comes back to the grid once the loop settles).  plan_info[2] = count.
+__global__ __launch_bounds__(256) void grid_count_far_kernel(const float *__restrict__ corr_d2, uint32_t n_valid, float thr2, uint32_t *__restrict__ plan_info) {
+  uint32_t c = 0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_valid; i += gridDim.x * 256) c += corr_d2[i] > thr2 ? 1u : 0u;
+  for (int off = 32; off >= 1; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off, 64);
+  if ((threadIdx.x & 63u) == 0 && c) atomicAdd(plan_info + 2, c);
+}
+void grid_count_far(hipStream_t stream, const float *corr_d2, uint32_t n_valid, float thr2, uint32_t *plan_info) {
+  (void)hipMemsetAsync(plan_info + 2, 0, 4, stream);
+  hipLaunchKernelGGL(grid_count_far_kernel, dim3(std::min<uint32_t>((n_valid + 255) / 256, 512)), dim3(256), 0, stream, corr_d2, n_valid, thr2, plan_info);
+}
+
 // d_keys: scratch of nch entries.  tmp sized by grid_plan_tmp_bytes.
 int grid_plan(hipStream_t stream, bool repartition, const unsigned char *qclass, uint32_t n_valid, uint32_t *qorder, uint32_t *plan_info,
               const uint32_t *cost, uint32_t *keys, uint32_t *cost_sorted, const uint32_t *ids, uint32_t *order, uint32_t nch, uint32_t n_waves,

@@ -157,3 +157,74 @@ def test_cpp_build_model_program_matches_the_python_driver_and_keeps_colours(env
     xyz, rgb = pcd.read_pcd(out_path)
     assert xyz.shape == (9000, 3) and np.abs(xyz - ref.cloud).max() < 1e-5
     np.testing.assert_array_equal(rgb, ref.rgb)
+
+
+def test_device_resident_loop_equals_the_host_cloud_loop(env):
+    """ope_cloud_concat (transform + append + re-sort on the device, host mirrors materialised lazily) against the loop
+    that goes through host clouds pair by pair: same transforms, same accumulated cloud, bit for bit."""
+    ope, ctx = env
+    frames = synth.frame_views(4, 3000, n_azimuths=32)
+    a = buildmodel.register_point_clouds(ope, ctx, frames, max_iterations=30, on_device=True)
+    b = buildmodel.register_point_clouds(ope, ctx, frames, max_iterations=30, on_device=False)
+    assert len(a.pairs) == len(b.pairs) == 3
+    for pa, pb in zip(a.pairs, b.pairs):
+        assert pa.iterations == pb.iterations and np.abs(np.asarray(pa.T) - np.asarray(pb.T)).max() < 2e-7
+    np.testing.assert_allclose(a.cloud, b.cloud, atol=1e-7)
+    # the concatenated cloud is a full citizen: non-finite points keep their place, searches report original indices
+    x = frames[0].copy(); x[5] = np.nan
+    ca, cb = ctx.upload(x), ctx.upload(frames[1])
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = [0.01, -0.02, 0.03]
+    cc = ctx.concat(ca, T, cb)
+    got = ctx.download(cc)
+    want = np.concatenate([x + T[:3, 3], frames[1]])
+    np.testing.assert_allclose(got, want, atol=1e-7, equal_nan=True)
+    idx, d2 = ctx.nn(cc, ctx.build_index(ctx.upload(want[np.isfinite(want).all(1)])))
+    fin = np.isfinite(want).all(1)
+    assert idx[5] == -1 and (d2[fin] < 1e-12).all()
+
+
+@pytest.mark.timeout(900)
+def test_c5_full_size_thirty_two_frames_of_half_a_million_points(env):
+    """Config C5 at BASELINE's size on one GPU: 32 frames x 500 k points registered one after the other, the source
+    growing to 15.5 M points, LM point-to-plane estimator as the reference installs it.  Checked where a CPU can follow:
+    completion, sizes, every pair's fit, and the LAST pair against the oracle on a sub-sample — one oracle LM estimate
+    from the device's final transform must be (nearly) the identity, i.e. the device stopped at the minimum the oracle
+    sees for the same correspondences."""
+    ope, ctx = env
+    F, N = 32, 500_000
+    pool, pool_n = synth.model_surface(3_000_000, 77, return_normals=True)     # one dense sampling, viewed 32 times
+    frames, poses = [], []
+    for i in range(F):
+        az = 2.0 * np.pi * i / F
+        view = np.array([np.cos(az), np.sin(az), 0.35]); view /= np.linalg.norm(view)
+        vis = np.flatnonzero((pool_n.astype(np.float64) @ view) > 0.05)
+        rng = np.random.default_rng(400 + i)
+        pts = pool[rng.choice(vis, N, replace=len(vis) < N)].astype(np.float64)
+        T = np.eye(4); T[:3, :3] = synth.rot_xyz(*rng.uniform(-3.0, 3.0, 3)); T[:3, 3] = rng.uniform(-0.005, 0.005, 3)
+        pts = pts @ T[:3, :3].T + T[:3, 3] + rng.standard_normal(pts.shape) * 2e-4
+        frames.append(pts.astype(np.float32)); poses.append(T)
+    import time
+    t0 = time.perf_counter()
+    res = buildmodel.register_point_clouds(ope, ctx, frames, corr_rej_thresh=0.7, max_iterations=500)
+    dt = time.perf_counter() - t0
+    print(f"C5: 32 x 500 k registered in {dt:.1f} s; iterations per pair {[p.iterations for p in res.pairs]}")
+    assert len(res.pairs) == F - 1 and res.cloud.shape == (F * N, 3) and np.isfinite(res.cloud).all()
+    assert [p.n_source for p in res.pairs] == [N * (i + 1) for i in range(F - 1)]
+    # (the accumulated source holds every earlier view: the points the last frame does not see keep the score up)
+    assert all(p.converged and p.fitness < 2e-4 for p in res.pairs), [p.fitness for p in res.pairs]
+    # the first pair against the generator: frame 0 -> frame 1 is poses[1] * poses[0]^-1 up to the sampling noise
+    want01 = poses[1] @ np.linalg.inv(poses[0])
+    assert np.linalg.norm(np.asarray(res.pairs[0].T, np.float64) - want01) < 5e-3
+    # last pair on a sub-sample: source = the accumulated cloud before the last pair, moved by the device's transform
+    last = res.pairs[-1]
+    acc_before = res.cloud[: N * (F - 1)]                        # = T_last * (accumulated source): already aligned
+    sub = acc_before[:: 400]                                      # ~39 k points
+    tgt = frames[-1][:: 4]
+    tn, _ = oracle.normals_knn(tgt, 12)
+    sn, _ = oracle.normals_knn(sub, 12)
+    p = oracle.default_icp_params()
+    p.max_iterations = 1; p.corr_mode = 1; p.k_normal_shooting = 20; p.use_surface_normal_rej = 1; p.surface_normal_thr = 0.7
+    p.estimator = 2; p.lm_precision = 1; p.acc_mode = 1; p.transform_mode = 1
+    one = oracle.icp(sub, tgt, p, src_nrm=sn, tgt_nrm=tn)
+    assert np.linalg.norm(one.T.astype(np.float64) - np.eye(4)) < 2e-3, one.T
+    assert dt < 120
