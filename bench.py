@@ -6,15 +6,25 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE ICP iteration (icp_mod.hpp:171-259: correspondence search over all scene points,
-17-sum reduction, SVD transform update, convergence test) on synthetic config C3: a 1 M-point scene
-(source/queries) against a 100 k-point model (target/indexed), inputs resident in HBM, target index
-prebuilt, early exit disabled so exactly W + K iterations execute.  With N > 1 the scene is sharded
-across ranks (strong scaling: total work fixed), the model index is replicated and the 17 fp64 sums
-are all-reduced over RCCL once per iteration.
+17-sum reduction, SVD transform update, convergence test) on synthetic config C3: a 1 M-point frame
+(source/queries, 10 % clutter included) against a 100 k-point model (target/indexed), inputs resident in HBM,
+target index prebuilt, early exit disabled so exactly W + K (+ the steady-state phase's) iterations execute.
+With N > 1 the frame is sharded across ranks (strong scaling: total work fixed), the model index is replicated and
+the 17 fp64 sums are all-reduced over RCCL once per iteration.
 
-Rank 0 prints one JSON line with `roofline` (dominant kernel = icp_accumulate_kernel, timed with HIP
-events on its launch stream inside the timed region) and, at N = 1, `cpu_baseline` (the C oracle, a
-scalar single-thread port of the PCL path, on a bounded sample of the same workload).
+The run starts where the reference's own flow would start it (config C3 = "FPFH init + 100 ICP iters"): pass-through
+crop of the frame (rosinterface.cpp:212), the reference's statistical outlier removal (processingpcd.cpp:62-77) standing
+in for the segmentation this repo does not build, estimateCoarsePose (uniform key points, normals, FPFH, SAC-IA) on the
+resulting cluster.  `pose_check` then asserts two things: the cluster's ICP from that pose lands within 1e-2 Frobenius of
+the generator's pose (the reference flow end to end), and the timed run over the whole frame ends in the right basin
+(its 10 % clutter, with no correspondence distance limit, pulls the fit by a few degrees — the oracle lands on the same
+pose).  A failed check prints the JSON line and exits 4.
+
+Rank 0 prints one JSON line with `roofline` (dominant kernel = the accumulate kernel, timed with HIP events on its
+launch stream inside the timed region), `phases` (from the coarse pose = `value`; steady state, reported separately),
+`coarse_stage` (per-kernel HIP-event times with the algorithmic bytes of SURVEY 8d, FPFH points/s, SAC-IA hypotheses/s)
+and, at N = 1, `cpu_baseline` (the C oracle, a scalar single-thread port of the PCL path, on a bounded sample of the same
+workload).
 """
 from __future__ import annotations
 

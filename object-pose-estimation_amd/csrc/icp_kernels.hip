@@ -80,16 +80,16 @@ __device__ __forceinline__ void add_query_sums(double *acc, lds_cfloat_ptr cs2, 
     }
 }
 
-// MODE 0: 1-NN correspondences.  MODE 1: normal shooting over the k nearest (list in LDS, any k <= 32).
-// MODE 2: the same for k = 20, the value the reference uses (poseestimator.cpp:246, regmeshpcd.cpp:144): list in
-// registers, walk started at last iteration's leaf.  MODE 3: the same for k = 10, the class default
-// (vPCL correspondence_estimation_normal_shooting_weighted.h:117).
+// MODE 0: 1-NN correspondences.  MODE 2: normal shooting over the k nearest, list in KREG >= k registers (every k <= 32:
+// KREG = k rounded up to a multiple of four, plus 10, the class default of vPCL
+// correspondence_estimation_normal_shooting_weighted.h:117; the reference uses 20, poseestimator.cpp:246,
+// regmeshpcd.cpp:144), walk started at last iteration's leaf.  (MODE 1, the LDS list of round 1, is no longer dispatched.)
 // NRM: source/target normals present (rejectors and/or normal shooting).
 // RECIP: reciprocal correspondences (vPCL impl/correspondence_estimation_mod.hpp:216-303): keep (i, j) only
 // if the nearest SOURCE point of target point j is i again.  The reference searches a kd-tree rebuilt
 // over the transformed source every iteration; here the source index is built once in the source's own
 // frame and queried with F^-1 * t_j (a rigid map preserves the ranking up to fp32 rounding).
-template <int MODE, bool NRM, bool RECIP = false, bool PACKET = false>
+template <int MODE, bool NRM, bool RECIP = false, bool PACKET = false, int KREG = 20>
 __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !RECIP) ? kAccWavesPerSimd : 4) void icp_accumulate_kernel(
     CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
@@ -210,8 +210,9 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
         ok = ok && r.pos != kNoPos && !((double)r.best > max_d2) &&
              __float_as_int(srcix.pts[r.pos].w) == __float_as_int(s.w);
       }
-    } else if (MODE == 2 || MODE == 3) {
-      constexpr int K = (MODE == 3) ? 10 : 20;
+    } else if (MODE == 2) {
+      // register list of KREG >= k entries: the k nearest are the first k of the KREG nearest
+      constexpr int K = KREG;
       KnnRegVisitor<K> v;
       v.init(active);
       bvh_traverse(tgt, x, y, z, v, stk, BLOCK, active ? hint[i] : 0u);
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       pos = 0;
 #pragma unroll
       for (int j = 0; j < K; ++j) {
-        if (j < v.count) {
+        if (j < v.count && j < kk) {
           const float4 p = tgt.pts[v.p[j]];
           const double vx = (double)__fsub_rn(p.x, x), vy = (double)__fsub_rn(p.y, y), vz = (double)__fsub_rn(p.z, z);
           const double cx = (double)ny * vz - (double)nz * vy;
@@ -1132,12 +1133,24 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
   if (mode == 0) {
     if (recip) { if (nrm) OPE_LAUNCH_ACC(0, true, true, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, true, kAccBlock, 0); }
     else       { if (nrm) OPE_LAUNCH_ACC(0, true, false, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, false, kAccBlock, 0); }
-  } else if (k_normal_shooting == 20) {
-    OPE_LAUNCH_ACC(2, true, false, kKnnBlock, 0);
-  } else if (k_normal_shooting == 10) {
-    OPE_LAUNCH_ACC(3, true, false, kKnnBlock, 0);
   } else {
-    OPE_LAUNCH_ACC(1, true, false, kKnnBlock, kKnnLdsBytes);
+    // normal shooting: the k-nearest list lives in registers for EVERY k <= 32 (instantiations at k rounded up to a
+    // multiple of four, and at the class default 10): the LDS list of round 1 took 2.4 ms per C3 iteration where the
+    // register list takes ~0.5 ms, and held the kernel at two waves per SIMD
+#define OPE_LAUNCH_NS(KR)                                                                                                          \
+  hipLaunchKernelGGL((icp_accumulate_kernel<2, true, false, false, KR>), dim3(nblocks), dim3(kKnnBlock), 0, stream, src, tgt, srcix, st, \
+                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic)
+    const int k = k_normal_shooting;
+    if (k == 10) OPE_LAUNCH_NS(10);
+    else if (k <= 4) OPE_LAUNCH_NS(4);
+    else if (k <= 8) OPE_LAUNCH_NS(8);
+    else if (k <= 12) OPE_LAUNCH_NS(12);
+    else if (k <= 16) OPE_LAUNCH_NS(16);
+    else if (k <= 20) OPE_LAUNCH_NS(20);
+    else if (k <= 24) OPE_LAUNCH_NS(24);
+    else if (k <= 28) OPE_LAUNCH_NS(28);
+    else OPE_LAUNCH_NS(32);
+#undef OPE_LAUNCH_NS
   }
 #undef OPE_LAUNCH_ACC
 }

@@ -8,13 +8,17 @@ for f in find("trace/**/*kernel_stats.csv"):
     for i, row in enumerate(csv.DictReader(open(f))):
         if i < 8:
             print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
-print("== PMC (mean per dispatch of kernels matching 'accumulate') ==")
-agg = collections.defaultdict(list)
+print("== PMC (mean per dispatch, per kernel whose name contains 'accumulate') ==")
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in find("pmc_*/**/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        if "accumulate" not in row.get("Kernel_Name", ""):
+        name = row.get("Kernel_Name", "")
+        if "accumulate" not in name:
             continue
-        agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
-for k in sorted(agg):
-    v = agg[k]
-    print(f"{k:36s} n={len(v):4d} mean={sum(v)/len(v):.4g}")
+        short = name.split("(")[0].replace("void ", "").replace("ope::", "")
+        agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for short in sorted(agg):
+    print(f"-- {short}")
+    for k in sorted(agg[short]):
+        v = agg[short][k]
+        print(f"{k:36s} n={len(v):4d} mean={sum(v)/len(v):.4g}")
