@@ -45,7 +45,7 @@ int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count);
 
 static thread_local std::string g_global_err;
 
-constexpr double kGridMaxTreeShare = 0.03;
+constexpr double kGridMaxTreeShare = 0.03, kGridMinTreeShare = 0.015;
 constexpr size_t kGridMinQueries = 0;
 constexpr float kHeavyMaxChunksPerWave = 1.8f;   // beyond this the launch is throughput-bound: no 8-lane group walks
 
@@ -104,6 +104,49 @@ static double *sums_ptr(ope_ctx *ctx) {
 // run to run.  OPE_DETERMINISTIC_SUMS=1 keeps one row per block and reduces the rows in a fixed tree instead.
 static bool atomic_sums(const ope_ctx *ctx) { return ctx->run_params.deterministic_sums == 0; }
 
+// ---- which 1-NN kernel a run uses (ope_index_params.grid == 1: automatic)
+// The grid kernel is the better one while (nearly) every query has a model point within one grid cell; queries beyond that
+// (clutter, or a source that is still far from aligned) are long tree walks that the tree kernel schedules better.  The
+// share of such queries is counted on the device from the correspondences' d2 at the plan steps, read back asynchronously
+// (no host synchronisation) and acted on with hysteresis: to the tree kernel above kGridMaxTreeShare, back to the grid
+// kernel below kGridMinTreeShare.  Either kernel is exact: the choice only moves time.
+static int grid_probe_issue(ope_ctx *ctx) {
+  if (ctx->grid_probe_pending || !ctx->grid_probe_event || !ctx->grid_auto) return OPE_OK;
+  const float cell = 1.0f / ctx->run_tgt->grid.inv;
+  grid_count_far(ctx->stream, ctx->d_corr_d2, (uint32_t)ctx->run_src->n_valid, cell * cell, ctx->d_work_counter + 8);
+  OPE_HIP(ctx, hipMemcpyAsync(ctx->h_grid_probe, ctx->d_work_counter + 10, 4, hipMemcpyDeviceToHost, ctx->stream));
+  OPE_HIP(ctx, hipEventRecord(ctx->grid_probe_event, ctx->stream));
+  ctx->grid_probe_pending = true;
+  return OPE_OK;
+}
+// returns +1: switch to the grid kernel, -1: switch to the tree kernel, 0: stay
+static int grid_probe_poll(ope_ctx *ctx, int it_done) {
+  if (!ctx->grid_probe_pending || hipEventQuery(ctx->grid_probe_event) != hipSuccess) return 0;
+  ctx->grid_probe_pending = false;
+  const uint32_t n_far = *ctx->h_grid_probe;
+  const double share = (double)n_far / (double)std::max<size_t>(ctx->run_src->n_valid, 1);
+  if (dev_env("OPE_TRACE_GRID"))
+    fprintf(stderr, "[ope] launch %d (%s kernel): %u of %zu queries beyond one cell of the target (share %.4f)\n", it_done,
+            ctx->use_grid ? "grid" : "tree", n_far, ctx->run_src->n_valid, share);
+  if (ctx->use_grid && share > kGridMaxTreeShare) return -1;
+  if (!ctx->use_grid && share < kGridMinTreeShare) return +1;
+  return 0;
+}
+static int switch_kernel(ope_ctx *ctx, bool to_grid, int it_done, uint32_t nch) {
+  ctx->use_grid = to_grid;
+  ctx->plan_valid = false;   // chunk ids mean something else to the other kernel
+  OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * (size_t)(nch + 1), ctx->stream));
+  OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 8, 0, 8, ctx->stream));
+  if (to_grid) {
+    // query order and classes start over (the hints into the grid may be stale: a stale hint is still a model point, so
+    // it only costs the first launch a tree walk)
+    fill_iota(ctx->stream, ctx->d_qorder, (uint32_t)std::max<size_t>(ctx->run_src->n, 1));
+    OPE_HIP(ctx, hipMemsetAsync(ctx->d_qclass, 0, std::max<size_t>(ctx->run_src->n, 1), ctx->stream));
+  }
+  ctx->force_plan_at = it_done + 2;   // as soon as two launches have measured their chunks
+  return OPE_OK;
+}
+
 static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   // re-sort the chunks by the cost they measured: after launches 1, 2, 4, ..., 32 and then every 32
   static const bool no_plan = dev_env("OPE_NO_PLAN") != nullptr;  // developer A/B switch
@@ -115,41 +158,25 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     // the query order is re-partitioned by class at launches 1, 2, 4 and then with every plan step.
     const ope_icp_params &p = ctx->run_params;
     const bool nrm = p.use_surface_normal_rej || p.use_self_occluded_rej || p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
-    const bool plan_step = !no_plan && nch > 1 && it_done >= 1 && (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0);
-    // Which kernel a run is better served by is measured, not guessed: the share of queries whose nearest model point is
-    // further away than one grid cell (clutter: the grid can never answer them, each is a long private walk) is counted
-    // on the device at the plan steps and read back asynchronously.  Above kGridMaxTreeShare the run continues on the tree
-    // kernel, whose packet / per-lane / group scheduling is built around exactly that mix (steady state, kernel us, tree /
-    // grid: C3 frame with 9 % clutter 174 / 214, its clutter-free cluster 110 / 88; a 1/8 shard 70 / 124 and 36 / 27).
-    if (ctx->grid_probe_pending && hipEventQuery(ctx->grid_probe_event) == hipSuccess) {
-      ctx->grid_probe_pending = false;
-      const uint32_t n_far = *ctx->h_grid_probe;
-      const double tree_share = (double)n_far / (double)std::max<size_t>(ctx->run_src->n_valid, 1);
-      if (dev_env("OPE_TRACE_GRID")) fprintf(stderr, "[ope] grid probe at launch %d: %u of %zu queries beyond one cell of the target (share %.4f), mode %d\n", it_done, n_far, ctx->run_src->n_valid, tree_share, ctx->run_tgt->grid_mode);
-      if (tree_share > kGridMaxTreeShare && ctx->run_tgt->grid_mode != 2) {
-        ctx->use_grid = false;
-        ctx->plan_valid = false;   // chunk ids mean something else to the tree kernel
-        OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * (size_t)(nch + 1), ctx->stream));
-        OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 8, 0, 8, ctx->stream));
-        ctx->force_plan_at = it_done + 2;   // as soon as two launches have measured their chunks
-        --ctx->acc_launches;
-        return enqueue_accumulate(ctx, atomic_sums);
-      }
+    const bool plan_step = !no_plan && nch > 1 && it_done >= 1 &&
+                           (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0 || it_done == ctx->force_plan_at);
+    if (grid_probe_poll(ctx, it_done) < 0) {
+      const int rcs = switch_kernel(ctx, false, it_done, nch);
+      if (rcs != OPE_OK) return rcs;
+      --ctx->acc_launches;
+      return enqueue_accumulate(ctx, atomic_sums);
     }
     if (plan_step) {
       static const float heavy_env = [] { const char *e = dev_env("OPE_HEAVY_FACTOR"); return e ? (float)atof(e) : -1.0f; }();
-      const bool repart = it_done <= 4 || it_done % plan_every == 0;
+      const bool repart = it_done <= 4 || it_done % plan_every == 0 || it_done == ctx->force_plan_at;
       if (grid_plan(ctx->stream, repart, ctx->d_qclass, (uint32_t)ctx->run_src->n_valid, ctx->d_qorder, ctx->d_work_counter + 8, ctx->d_chunk_cost,
                     ctx->d_chunk_keys, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
                     (uint32_t)ctx->acc_blocks * (kAccBlock / 64), heavy_env, ctx->d_part_tmp, ctx->part_tmp_bytes) != 0)
         return set_err(ctx, OPE_EHIP, "grid plan step failed");
       ctx->plan_valid = true;
-      if (repart && it_done >= 2 && !ctx->grid_probe_pending && ctx->grid_probe_event && ctx->run_tgt->grid_mode != 2) {
-        const float cell = 1.0f / ctx->run_tgt->grid.inv;
-        grid_count_far(ctx->stream, ctx->d_corr_d2, (uint32_t)ctx->run_src->n_valid, cell * cell, ctx->d_work_counter + 8);
-        OPE_HIP(ctx, hipMemcpyAsync(ctx->h_grid_probe, ctx->d_work_counter + 10, 4, hipMemcpyDeviceToHost, ctx->stream));
-        OPE_HIP(ctx, hipEventRecord(ctx->grid_probe_event, ctx->stream));
-        ctx->grid_probe_pending = true;
+      if (it_done >= 2) {
+        const int rcp = grid_probe_issue(ctx);
+        if (rcp != OPE_OK) return rcp;
       }
     }
     const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
@@ -164,8 +191,18 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     }
     return OPE_OK;
   }
+  if (ctx->grid_auto && grid_probe_poll(ctx, it_done) > 0) {
+    const int rcs = switch_kernel(ctx, true, it_done, nch);
+    if (rcs != OPE_OK) return rcs;
+    --ctx->acc_launches;
+    return enqueue_accumulate(ctx, atomic_sums);
+  }
   if (!no_plan && nch > 1 && it_done >= 1 &&
       (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0 || it_done == ctx->force_plan_at)) {
+    if (ctx->grid_auto && it_done >= 8) {
+      const int rcp = grid_probe_issue(ctx);
+      if (rcp != OPE_OK) return rcp;
+    }
     size_t tb = ctx->plan_tmp_bytes;
     if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
                    ctx->d_plan_tmp, tb) != 0)
@@ -749,6 +786,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     if (rcg != OPE_OK) return rcg;
     ctx->use_grid = tgt->has_grid;
   }
+  ctx->grid_auto = ctx->use_grid && tgt->grid_mode == 1;
   if (ctx->use_grid) {
     const size_t cap = std::max<size_t>(src->n, 1);
     if (ctx->grid_cap < cap) {

@@ -136,6 +136,7 @@ struct ope_ctx {
   hipEvent_t grid_probe_event = nullptr;  // asynchronous read-back of the grid-class query count
   uint32_t *h_grid_probe = nullptr;       // pinned
   bool grid_probe_pending = false;
+  bool grid_auto = false;                 // the run may move between the grid and the tree kernel (ope_index_params.grid == 1)
   int force_plan_at = -1;                 // launch at which the tree kernel re-plans after taking over from the grid kernel
   size_t corr_cap = 0;
   ope::IcpState *h_state = nullptr;  // pinned
