@@ -1288,6 +1288,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void debug_chunk_kerne
   const bool active = i < src.n_valid;
   unsigned long long t0, t1, ta, tb;
   unsigned long long c_node = 0, c_leaf = 0, c_pop = 0, c_eager = 0, n_node = 0;
+  int my_trips = 0;  // trips in which THIS lane still had work: sum over lanes / (64 * trips) = lane utilisation of the walk
   OPE_STAMP(t0);
   const float4 s4 = src.xyzw[active ? i : base];
   const float qx = xform_row(T + 0, s4.x, s4.y, s4.z), qy = xform_row(T + 4, s4.x, s4.y, s4.z), qz = xform_row(T + 8, s4.x, s4.y, s4.z);
@@ -1323,6 +1324,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void debug_chunk_kerne
   c_eager += tb - ta;
   while (__ballot(alive) != 0ull) {
     bool do_pop = false;
+    my_trips += alive ? 1 : 0;
     OPE_STAMP(ta);
     if (alive && node < leaf0) {
       v.on_node();
@@ -1378,11 +1380,12 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void debug_chunk_kerne
   }
   OPE_STAMP(t1);
   int mn = v.nodes, mp = v.points;
-  for (int off = 32; off >= 1; off >>= 1) { mn = max(mn, __shfl_xor(mn, off, 64)); mp = max(mp, __shfl_xor(mp, off, 64)); }
+  int st = my_trips;
+  for (int off = 32; off >= 1; off >>= 1) { mn = max(mn, __shfl_xor(mn, off, 64)); mp = max(mp, __shfl_xor(mp, off, 64)); st += __shfl_xor(st, off, 64); }
   if (lane_id == 0) {
     long long *o = out + 10 * (size_t)chunk;
     o[0] = (long long)(t1 - t0); o[1] = mn; o[2] = mp; o[3] = (long long)c_eager; o[4] = (long long)c_node;
-    o[5] = (long long)c_leaf; o[6] = (long long)c_pop; o[7] = (long long)n_node; o[8] = 0; o[9] = 0;
+    o[5] = (long long)c_leaf; o[6] = (long long)c_pop; o[7] = (long long)n_node; o[8] = st; o[9] = 0;
   }
 }
 }  // namespace ope

@@ -22,6 +22,9 @@ for use_hint in (1, 0):
         rc = L.ope_debug_chunk_profile(ctx.h, cs.h, ix.h, t.ctypes.data_as(C.POINTER(C.c_float)), use_hint, buf.ctypes.data_as(C.POINTER(C.c_longlong)))
         assert rc == 0
     cyc, mn, mp, ce, cn, cl, cp, trips = buf[:, :8].T
+    lane_trips = buf[:, 8]
+    print(f"   lane utilisation of the walk loop (lane-trips with work / 64 x trips): {lane_trips.sum()/(64.0*trips.sum()):.3f}; "
+          f"mean lane-trips per query {lane_trips.sum()/len(src):.2f} vs trips per chunk {trips.mean():.1f}")
     print(f"hint={use_hint}: chunks {nch}; sum of chunk cycles {cyc.sum()/1e9:.2f} G (/8192 slots = {cyc.sum()/8192/2400:.0f} us @2.4GHz)")
     print(f"   chunk cycles: mean {cyc.mean():.0f} p50 {np.percentile(cyc,50):.0f} p90 {np.percentile(cyc,90):.0f} p99 {np.percentile(cyc,99):.0f} max {cyc.max()}")
     print(f"   shares: eager-siblings {ce.sum()/cyc.sum():.2f} node-branch {cn.sum()/cyc.sum():.2f} leaf-branch {cl.sum()/cyc.sum():.2f} pop {cp.sum()/cyc.sum():.2f}")
