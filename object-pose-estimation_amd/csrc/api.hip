@@ -16,7 +16,9 @@ namespace ope {
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
                            uint32_t *, const uint32_t *, bool, int, double *);
-void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, uint32_t *);
+void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
+int icp_accumulate_blocks_per_cu(bool, bool, bool);
+extern bool g_plan_no_alone;
 int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t, void *, size_t &);
 void fill_iota(hipStream_t, uint32_t *, uint32_t);
 hipError_t morton_order_device(hipStream_t, const float *, size_t, const float[3], const float[3], float4 *, int32_t *);
@@ -27,7 +29,7 @@ void launch_icp_accumulate_grid(hipStream_t, int, bool, const CloudView &, const
                                 float *, uint32_t *, uint32_t *, const uint32_t *, unsigned char *, const uint32_t *, uint32_t *, const uint32_t *,
                                 double *);
 int grid_plan(hipStream_t, bool, const unsigned char *, uint32_t, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, const uint32_t *,
-              uint32_t *, uint32_t, uint32_t, float, void *, size_t);
+              uint32_t *, uint32_t, uint32_t, float, float, void *, size_t);
 size_t grid_plan_tmp_bytes(uint32_t, uint32_t);
 void grid_count_far(hipStream_t, const float *, uint32_t, float, uint32_t *);
 hipError_t build_grid_device(hipStream_t, const float4 *, const float4 *, size_t, const float[3], const float[3], double, uint32_t, GridView *,
@@ -47,6 +49,7 @@ static thread_local std::string g_global_err;
 
 constexpr double kGridMaxTreeShare = 0.03, kGridMinTreeShare = 0.015;
 constexpr size_t kGridMinQueries = 0;
+constexpr float kHeavyLoadFactor = 1.7f;   // launches that fill the GPU: group walks for chunks beyond this multiple of a wave's fair share (C3: 1.45 177 us, 1.6-1.8 157-159, 2.0 168, 2.4 178)
 constexpr float kHeavyMaxChunksPerWave = 1.8f;   // beyond this the launch is throughput-bound: no 8-lane group walks
 
 // Developer A/B switches and sweeps (tools/*.py) read the environment only in builds made with -DOPE_DEVELOPER
@@ -119,6 +122,12 @@ static int grid_probe_issue(ope_ctx *ctx) {
   ctx->grid_probe_pending = true;
   return OPE_OK;
 }
+static float heavy_load_factor() {
+  static const bool once = [] { g_plan_no_alone = dev_env("OPE_NO_ALONE") != nullptr; return true; }();  // developer A/B switch
+  (void)once;
+  static const float f = [] { const char *e = dev_env("OPE_HEAVY_LOAD"); return e ? (float)atof(e) : kHeavyLoadFactor; }();  // developer sweep
+  return f;
+}
 // returns +1: switch to the grid kernel, -1: switch to the tree kernel, 0: stay
 static int grid_probe_poll(ope_ctx *ctx, int it_done) {
   if (!ctx->grid_probe_pending || hipEventQuery(ctx->grid_probe_event) != hipSuccess) return 0;
@@ -153,6 +162,16 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   const int it_done = ctx->acc_launches++;
   const uint32_t nch = (uint32_t)((ctx->run_src->n_valid + 63) / 64);
   static const int plan_every = [] { const char *e = dev_env("OPE_PLAN_EVERY"); return e ? std::max(1, atoi(e)) : 32; }();  // developer sweep
+  {
+    // the launch before a plan step measures: no 8-lane group walks (their chunks would keep the cost of the last
+    // per-lane walk they had, however old), flagged to the kernels through plan_info[4]
+    const int nx = it_done + 1;
+    const bool measuring = !no_plan && nch > 1 && ((((nx & (nx - 1)) == 0 && nx <= plan_every) || nx % plan_every == 0 || nx == ctx->force_plan_at));
+    if (measuring != ctx->measuring_flag) {
+      OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 12, measuring ? 0x01 : 0x00, 4, ctx->stream));
+      ctx->measuring_flag = measuring;
+    }
+  }
   if (ctx->use_grid) {
     // GRID instantiation (1-NN, no reciprocal check, device-built index).  Plan steps at the same launches as below;
     // the query order is re-partitioned by class at launches 1, 2, 4 and then with every plan step.
@@ -171,7 +190,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
       const bool repart = it_done <= 4 || it_done % plan_every == 0 || it_done == ctx->force_plan_at;
       if (grid_plan(ctx->stream, repart, ctx->d_qclass, (uint32_t)ctx->run_src->n_valid, ctx->d_qorder, ctx->d_work_counter + 8, ctx->d_chunk_cost,
                     ctx->d_chunk_keys, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
-                    (uint32_t)ctx->acc_blocks * (kAccBlock / 64), heavy_env, ctx->d_part_tmp, ctx->part_tmp_bytes) != 0)
+                    (uint32_t)ctx->acc_blocks * (kAccBlock / 64), heavy_env, heavy_load_factor(), ctx->d_part_tmp, ctx->part_tmp_bytes) != 0)
         return set_err(ctx, OPE_EHIP, "grid plan step failed");
       ctx->plan_valid = true;
       if (it_done >= 2) {
@@ -217,7 +236,9 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     const float chunks_per_wave = (float)nch / (float)(ctx->n_cu * 4 * kAccWavesPerSimd);
     const float heavy_factor = heavy_env >= 0.f ? heavy_env
                                : (chunks_per_wave > kHeavyMaxChunksPerWave ? 0.0f : std::min(7.0f, std::max(2.0f, 1.2f + 1.5f * chunks_per_wave)));
-    plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch, heavy_factor, ctx->d_work_counter + 8);
+    const float load_factor = (heavy_env < 0.f && chunks_per_wave > kHeavyMaxChunksPerWave) ? heavy_load_factor() : 0.0f;
+    plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch, heavy_factor, load_factor, (uint32_t)ctx->acc_blocks * (kAccBlock / 64),
+               ctx->d_work_counter + 8);
     ctx->plan_valid = true;
   }
   const ope_icp_params &p = ctx->run_params;
@@ -891,6 +912,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   if (ctx->d_sums_ext)
     OPE_HIP(ctx, hipMemsetAsync(ctx->d_sums_ext, 0, sizeof(double) * (p.estimator == OPE_EST_POINT_TO_PLANE_LLS ? kNumSumsMax : kNumSums), ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 256, ctx->stream));
+  ctx->measuring_flag = false;
   // partial-sum rows of blocks that do not exist in this run must read as zero
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_partials, 0, sizeof(double) * kNumSumsMax * kAccMaxBlocks, ctx->stream));
   // the pinned block is reused for read-back: make sure the upload is finished with it first
@@ -906,6 +928,14 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   // twice the waves the chunks alone would need: the chunks handed to 8-lane groups take eight slots each, and on a
   // launch that does not fill the GPU every slot should find a wave of its own (125 k queries: 84 -> 74 us)
   ctx->acc_blocks = (int)std::min<size_t>(std::max<size_t>(2 * ((src->n_valid + block - 1) / block), 1), kAccMaxBlocks);
+  if (p.corr_mode == OPE_CORR_NEAREST && !p.use_reciprocal) {
+    // ... but never more blocks than the GPU holds at once: the surplus would start when the first blocks end
+    const bool nrm = p.use_surface_normal_rej || p.use_self_occluded_rej || p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
+    const uint32_t nch0 = (uint32_t)((src->n_valid + 63) / 64);
+    const bool packet = nch0 > (uint32_t)ctx->n_cu * 4u * (uint32_t)kAccWavesPerSimd;
+    const int per_cu = icp_accumulate_blocks_per_cu(nrm, packet, tgt->has_grid && tgt->grid_mode == 2);
+    if (per_cu > 0) ctx->acc_blocks = std::min(ctx->acc_blocks, per_cu * ctx->n_cu);
+  }
   if (const char *e = dev_env("OPE_ACC_BLOCKS")) ctx->acc_blocks = std::max(1, std::min(atoi(e), (int)kAccMaxBlocks));
   if (ctx->n_src_total <= 0) ctx->n_src_total = (int64_t)src->n;
   if (ctx->n_tgt_total <= 0) ctx->n_tgt_total = (int64_t)tgt->n_total;
@@ -1029,6 +1059,18 @@ int ope_icp_profile_read(ope_ctx *ctx, double *total_ms, int *n_launches) {
   if (n_launches) *n_launches = (int)ctx->prof_used;
   return OPE_OK;
 }
+
+#ifdef OPE_DEVELOPER
+// tools/cost_probe.py: the per-chunk costs the last launches measured (s_memtime ticks >> 4), the plan's order and plan_info
+int ope_debug_chunk_costs(ope_ctx *ctx, uint32_t *cost, uint32_t *order, uint32_t *plan_info4, int n) {
+  if (!ctx || !ctx->run_active) return OPE_ESTATE;
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  OPE_HIP(ctx, hipMemcpy(cost, ctx->d_chunk_cost, 4 * (size_t)n, hipMemcpyDeviceToHost));
+  OPE_HIP(ctx, hipMemcpy(order, ctx->d_chunk_order, 4 * (size_t)n, hipMemcpyDeviceToHost));
+  OPE_HIP(ctx, hipMemcpy(plan_info4, ctx->d_work_counter + 8, 16, hipMemcpyDeviceToHost));
+  return OPE_OK;
+}
+#endif
 
 int ope_icp_update(ope_ctx *ctx) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_update: no run in progress");

@@ -145,18 +145,35 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   const uint32_t n_waves = gridDim.x * (BLOCK / 64);
   const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
   const uint32_t n_chunks = (src.n_valid + 63u) / 64u;
-  const uint32_t n_heavy = (OCT_OK && chunk_order) ? min(plan_info[0], n_chunks) : 0u;
-  const uint32_t n_slots = n_chunks + 7u * n_heavy;
+  // plan_info[4] != 0: a measuring launch (the one before a plan step) — every chunk takes the per-lane walk, so that the
+  // costs the plan sorts are all of one kind and none is older than one launch
+  const bool measuring = chunk_order && plan_info[4] != 0u;
+  const uint32_t n_heavy = (OCT_OK && chunk_order && !measuring) ? min(plan_info[0], n_chunks) : 0u;
+  // The plan's costliest per-lane chunks each outlast the share of work a wave has in a balanced launch (plan_info[5] of
+  // them, ranks n_heavy .. n_heavy + n_alone - 1): each gets a wave to itself (waves 0 .. n_alone - 1) and that wave
+  // takes nothing else; all other slots are dealt to the remaining waves in snake order.
+  const uint32_t n_alone = chunk_order ? min(min(plan_info[5] + (measuring ? min(plan_info[0], n_chunks) : 0u), n_chunks - n_heavy), n_waves / 2u) : 0u;
+  const uint32_t n_snake = 8u * n_heavy + (n_chunks - n_heavy - n_alone);
+  const uint32_t snake_waves = n_waves - n_alone;
   for (uint32_t round = 0;; ++round) {
-    if (round * n_waves >= n_slots) break;
-    const uint32_t slot = round * n_waves + ((round & 1u) ? (n_waves - 1u - wave_id) : wave_id);
-    if (slot >= n_slots) continue;
-    const bool oct = slot < 8u * n_heavy;
-    const uint32_t ord = oct ? (slot >> 3) : (slot - 7u * n_heavy);
+    bool oct = false;
+    uint32_t ord, sub = 0;
+    if (wave_id < n_alone) {
+      if (round > 0) break;
+      ord = n_heavy + wave_id;
+    } else {
+      if (round * snake_waves >= n_snake) break;
+      const uint32_t w = wave_id - n_alone;
+      const uint32_t slot = round * snake_waves + ((round & 1u) ? (snake_waves - 1u - w) : w);
+      if (slot >= n_snake) continue;
+      oct = slot < 8u * n_heavy;
+      ord = oct ? (slot >> 3) : (n_heavy + n_alone + (slot - 8u * n_heavy));
+      sub = slot & 7u;
+    }
     const uint32_t chunk = chunk_order ? chunk_order[ord] : ord;
     const uint32_t base = chunk * 64u;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-    const uint32_t i = oct ? (base + (slot & 7u) * 8u + (lane_id >> 3)) : (base + lane_id);
+    const uint32_t i = oct ? (base + sub * 8u + (lane_id >> 3)) : (base + lane_id);
     const bool active = i < src.n_valid;
     const bool owner = active && (!oct || (lane_id & 7u) == 0u);  // the one lane that reports a query
     // (the pointer keeps its LDS address space: through a generic pointer these became flat_loads, which take the
@@ -408,27 +425,42 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
   const uint32_t n_grid_q = min(plan_info[1], src.n_valid);
   const uint32_t n_tree_q = src.n_valid - n_grid_q;
   const uint32_t n_gc = (n_grid_q + 63u) / 64u, n_tc = (n_tree_q + 63u) / 64u;
-  const uint32_t n_heavy = chunk_order ? min(plan_info[0], n_tc) : 0u;
-  // slots, costliest first: 8 per heavy tree chunk (8-lane group walks), the other tree chunks, the grid chunks
-  const uint32_t n_slots = n_tc + 7u * n_heavy + n_gc;
+  const bool measuring = chunk_order && plan_info[4] != 0u;   // see icp_accumulate_kernel
+  const uint32_t n_heavy = (chunk_order && !measuring) ? min(plan_info[0], n_tc) : 0u;
+  // waves 0 .. n_alone-1: one of the costliest per-lane tree chunks each and nothing else; all other waves, in snake
+  // order: 8 slots per heavy tree chunk (8-lane group walks), the other tree chunks, the grid chunks (see icp_accumulate_kernel)
+  const uint32_t n_alone = chunk_order ? min(min(plan_info[5] + (measuring ? min(plan_info[0], n_tc) : 0u), n_tc - n_heavy), n_waves / 2u) : 0u;
+  const uint32_t n_tree_slots = 8u * n_heavy + (n_tc - n_heavy - n_alone);
+  const uint32_t n_snake = n_tree_slots + n_gc;
+  const uint32_t snake_waves = n_waves - n_alone;
   for (uint32_t round = 0;; ++round) {
-    if (round * n_waves >= n_slots) break;
-    const uint32_t slot = round * n_waves + ((round & 1u) ? (n_waves - 1u - wave_id) : wave_id);
-    if (slot >= n_slots) continue;
-    const bool oct = slot < 8u * n_heavy;
-    const bool tree_part = slot < n_tc + 7u * n_heavy;
+    bool oct = false, tree_part = true;
+    uint32_t ord = 0, sub = 0, gchunk = 0;
+    if (wave_id < n_alone) {
+      if (round > 0) break;
+      ord = n_heavy + wave_id;
+    } else {
+      if (round * snake_waves >= n_snake) break;
+      const uint32_t w = wave_id - n_alone;
+      const uint32_t slot = round * snake_waves + ((round & 1u) ? (snake_waves - 1u - w) : w);
+      if (slot >= n_snake) continue;
+      oct = slot < 8u * n_heavy;
+      tree_part = slot < n_tree_slots;
+      ord = oct ? (slot >> 3) : (n_heavy + n_alone + (slot - 8u * n_heavy));
+      sub = slot & 7u;
+      gchunk = slot - n_tree_slots;
+    }
     uint32_t chunk = 0, pos0, pos_end;
     if (tree_part) {
-      const uint32_t ord = oct ? (slot >> 3) : (slot - 7u * n_heavy);
       chunk = chunk_order ? min(chunk_order[ord], n_tc - 1u) : ord;
       pos0 = n_grid_q + chunk * 64u;
       pos_end = src.n_valid;
     } else {
-      pos0 = (slot - (n_tc + 7u * n_heavy)) * 64u;
+      pos0 = gchunk * 64u;
       pos_end = n_grid_q;
     }
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-    const uint32_t qpos = oct ? (pos0 + (slot & 7u) * 8u + (lane_id >> 3)) : (pos0 + lane_id);
+    const uint32_t qpos = oct ? (pos0 + sub * 8u + (lane_id >> 3)) : (pos0 + lane_id);
     const bool active = qpos < pos_end;
     const uint32_t i = active ? qorder[qpos] : qorder[pos0];
     const bool owner = active && (!oct || (lane_id & 7u) == 0u);
@@ -469,10 +501,14 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
         if (owner && v.leaf != 0u) hint[i] = v.leaf;
       }
     } else if (__ballot(need_tree) != 0ull) {
+      // lanes the grid has answered sit the walk out (best = -inf: nothing can improve them); a chunk of the tree part
+      // whose lanes start from a handful of leaves (clutter far from the model does) takes ONE packet walk through the
+      // scalar cache, everything else the per-lane walk (icp_accumulate_kernel)
+      const uint32_t h = need_tree ? hint[i] : 0u;
+      NearestVisitor v{need_tree ? (gpos != kNoPos ? nextafterf(best, INFINITY) : best) : -INFINITY, kNoPos, 0};
+      const bool done = tree_part && bvh_traverse_packet(tgt, x, y, z, need_tree, v, h, stk, BLOCK);
+      if (!done && need_tree) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, h);
       if (need_tree) {
-        const uint32_t h = hint[i];
-        NearestVisitor v{gpos != kNoPos ? nextafterf(best, INFINITY) : best, kNoPos, 0};
-        bvh_traverse(tgt, x, y, z, v, stk, BLOCK, h);
         if (v.pos != kNoPos) { best = v.best; gpos = grid.gpos_of_bvhpos[v.pos]; }
         if (v.leaf != 0u && v.leaf != h) hint[i] = v.leaf;
       }
@@ -504,7 +540,8 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     }
     add_query_sums<NRM>(s_red[threadIdx.x >> 6], (lds_cfloat_ptr)s_const, lane_id, ok, p2p, x, y, z, make_float4(tm.x, tm.y, tm.z, tm.w),
                         (NRM && p2p) ? grid.gnrm[ok ? gpos : 0u] : make_float4(0.f, 0.f, 0.f, 0.f), d2);
-    if (lane_id == 0 && tree_part && !oct) chunk_cost[chunk] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
+    // tree chunks record their cost under their id, grid chunks behind them (the plan only needs their sum)
+    if (lane_id == 0 && !oct) chunk_cost[tree_part ? chunk : n_tc + gchunk] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
   }
   __syncthreads();
   if (threadIdx.x < (p2p ? kNumSumsMax : kNumSums)) {
@@ -1153,6 +1190,21 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
 #undef OPE_LAUNCH_NS
   }
 #undef OPE_LAUNCH_ACC
+}
+
+// Blocks of the 1-NN accumulate kernel (tree or grid instantiation) that one CU holds at a time: a launch of more blocks
+// than the GPU holds runs its surplus after the first blocks have ended, behind the costliest chunks (C3 without
+// clutter: 109 -> 94 us when the launch is cut to the resident number).
+int icp_accumulate_blocks_per_cu(bool nrm, bool packet, bool grid) {
+  int nb = 0;
+  hipError_t e;
+  if (grid) e = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_grid_kernel<true>, kAccBlock, 0)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_grid_kernel<false>, kAccBlock, 0);
+  else if (packet) e = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, true, false, true>, kAccBlock, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, false, false, true>, kAccBlock, 0);
+  else e = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, true, false, false>, kAccBlock, 0)
+               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, false, false, false>, kAccBlock, 0);
+  return (e == hipSuccess && nb > 0) ? nb : 0;
 }
 
 void launch_icp_accumulate_grid(hipStream_t stream, int nblocks, bool nrm, const CloudView &src, const BvhView &tgt, const GridView &grid,

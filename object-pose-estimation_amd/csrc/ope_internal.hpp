@@ -137,6 +137,7 @@ struct ope_ctx {
   uint32_t *h_grid_probe = nullptr;       // pinned
   bool grid_probe_pending = false;
   bool grid_auto = false;                 // the run may move between the grid and the tree kernel (ope_index_params.grid == 1)
+  bool measuring_flag = false;   // plan_info[4] as last written (enqueue_accumulate)
   int force_plan_at = -1;                 // launch at which the tree kernel re-plans after taking over from the grid kernel
   size_t corr_cap = 0;
   ope::IcpState *h_state = nullptr;  // pinned

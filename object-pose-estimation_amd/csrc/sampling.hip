@@ -80,24 +80,87 @@ int chunk_plan(hipStream_t stream, const uint32_t *cost, uint32_t *cost_sorted, 
   return e == hipSuccess ? 0 : -1;
 }
 
-// plan_info[0] = number of "heavy" chunks: those costlier than factor x the median chunk (capped at n/4)
-__global__ void plan_heavy_kernel(const uint32_t *cost_sorted_desc, uint32_t n, float factor, uint32_t *plan_info) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  uint32_t nh = 0;
-  if (factor > 0.f && n >= 8) {
-    const float thr = factor * (float)cost_sorted_desc[n / 2];
-    uint32_t lo = 0, hi = n / 4;  // first index whose cost <= thr
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) / 2;
-      if ((float)cost_sorted_desc[mid] > thr) lo = mid + 1; else hi = mid;
-    }
-    nh = lo;
+// first index of a descending cost list whose entry is <= thr, searched in [0, cap)
+__device__ __forceinline__ uint32_t count_costlier(const uint32_t *cost_sorted_desc, uint32_t cap, float thr) {
+  uint32_t lo = 0, hi = cap;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) / 2;
+    if ((float)cost_sorted_desc[mid] > thr) lo = mid + 1; else hi = mid;
   }
-  plan_info[0] = nh;
+  return lo;
 }
 
-void plan_heavy(hipStream_t stream, const uint32_t *cost_sorted_desc, uint32_t n, float factor, uint32_t *plan_info) {
-  hipLaunchKernelGGL(plan_heavy_kernel, dim3(1), dim3(64), 0, stream, cost_sorted_desc, n, factor, plan_info);
+// Plan of a launch from the chunk costs in descending order (one block of 256 threads).
+// plan_info[0] = n_heavy, the chunks walked by 8-lane groups (capped at n/4):
+//   factor > 0:      those costlier than factor x the median chunk (launches with few chunks per wave: latency-bound)
+//   load_factor > 0: those costlier than load_factor x (sum of all costs / waves), i.e. chunks that on their own far
+//                    outlast the share of work a wave has in a balanced launch (launches that fill the GPU)
+// plan_info[5] = n_alone, the next-costliest chunks that get a wave to themselves: those at or above the fair share L of
+//   the waves that are left, L = (work not yet given away) / (waves not yet given away), iterated to its fixed point.  A
+//   group-walked chunk counts as kOctWork x its per-lane cost (eight slots of about a third of the duration each).
+constexpr double kOctWork = 2.7;
+bool g_plan_no_alone = false;   // developer A/B switch (OPE_NO_ALONE, set by api.hip in DEVELOPER builds)
+__device__ __forceinline__ double block_sum_range(const uint32_t *v, uint32_t a, uint32_t b, double *s_sum) {
+  double acc = 0.0;
+  for (uint32_t i = a + threadIdx.x; i < b; i += 256) acc += (double)v[i];
+  __syncthreads();   // s_sum may still be read from the previous call
+  s_sum[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+    __syncthreads();
+  }
+  return s_sum[0];
+}
+__global__ __launch_bounds__(256) void plan_heavy_kernel(const uint32_t *cost_sorted_desc, uint32_t n, float factor, float load_factor,
+                                                         uint32_t n_waves, uint32_t *plan_info) {
+  __shared__ double s_sum[256];
+  __shared__ uint32_t s_nh, s_k;
+  const double total = block_sum_range(cost_sorted_desc, 0, n, s_sum);
+  if (threadIdx.x == 0) {
+    uint32_t nh = 0;
+    if (n >= 8) {
+      if (factor > 0.f) nh = count_costlier(cost_sorted_desc, n / 4, factor * (float)cost_sorted_desc[n / 2]);
+      else if (load_factor > 0.f) nh = count_costlier(cost_sorted_desc, n / 4, load_factor * (float)(total / (double)max(n_waves, 1u)));
+    }
+    s_nh = nh;
+    s_k = 0;
+  }
+  __syncthreads();
+  const uint32_t nh = s_nh;
+  const double heavy = block_sum_range(cost_sorted_desc, 0, nh, s_sum);
+  // the eight slots of a group-walked chunk are dealt like ordinary chunks; everything but the alone chunks is "the rest"
+  double rest = kOctWork * heavy + (total - heavy);
+  uint32_t k = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    if (threadIdx.x == 0) {
+      const uint32_t w_left = n_waves > k ? n_waves - k : 1u;
+      const float fair = (float)(rest / (double)w_left);
+      // chunks nh .. n-1 at or above the fair share (descending list: a prefix), at most half the waves
+      uint32_t lo = nh, hi = min(n, nh + n_waves / 2u);
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if ((float)cost_sorted_desc[mid] >= fair && fair > 0.f) lo = mid + 1; else hi = mid;
+      }
+      s_k = lo - nh;
+    }
+    __syncthreads();
+    const uint32_t k_new = s_k;
+    if (k_new == k) break;   // (uniform: every thread reads the same s_k)
+    const double alone = block_sum_range(cost_sorted_desc, nh, nh + k_new, s_sum);
+    rest = kOctWork * heavy + (total - heavy) - alone;
+    k = k_new;
+  }
+  if (threadIdx.x == 0) {
+    plan_info[0] = nh;
+    plan_info[5] = k;
+  }
+}
+
+void plan_heavy(hipStream_t stream, const uint32_t *cost_sorted_desc, uint32_t n, float factor, float load_factor, uint32_t n_waves,
+                uint32_t *plan_info) {
+  hipLaunchKernelGGL(plan_heavy_kernel, dim3(1), dim3(256), 0, stream, cost_sorted_desc, n, factor, load_factor, n_waves, plan_info);
+  if (g_plan_no_alone) (void)hipMemsetAsync(plan_info + 5, 0, 4, stream);
 }
 
 // ---- plan step of the GRID accumulate kernel (icp_accumulate_grid_kernel): everything stays on the device
@@ -116,30 +179,58 @@ __global__ void grid_plan_keys_kernel(const uint32_t *__restrict__ cost, uint32_
   keys[c] = c < n_tc ? max(cost[c], 1u) : 0u;
 }
 
-__global__ void grid_plan_heavy_kernel(const uint32_t *cost_sorted_desc, uint32_t n_valid, uint32_t n_waves, float factor_override,
-                                       uint32_t *plan_info) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const uint32_t n = (n_valid - min(plan_info[1], n_valid) + 63u) / 64u;
-  // the fewer tree chunks there are per resident wave, the more the slowest one decides the launch (see enqueue_accumulate)
-  const float cpw = (float)n / (float)max(n_waves, 1u);
-  const float factor = factor_override >= 0.f ? factor_override : fminf(7.0f, fmaxf(2.0f, 1.2f + 1.5f * cpw));
-  uint32_t nh = 0;
-  // 8-lane group walks trade lane-cycles for latency: only while the launch is latency-bound (see enqueue_accumulate).
-  // Here the load of a launch is its tree chunks (x8 if walked by groups) plus the grid chunks at about a third each.
-  const uint32_t n_gc = (min(plan_info[1], n_valid) + 63u) / 64u;
-  const float load = (8.0f * (float)n + 0.33f * (float)n_gc) / (float)max(n_waves, 1u);
-  if (factor_override < 0.f && load > 1.8f) {
-    nh = 0;
-  } else if (factor > 0.f && n >= 8) {
-    const float thr = factor * (float)cost_sorted_desc[n / 2];
-    uint32_t lo = 0, hi = n / 4;
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) / 2;
-      if ((float)cost_sorted_desc[mid] > thr) lo = mid + 1; else hi = mid;
+__global__ __launch_bounds__(256) void grid_plan_heavy_kernel(const uint32_t *cost_sorted_desc, const uint32_t *cost, uint32_t n_valid, uint32_t n_waves,
+                                                              float factor_override, float load_factor, uint32_t *plan_info) {
+  __shared__ double s_sum[256];
+  __shared__ uint32_t s_nh, s_k;
+  const uint32_t n = (n_valid - min(plan_info[1], n_valid) + 63u) / 64u;       // tree chunks: the first n entries of the sorted list
+  const uint32_t n_gc = (min(plan_info[1], n_valid) + 63u) / 64u;              // grid chunks: their costs sit behind the tree chunks' in `cost`
+  const double tree_total = block_sum_range(cost_sorted_desc, 0, n, s_sum);
+  const double grid_total = block_sum_range(cost, n, n + n_gc, s_sum);
+  const double total = tree_total + grid_total;
+  if (threadIdx.x == 0) {
+    // the fewer tree chunks there are per wave, the more the slowest one decides the launch (see enqueue_accumulate)
+    const float cpw = (float)n / (float)max(n_waves, 1u);
+    const float factor = factor_override >= 0.f ? factor_override : fminf(7.0f, fmaxf(2.0f, 1.2f + 1.5f * cpw));
+    // 8-lane group walks trade lane-cycles for latency.  A launch that leaves waves idle (its tree chunks x8 plus its grid
+    // chunks at about a third each do not fill them) takes the median rule; a full one only hands over the chunks that
+    // far outlast a wave's fair share of the work.
+    const float load = (8.0f * (float)n + 0.33f * (float)n_gc) / (float)max(n_waves, 1u);
+    uint32_t nh = 0;
+    if (n >= 8) {
+      if (factor_override >= 0.f || load <= 1.8f) { if (factor > 0.f) nh = count_costlier(cost_sorted_desc, n / 4, factor * (float)cost_sorted_desc[n / 2]); }
+      else if (load_factor > 0.f) nh = count_costlier(cost_sorted_desc, n / 4, load_factor * (float)(total / (double)max(n_waves, 1u)));
     }
-    nh = lo;
+    s_nh = nh;
+    s_k = 0;
   }
-  plan_info[0] = nh;
+  __syncthreads();
+  const uint32_t nh = s_nh;
+  const double heavy = block_sum_range(cost_sorted_desc, 0, nh, s_sum);
+  double rest = kOctWork * heavy + (total - heavy);
+  uint32_t k = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    if (threadIdx.x == 0) {
+      const uint32_t w_left = n_waves > k ? n_waves - k : 1u;
+      const float fair = (float)(rest / (double)w_left);
+      uint32_t lo = nh, hi = min(n, nh + n_waves / 2u);
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) / 2;
+        if ((float)cost_sorted_desc[mid] >= fair && fair > 0.f) lo = mid + 1; else hi = mid;
+      }
+      s_k = lo - nh;
+    }
+    __syncthreads();
+    const uint32_t k_new = s_k;
+    if (k_new == k) break;
+    const double alone = block_sum_range(cost_sorted_desc, nh, nh + k_new, s_sum);
+    rest = kOctWork * heavy + (total - heavy) - alone;
+    k = k_new;
+  }
+  if (threadIdx.x == 0) {
+    plan_info[0] = nh;
+    plan_info[5] = k;
+  }
 }
 
 // Share of queries the grid can never answer, whatever the pose: their nearest model point is further away than one
@@ -159,7 +250,7 @@ void grid_count_far(hipStream_t stream, const float *corr_d2, uint32_t n_valid, 
 // d_keys: scratch of nch entries.  tmp sized by grid_plan_tmp_bytes.
 int grid_plan(hipStream_t stream, bool repartition, const unsigned char *qclass, uint32_t n_valid, uint32_t *qorder, uint32_t *plan_info,
               const uint32_t *cost, uint32_t *keys, uint32_t *cost_sorted, const uint32_t *ids, uint32_t *order, uint32_t nch, uint32_t n_waves,
-              float factor_override, void *tmp, size_t tmp_bytes) {
+              float factor_override, float load_factor, void *tmp, size_t tmp_bytes) {
   hipError_t e = hipSuccess;
   if (repartition) {
     size_t tb = tmp_bytes;
@@ -170,7 +261,8 @@ int grid_plan(hipStream_t stream, bool repartition, const unsigned char *qclass,
   size_t tb = tmp_bytes;
   e = rocprim::radix_sort_pairs_desc(tmp, tb, keys, cost_sorted, ids, order, nch, 0, 32, stream);
   if (e != hipSuccess) return -1;
-  hipLaunchKernelGGL(grid_plan_heavy_kernel, dim3(1), dim3(64), 0, stream, cost_sorted, n_valid, n_waves, factor_override, plan_info);
+  hipLaunchKernelGGL(grid_plan_heavy_kernel, dim3(1), dim3(256), 0, stream, cost_sorted, cost, n_valid, n_waves, factor_override, load_factor, plan_info);
+  if (g_plan_no_alone) (void)hipMemsetAsync(plan_info + 5, 0, 4, stream);
   return 0;
 }
 

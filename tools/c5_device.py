@@ -1,0 +1,19 @@
+"""Developer probe / profile target: config C5 (F frames of N points) through the device-resident BuildModel loop."""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ope = importlib.import_module("object-pose-estimation_amd")
+synth = importlib.import_module("object-pose-estimation_amd.synth")
+bm = importlib.import_module("object-pose-estimation_amd.buildmodel")
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 500_000
+frames = synth.frame_views(F, N, n_azimuths=32)
+ctx = ope.Context(0)
+ctx.profile_kernels(True)
+t0 = time.perf_counter()
+res = bm.register_point_clouds(ope, ctx, frames)
+dt = time.perf_counter() - t0
+print(f"C5 {F} x {N}: {dt:.2f} s, iterations per pair {[p.iterations for p in res.pairs]}", flush=True)
+for name, k in sorted(ctx.profile_kernels_read().items(), key=lambda kv: -kv[1]["ms"]):
+    print(f"   {name:28s} {k['launches']:6d} launches {k['ms']:9.2f} ms  {k['algorithmic_bytes']/1e9:8.3f} GB algorithmic -> {k['algorithmic_bytes']/max(k['ms'],1e-9)/1e6:8.1f} GB/s")
+ctx.close()
