@@ -320,7 +320,7 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": desc, "n_scene": n_scene, "n_model": n_model, "scene_shard_per_gpu": n_local,
                        "parallelism": f"scene-sharded x{world}, model index replicated, 17xfp64 all-reduce/iter"
-                                      + (f" ({args.comm})" if launched else ""),
+                                      + (f" ({args.comm}" + ({ope.COMM_P2P: ": peer-to-peer slots", ope.COMM_RCCL: ": ncclAllReduce"}.get(ctx.comm_transport(), "") if not use_torch_comm else "") + ")" if launched else ""),
                        "start": "identity" if guess is None else "FPFH + SAC-IA coarse pose",
                        "final_mse": out.last_mse, "n_corr": int(out.n_corr)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

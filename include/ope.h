@@ -271,6 +271,27 @@ int ope_transform_cloud(ope_ctx *ctx, const ope_cloud *cloud, const float T[16],
 int ope_comm_get_unique_id(char id[OPE_COMM_ID_BYTES]);
 int ope_comm_init_rank(ope_ctx *ctx, const char id[OPE_COMM_ID_BYTES], int nranks, int rank);
 int ope_comm_destroy(ope_ctx *ctx);
+/* How the 17 (44) sums of an iteration travel between the ranks of one node.
+ *   OPE_COMM_AUTO (default): peer-to-peer slots if every rank could set them up and exchange a test pattern, else RCCL
+ *   OPE_COMM_RCCL: ncclAllReduce on the run's stream, then the update kernel
+ *   OPE_COMM_P2P:  peer-to-peer slots or an error — every rank stores its sums into a slot it owns in each peer's
+ *                  fine-grained buffer (opened through hipIpc handles; 8-byte words {32 data bits, 32-bit sequence number},
+ *                  so a word is valid the moment its number matches: no fence between data and flag), reads its own slots
+ *                  in rank order and runs the update step in the same launch.  At most 8 ranks.
+ * To be called with the same value on every rank, after ope_comm_init_rank and outside a run.
+ * ope_comm_transport returns what iterations will use: OPE_COMM_RCCL or OPE_COMM_P2P (0 without a communicator). */
+enum { OPE_COMM_AUTO = 0, OPE_COMM_RCCL = 1, OPE_COMM_P2P = 2 };
+int ope_comm_set_transport(ope_ctx *ctx, int transport);
+int ope_comm_transport(const ope_ctx *ctx);
+/* The peer-to-peer slots WITHOUT an RCCL communicator, for drivers that have their own way of passing 64 bytes around
+ * (torch.distributed with any backend, MPI, a file): every rank calls ope_comm_p2p_open and publishes the handle it gets;
+ * every rank then calls ope_comm_p2p_connect with all handles in rank order.  connect is collective: it maps the peers'
+ * buffers and runs the test exchange (up to 10 s); OPE_ECOMM on any rank means no rank may use the communicator — agree
+ * on the return codes before iterating.  Such a communicator carries the SVD and LLS estimators (17 / 44 sums per
+ * iteration); the LM estimator's repeated reductions need ope_comm_init_rank. */
+#define OPE_P2P_HANDLE_BYTES 64
+int ope_comm_p2p_open(ope_ctx *ctx, char handle[OPE_P2P_HANDLE_BYTES]);
+int ope_comm_p2p_connect(ope_ctx *ctx, const char *handles /* nranks * OPE_P2P_HANDLE_BYTES */, int nranks, int rank);
 
 /* ---------------- features (coarse stage) ---------------- */
 /* pcl::NormalEstimation::compute with setKSearch(k) and viewpoint vp (poseestimator.cpp:151-156).

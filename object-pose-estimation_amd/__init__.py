@@ -24,6 +24,7 @@ OPE_OK, OPE_EINVAL, OPE_ENODEV, OPE_EHIP, OPE_ENOMEM, OPE_ESTATE, OPE_ECOMM, OPE
 CONV_NAMES = ["NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE", "NO_CORRESPONDENCES"]
 CORR_NEAREST, CORR_NORMAL_SHOOTING = 0, 1
 EST_SVD, EST_POINT_TO_PLANE_LLS, EST_POINT_TO_PLANE_LM = 0, 1, 2
+COMM_AUTO, COMM_RCCL, COMM_P2P = 0, 1, 2
 NUM_SUMS, NUM_SUMS_MAX = 17, 44
 COMM_ID_BYTES = 128
 
@@ -151,6 +152,10 @@ ABI = [
     ("ope_comm_get_unique_id", C.c_int, [C.c_char_p]),
     ("ope_comm_init_rank", C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
     ("ope_comm_destroy", C.c_int, [_vp]),
+    ("ope_comm_set_transport", C.c_int, [_vp, C.c_int]),
+    ("ope_comm_transport", C.c_int, [_vp]),
+    ("ope_comm_p2p_open", C.c_int, [_vp, C.c_char_p]),
+    ("ope_comm_p2p_connect", C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int]),
     ("ope_normals", C.c_int, [_vp, _vp, C.c_int, _fp, _fp, _fp]),
     ("ope_normals_from", C.c_int, [_vp, _vp, _vp, C.c_int, _fp, _fp, _fp]),
     ("ope_fpfh", C.c_int, [_vp, _vp, C.c_float, _fp]),
@@ -448,6 +453,26 @@ class Context:
 
     def comm_destroy(self):
         self._chk(lib().ope_comm_destroy(self.h))
+
+    def comm_p2p_open(self) -> bytes:
+        """Allocate this rank's slot buffer; returns its 64-byte hipIpc handle (to be passed to every rank)."""
+        buf = C.create_string_buffer(64)
+        self._chk(lib().ope_comm_p2p_open(self.h, buf))
+        return buf.raw
+
+    def comm_p2p_connect(self, handles, rank: int):
+        """Collective: map the peers' buffers (handles in rank order) and run the test exchange."""
+        blob = b"".join(handles)
+        assert len(blob) == 64 * len(handles)
+        self._chk(lib().ope_comm_p2p_connect(self.h, blob, len(handles), rank))
+
+    def comm_set_transport(self, transport: int):
+        """COMM_AUTO (peer-to-peer slots if every rank set them up, else RCCL), COMM_RCCL, COMM_P2P (or an error)."""
+        self._chk(lib().ope_comm_set_transport(self.h, int(transport)))
+
+    def comm_transport(self) -> int:
+        """What iterations of a sharded run will use: COMM_RCCL or COMM_P2P (0 without a communicator)."""
+        return int(lib().ope_comm_transport(self.h))
 
     # ---- features
     def normals(self, cloud: "Cloud", k: int = 30, vp=(0.0, 0.0, 0.0), fetch: bool = True):

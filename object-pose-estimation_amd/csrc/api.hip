@@ -44,6 +44,8 @@ void launch_fitness(hipStream_t, int, const CloudView &, const BvhView &, const 
 void launch_pairs_svd(hipStream_t, const float *, const float *, uint32_t, double *, int, float *);
 // comm.cpp
 int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count);
+bool comm_uses_p2p(const ope_ctx *ctx);
+int comm_p2p_exchange_update(ope_ctx *ctx, IcpState *d_state, double *d_sums, int nsums);
 
 static thread_local std::string g_global_err;
 
@@ -974,7 +976,7 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_iterate: no run in progress");
   // a context with a communicator takes the accumulate -> all-reduce -> update sequence, also with one rank
   // (that is how a one-GPU box exercises the path the multi-GPU runs take)
-  const bool sharded = ctx->nccl_comm != nullptr;
+  const bool sharded = ctx->nccl_comm != nullptr || ctx->p2p_ok;
   static const bool split_update = dev_env("OPE_SPLIT_UPDATE") != nullptr;  // developer A/B switch
   const bool atomic = atomic_sums(ctx);
   for (int b = 0; b < n_iterations; ++b) {
@@ -987,6 +989,8 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
     if (rc != OPE_OK) return rc;
     TraceRange r_red(ctx, "reduce");
     if (ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LM) {
+      if (sharded && !ctx->nccl_comm)
+        return set_err(ctx, OPE_EINVAL, "ope_icp_iterate: the LM estimator reduces through RCCL (ope_comm_init_rank); a communicator made by ope_comm_p2p_connect carries the SVD and LLS estimators");
       // correspondences are in place (corr_match = index positions); their 17 sums give n and the MSE
       if (!atomic)
         launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
@@ -1016,9 +1020,15 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
     if (sharded) {
       if (!atomic)
         launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
-      rc = comm_allreduce_sums(ctx, sums_ptr(ctx), ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LLS ? kNumSumsMax : kNumSums);
-      if (rc != OPE_OK) return rc;
-      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx), nullptr);
+      if (comm_uses_p2p(ctx)) {
+        // exchange through the peers' slots and update in one launch (no collective, no separate update kernel)
+        rc = comm_p2p_exchange_update(ctx, ctx->d_state, sums_ptr(ctx), run_nsums(ctx));
+        if (rc != OPE_OK) return rc;
+      } else {
+        rc = comm_allreduce_sums(ctx, sums_ptr(ctx), ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LLS ? kNumSumsMax : kNumSums);
+        if (rc != OPE_OK) return rc;
+        launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx), nullptr);
+      }
     } else if (atomic) {
       launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx), nullptr);
     } else if (split_update) {
@@ -1096,6 +1106,8 @@ int ope_icp_poll(ope_ctx *ctx, ope_icp_result *result) {
   OPE_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (result) fill_result(ctx, result);
+  if (ctx->h_state->comm_error)
+    return set_err(ctx, OPE_ECOMM, "a peer's sums did not arrive within 2 s (peer-to-peer exchange): the run was ended");
   return OPE_OK;
 }
 

@@ -10,7 +10,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "ope_internal.hpp"
 
@@ -23,6 +25,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -38,11 +41,128 @@ Rccl &rccl() {
   r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
   if (r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce) r.h = h;
   return r;
 }
 }  // namespace
+
+void launch_icp_p2p_update(hipStream_t, IcpState *, double *, int, const P2pView &, uint32_t, unsigned long long, bool, double *);
+
+P2pView p2p_view(const ope_ctx *ctx) {
+  P2pView v{};
+  v.nranks = ctx->comm_nranks;
+  v.rank = ctx->comm_rank;
+  for (int r = 0; r < kP2pMaxRanks; ++r)
+    v.buf[r] = r == ctx->comm_rank ? ctx->p2p_mine : static_cast<unsigned long long *>(ctx->p2p_peer[r]);
+  return v;
+}
+
+void p2p_teardown(ope_ctx *ctx) {
+  for (int r = 0; r < kP2pMaxRanks; ++r)
+    if (ctx->p2p_peer[r]) { (void)hipIpcCloseMemHandle(ctx->p2p_peer[r]); ctx->p2p_peer[r] = nullptr; }
+  if (ctx->p2p_mine) { (void)hipFree(ctx->p2p_mine); ctx->p2p_mine = nullptr; }
+  if (ctx->p2p_scratch) { (void)hipFree(ctx->p2p_scratch); ctx->p2p_scratch = nullptr; }
+  ctx->p2p_ok = false;
+  ctx->p2p_seq = 0;
+}
+
+// ---- the three steps of setting the slots up; each returns false (leaving things for p2p_teardown) on failure
+static bool p2p_alloc(ope_ctx *ctx, hipIpcMemHandle_t *handle) {
+  p2p_teardown(ctx);
+  bool ok = hipExtMallocWithFlags((void **)&ctx->p2p_mine, kP2pBufferBytes, hipDeviceMallocFinegrained) == hipSuccess;
+  if (!ok) ctx->p2p_mine = nullptr;
+  ok = ok && hipMemset(ctx->p2p_mine, 0, kP2pBufferBytes) == hipSuccess;
+  ok = ok && hipMalloc((void **)&ctx->p2p_scratch, sizeof(double) * 2 * kP2pMaxSums) == hipSuccess;
+  ok = ok && hipIpcGetMemHandle(handle, ctx->p2p_mine) == hipSuccess;
+  ok = ok && hipDeviceSynchronize() == hipSuccess;
+  (void)hipGetLastError();
+  return ok;
+}
+static bool p2p_map_peers(ope_ctx *ctx, const hipIpcMemHandle_t *handles, int nranks, int rank) {
+  bool ok = ctx->p2p_mine != nullptr && nranks >= 1 && nranks <= kP2pMaxRanks && rank >= 0 && rank < nranks;
+  for (int p = 0; p < nranks && ok; ++p) {
+    if (p == rank) continue;
+    if (hipIpcOpenMemHandle(&ctx->p2p_peer[p], handles[p], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { ctx->p2p_peer[p] = nullptr; ok = false; }
+  }
+  (void)hipGetLastError();
+  return ok;
+}
+// one exchange of a known pattern through the very kernel the iterations use (sequence number 1); collective
+static bool p2p_self_test(ope_ctx *ctx) {
+  const int n = ctx->comm_nranks;
+  double pat[kP2pMaxSums], got[kP2pMaxSums];
+  for (int k = 0; k < kP2pMaxSums; ++k) pat[k] = 1000.0 * (ctx->comm_rank + 1) + k + 0.25;
+  bool ok = hipMemcpyAsync(ctx->p2p_scratch, pat, sizeof pat, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+  ctx->p2p_seq = 1;
+  if (ok) {
+    launch_icp_p2p_update(ctx->stream, nullptr, ctx->p2p_scratch, kP2pMaxSums, p2p_view(ctx), ctx->p2p_seq, 1000000000ull /* 10 s */, false,
+                          ctx->p2p_scratch + kP2pMaxSums);
+    ok = hipMemcpyAsync(got, ctx->p2p_scratch + kP2pMaxSums, sizeof got, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+         hipStreamSynchronize(ctx->stream) == hipSuccess;
+  }
+  for (int k = 0; k < kP2pMaxSums && ok; ++k) {
+    double want = 0.0;
+    for (int p = 0; p < n; ++p) want += 1000.0 * (p + 1) + k + 0.25;
+    if (!(got[k] == want)) ok = false;
+  }
+  (void)hipGetLastError();
+  return ok;
+}
+
+// With an RCCL communicator in place (ope_comm_init_rank): handles travel through it and so does the verdict — any step
+// that fails on any rank leaves every rank on RCCL.  Collective.
+static void p2p_setup_over_rccl(ope_ctx *ctx) {
+  Rccl &r = rccl();
+  const int n = ctx->comm_nranks;
+  unsigned char *d_handles = nullptr;
+  int *d_ok = nullptr;
+  if (hipMalloc((void **)&d_handles, sizeof(hipIpcMemHandle_t) * (size_t)(n + 1)) != hipSuccess || hipMalloc((void **)&d_ok, sizeof(int)) != hipSuccess) {
+    // (the peers' collectives below would wait for this rank: like any other allocation failure at set-up, not recoverable)
+    if (d_handles) (void)hipFree(d_handles);
+    (void)hipGetLastError();
+    return;
+  }
+  ncclComm_t comm = (ncclComm_t)ctx->nccl_comm;
+  auto agree = [&](bool mine_ok) {   // min over ranks
+    int v = mine_ok ? 1 : 0, out = 0;
+    (void)hipMemcpyAsync(d_ok, &v, sizeof v, hipMemcpyHostToDevice, ctx->stream);
+    if (r.AllReduce(d_ok, d_ok, 1, ncclInt, ncclMin, comm, ctx->stream) != ncclSuccess) return false;
+    if (hipMemcpyAsync(&out, d_ok, sizeof out, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+    return out == 1;
+  };
+  hipIpcMemHandle_t mine{};
+  std::vector<hipIpcMemHandle_t> handles((size_t)std::max(n, 1));
+  bool ok = agree(n >= 2 && n <= kP2pMaxRanks && r.AllGather && p2p_alloc(ctx, &mine));
+  if (ok) {
+    unsigned char *d_mine = d_handles + sizeof(hipIpcMemHandle_t) * (size_t)n;
+    const bool step = hipMemcpyAsync(d_mine, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                      r.AllGather(d_mine, d_handles, sizeof mine, ncclChar, comm, ctx->stream) == ncclSuccess &&
+                      hipMemcpyAsync(handles.data(), d_handles, sizeof(hipIpcMemHandle_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                      hipStreamSynchronize(ctx->stream) == hipSuccess;
+    ok = agree(step && p2p_map_peers(ctx, handles.data(), n, ctx->comm_rank));
+  }
+  if (ok) ok = agree(p2p_self_test(ctx));
+  (void)hipFree(d_handles);
+  (void)hipFree(d_ok);
+  if (ok) ctx->p2p_ok = true;
+  else p2p_teardown(ctx);
+  (void)hipGetLastError();
+}
+
+bool comm_uses_p2p(const ope_ctx *ctx) { return ctx->p2p_ok && ctx->comm_transport != OPE_COMM_RCCL; }
+
+// accumulate -> THIS -> next accumulate: exchange and update in one launch
+int comm_p2p_exchange_update(ope_ctx *ctx, IcpState *d_state, double *d_sums, int nsums) {
+  if (!comm_uses_p2p(ctx)) return set_err(ctx, OPE_ECOMM, "comm_p2p_exchange_update: peer-to-peer slots are not set up");
+  if (nsums > kP2pMaxSums) return set_err(ctx, OPE_EINVAL, "comm_p2p_exchange_update: too many sums");
+  ++ctx->p2p_seq;
+  if (ctx->p2p_seq == 0) ctx->p2p_seq = 2;   // 0 is the cleared buffer, and the parity alternation must go on: 0xffffffff (odd) -> 2
+  launch_icp_p2p_update(ctx->stream, d_state, d_sums, nsums, p2p_view(ctx), ctx->p2p_seq, 200000000ull /* 2 s */, true, nullptr);
+  return OPE_OK;
+}
 
 int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count) {
   Rccl &r = rccl();
@@ -86,16 +206,72 @@ int ope_comm_init_rank(ope_ctx *ctx, const char id[OPE_COMM_ID_BYTES], int nrank
   ctx->nccl_comm = comm;
   ctx->comm_nranks = nranks;
   ctx->comm_rank = rank;
+  ctx->comm_transport = OPE_COMM_AUTO;
+  p2p_setup_over_rccl(ctx);
+  return OPE_OK;
+}
+
+int ope_comm_set_transport(ope_ctx *ctx, int transport) {
+  if (!ctx || transport < OPE_COMM_AUTO || transport > OPE_COMM_P2P) return set_err(ctx, OPE_EINVAL, "ope_comm_set_transport: bad argument");
+  if (!ctx->nccl_comm && !ctx->p2p_ok) return set_err(ctx, OPE_ESTATE, "ope_comm_set_transport: no communicator (ope_comm_init_rank or ope_comm_p2p_connect first)");
+  if (transport == OPE_COMM_RCCL && !ctx->nccl_comm) return set_err(ctx, OPE_ECOMM, "ope_comm_set_transport: this communicator has no RCCL side (it was made by ope_comm_p2p_connect)");
+  if (ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_comm_set_transport: a run is in progress");
+  if (transport == OPE_COMM_P2P && !ctx->p2p_ok)
+    return set_err(ctx, OPE_ECOMM, "ope_comm_set_transport: peer-to-peer slots could not be set up on every rank (hipIpc handles, fine-grained memory or the test exchange failed)");
+  ctx->comm_transport = transport;
+  return OPE_OK;
+}
+
+int ope_comm_transport(const ope_ctx *ctx) {
+  if (!ctx || (!ctx->nccl_comm && !ctx->p2p_ok)) return 0;
+  return comm_uses_p2p(ctx) ? OPE_COMM_P2P : OPE_COMM_RCCL;
+}
+
+int ope_comm_p2p_open(ope_ctx *ctx, char handle[OPE_P2P_HANDLE_BYTES]) {
+  static_assert(sizeof(hipIpcMemHandle_t) <= OPE_P2P_HANDLE_BYTES, "hipIpcMemHandle_t larger than OPE_P2P_HANDLE_BYTES");
+  if (!ctx || !handle) return set_err(ctx, OPE_EINVAL, "ope_comm_p2p_open: bad argument");
+  if (ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_comm_p2p_open: a run is in progress");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  ope_comm_destroy(ctx);
+  hipIpcMemHandle_t h{};
+  if (!p2p_alloc(ctx, &h)) {
+    p2p_teardown(ctx);
+    return set_err(ctx, OPE_ECOMM, "ope_comm_p2p_open: fine-grained buffer or its hipIpc handle could not be made");
+  }
+  std::memset(handle, 0, OPE_P2P_HANDLE_BYTES);
+  std::memcpy(handle, &h, sizeof h);
+  return OPE_OK;
+}
+
+int ope_comm_p2p_connect(ope_ctx *ctx, const char *handles, int nranks, int rank) {
+  if (!ctx || !handles || nranks < 1 || nranks > kP2pMaxRanks || rank < 0 || rank >= nranks)
+    return set_err(ctx, OPE_EINVAL, "ope_comm_p2p_connect: bad argument (at most 8 ranks)");
+  if (!ctx->p2p_mine) return set_err(ctx, OPE_ESTATE, "ope_comm_p2p_connect: ope_comm_p2p_open first");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<hipIpcMemHandle_t> hs((size_t)nranks);
+  for (int p = 0; p < nranks; ++p) std::memcpy(&hs[(size_t)p], handles + (size_t)p * OPE_P2P_HANDLE_BYTES, sizeof(hipIpcMemHandle_t));
+  ctx->comm_nranks = nranks;
+  ctx->comm_rank = rank;
+  if (!p2p_map_peers(ctx, hs.data(), nranks, rank) || !p2p_self_test(ctx)) {
+    p2p_teardown(ctx);
+    ctx->comm_nranks = 1;
+    ctx->comm_rank = 0;
+    return set_err(ctx, OPE_ECOMM, "ope_comm_p2p_connect: a peer's buffer could not be opened, or the test exchange did not complete");
+  }
+  ctx->p2p_ok = true;
+  ctx->comm_transport = OPE_COMM_P2P;
   return OPE_OK;
 }
 
 int ope_comm_destroy(ope_ctx *ctx) {
   if (!ctx) return OPE_EINVAL;
+  p2p_teardown(ctx);
   if (ctx->nccl_comm) {
     Rccl &r = rccl();
     if (r.h) r.CommDestroy((ncclComm_t)ctx->nccl_comm);
     ctx->nccl_comm = nullptr;
   }
+  ctx->comm_transport = OPE_COMM_AUTO;
   ctx->comm_nranks = 1;
   ctx->comm_rank = 0;
   return OPE_OK;

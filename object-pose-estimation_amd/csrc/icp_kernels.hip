@@ -995,6 +995,74 @@ __global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, double *S,
 }
 
 // ------------------------------------------------------------------------------------------
+// Peer-to-peer exchange of the sums and the update step in ONE launch (sharded runs on one node).
+// Thread w < 2 * nsums sends half w & 1 of sum w >> 1: an 8-byte word {32 data bits, sequence number} stored (relaxed,
+// system scope) into this rank's slot of parity seq & 1 in every rank's buffer, this rank's own included.  The same
+// thread then polls word w of every rank's slot in its OWN buffer until the number matches — a word is complete the
+// moment it is visible (aligned 8-byte stores are single-copy atomic), so no fence orders data before flags, the one
+// assumption the protocol makes about the fabric.  Sums are added in rank order: every rank computes bit-identical
+// totals, hence the same transform and the same "done".  Two parities: a rank that is one exchange ahead writes the
+// other parity, and it cannot be two ahead because it needs every peer's words of the exchange in between.
+// A peer that does not deliver within `timeout_ticks` (100 MHz ticks) ends the run with comm_error set: the kernel
+// always terminates.
+__global__ __launch_bounds__(128) void icp_p2p_update_kernel(IcpState *st, double *S, int nsums, P2pView pv, uint32_t seq,
+                                                            unsigned long long timeout_ticks, int do_update, double *out_sums) {
+  if (do_update && st->done) return;
+  __shared__ double s_S[kNumSumsMax];
+  __shared__ IcpState s_st;
+  __shared__ uint32_t s_half[kP2pMaxRanks][kP2pSlotWords];
+  __shared__ int s_fail;
+  const int t = (int)threadIdx.x;
+  const int nw = 2 * nsums;
+  const size_t parity_off = (size_t)(seq & 1u) * kP2pMaxRanks * kP2pSlotWords;
+  if (do_update) state_to_lds(&s_st, st);
+  if (t == 0) s_fail = 0;
+  __syncthreads();
+  if (t < nw) {
+    const double v = S[t >> 1];
+    const uint32_t bits = (uint32_t)((t & 1) ? __double2hiint(v) : __double2loint(v));
+    const unsigned long long word = ((unsigned long long)seq << 32) | bits;
+    for (int r = 0; r < pv.nranks; ++r)
+      __hip_atomic_store(pv.buf[r] + parity_off + (size_t)pv.rank * kP2pSlotWords + t, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long *mine = pv.buf[pv.rank] + parity_off + t;
+    for (int r = 0; r < pv.nranks; ++r) {
+      unsigned long long w;
+      for (;;) {
+        w = __hip_atomic_load(mine + (size_t)r * kP2pSlotWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((uint32_t)(w >> 32) == seq) break;
+        if (wall_clock64() - t0 > timeout_ticks) { s_fail = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      s_half[r][t] = (uint32_t)w;
+    }
+  }
+  __syncthreads();
+  if (t < kNumSumsMax) {
+    double acc = 0.0;
+    if (t < nsums)
+      for (int r = 0; r < pv.nranks; ++r) acc += __hiloint2double((int)s_half[r][2 * t + 1], (int)s_half[r][2 * t]);
+    s_S[t] = acc;
+  }
+  __syncthreads();
+  const bool failed = s_fail != 0;
+  if (!do_update) {   // self-test at communicator set-up: hand the totals (or NaNs) back
+    if (t < nsums) out_sums[t] = failed ? __longlong_as_double(0x7ff8000000000000ll) : s_S[t];
+    return;
+  }
+  if (failed) {
+    if (t == 0) { st->comm_error = 1; st->done = 1; }
+    return;
+  }
+  if (t == 0) icp_update_lane(&s_st, s_S, nullptr);
+  __syncthreads();
+  if (t < kNumSumsMax) s_st.S[t] = 0.0;
+  __syncthreads();
+  state_to_lds(st, &s_st);
+  if (t < nsums) S[t] = 0.0;   // consumed: ready for the next accumulate launch to add into
+}
+
+// ------------------------------------------------------------------------------------------
 // Stand-alone TransformationEstimationSVD on n given pairs (poseestimator.cpp:429-435):
 // the same 17 sums, about the first source point, then the same umeyama lane.
 __global__ __launch_bounds__(256) void pairs_sums_kernel(const float *__restrict__ src, const float *__restrict__ tgt,
@@ -1223,6 +1291,11 @@ void launch_icp_reduce_update(hipStream_t stream, IcpState *st, const double *pa
                               bool do_update, uint32_t *work_counter) {
   hipLaunchKernelGGL(icp_reduce_update_kernel, dim3(1), dim3(kRedBlock), 0, stream, st, partials, S, nblocks,
                      do_update ? 1 : 0, work_counter);
+}
+
+void launch_icp_p2p_update(hipStream_t stream, IcpState *st, double *S, int nsums, const P2pView &pv, uint32_t seq,
+                           unsigned long long timeout_ticks, bool do_update, double *out_sums) {
+  hipLaunchKernelGGL(icp_p2p_update_kernel, dim3(1), dim3(128), 0, stream, st, S, nsums, pv, seq, timeout_ticks, do_update ? 1 : 0, out_sums);
 }
 
 void launch_icp_update(hipStream_t stream, IcpState *st, double *S, int nsums, const float *Tk_ext) {

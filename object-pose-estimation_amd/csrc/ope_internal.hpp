@@ -79,6 +79,18 @@ struct IcpState {
   int max_iterations, failure_after_max_iter, min_correspondences;
   int iterations, converged, state, done;
   int corr_mode, k_normal_shooting, use_surface_normal_rej, use_self_occluded_rej, use_reciprocal, estimator;
+  int comm_error, pad2_;   // set by the peer-to-peer exchange when a peer's sums did not arrive in time (run ends)
+};
+
+// Peer-to-peer exchange of the sums (comm.cpp, icp_p2p_update_kernel): every rank owns one slot per parity in every
+// rank's buffer; a slot is 2 * kP2pMaxSums 8-byte words {low: 32 data bits, high: sequence number of the exchange}.
+constexpr int kP2pMaxRanks = 8;
+constexpr int kP2pMaxSums = 44;
+constexpr int kP2pSlotWords = 2 * kP2pMaxSums;
+constexpr size_t kP2pBufferBytes = sizeof(unsigned long long) * 2 * kP2pMaxRanks * kP2pSlotWords;
+struct P2pView {
+  unsigned long long *buf[kP2pMaxRanks];   // buf[r]: rank r's buffer as mapped here (buf[rank] is this rank's own)
+  int nranks, rank;
 };
 
 constexpr int kNumSums = 17;
@@ -160,6 +172,13 @@ struct ope_ctx {
   // RCCL (dlopen'ed lazily)
   void *nccl_comm = nullptr;
   int comm_nranks = 1, comm_rank = 0;
+  // peer-to-peer slots (comm.cpp): own buffer, the peers' buffers as opened here, whether every rank passed the self-test
+  unsigned long long *p2p_mine = nullptr;
+  void *p2p_peer[ope::kP2pMaxRanks] = {};
+  bool p2p_ok = false;
+  int comm_transport = 0;        // OPE_COMM_AUTO / RCCL / P2P as requested
+  uint32_t p2p_seq = 0;          // sequence number of the last exchange (never 0 in a slot)
+  double *p2p_scratch = nullptr; // kP2pMaxSums doubles for the self-test
 
   // per-kernel timing of the coarse-stage / filter kernels (ope_profile_kernels): HIP events on the launch stream
   bool ktime_on = false;

@@ -198,3 +198,75 @@ def test_native_rccl_loop_sequence_matches_the_one_gpu_loop(tmp_path):
     assert a[16] == b[16] == 30 and a[17] == b[17] == 60000
     assert np.abs(a[:16] - b[:16]).max() < 1e-5          # atomic sums: the addition order differs at the 1e-16 level
     assert abs(a[18] - b[18]) <= 1e-9 * abs(a[18])
+
+
+def _p2p_worker(rank, world, port, ns, nt, max_it, out_dir):
+    """One rank of a run whose sums travel through the peer-to-peer slots: handles exchanged over gloo, no RCCL (RCCL refuses
+    two ranks on one device, which is all a test box has)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ope = importlib.import_module("object-pose-estimation_amd")
+    sharded = importlib.import_module("object-pose-estimation_amd.sharded")
+    synth = importlib.import_module("object-pose-estimation_amd.synth")
+    torch.cuda.set_device(0)
+    ctx = ope.Context(0)
+    ok, why = 1, ""
+    try:
+        handles = [None] * world
+        dist.all_gather_object(handles, ctx.comm_p2p_open())
+        ctx.comm_p2p_connect(handles, rank)
+    except ope.OpeError as e:
+        ok, why = 0, str(e)
+    t = torch.tensor([ok]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t) == 0:
+        if rank == 0:
+            open(os.path.join(out_dir, f"p2p_w{world}_unavailable.txt"), "w").write(why or "a peer failed")
+        ctx.close(); dist.destroy_process_group()
+        return
+    assert ctx.comm_transport() == ope.COMM_P2P
+    src = synth.scene_cloud(ns); tgt = synth.model_surface(nt, 1)
+    lo, hi = sharded.shard_range(ns, world, rank)
+    cs = ctx.upload(src[lo:hi]); ix = ctx.build_index(ctx.upload(tgt))
+    p = ope.default_icp_params(max_iterations=max_it, transformation_epsilon=1e-10, euclidean_fitness_epsilon=1e-10, check_every=0)
+    ctx.icp_set_global_sizes(ns, nt)
+    ctx.icp_begin(cs, ix, p, None)
+    import time
+    ctx.icp_iterate(2); ctx.sync(); dist.barrier()
+    t0 = time.perf_counter(); ctx.icp_iterate(max_it - 2); ctx.sync(); dt = time.perf_counter() - t0
+    out = ctx.icp_end()
+    allT = [None] * world
+    dist.all_gather_object(allT, np.asarray(out.T))
+    if rank == 0:
+        assert all(np.array_equal(allT[0], T) for T in allT)     # sums are added in rank order on every rank: bit-identical transforms
+        np.save(os.path.join(out_dir, f"p2p_T_w{world}.npy"), out.T)
+        np.save(os.path.join(out_dir, f"p2p_meta_w{world}.npy"), np.array([out.iterations, out.n_corr, out.state, out.align_strength, dt / (max_it - 2)]))
+    ctx.comm_destroy()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,ns,nt,max_it", [(2, 40000, 8000, 25), (4, 1_000_000, 100_000, 12)])
+def test_peer_to_peer_slots_carry_the_sums_between_ranks_on_one_gpu(tmp_path, world, ns, nt, max_it):
+    """SURVEY 8e's latency path: every rank writes its 17 sums into its slot of every peer's fine-grained buffer (hipIpc), reads
+    its own slots in rank order and updates in the same launch — no collective, no separate update kernel.  Ranks share
+    the box's one GPU (cross-process, same device: the mapping, the protocol and the kernel are the ones an 8-GPU node
+    runs; what this cannot show is the fabric).  Against the one-rank loop, and all ranks bit-identical."""
+    sys.path.insert(0, ROOT)
+    mp.spawn(_p2p_worker, args=(world, _free_port(), ns, nt, max_it, str(tmp_path)), nprocs=world, join=True)
+    marker = tmp_path / f"p2p_w{world}_unavailable.txt"
+    assert not marker.exists(), "peer-to-peer slots could not be set up on this box: " + (marker.read_text() if marker.exists() else "")
+    T = np.load(tmp_path / f"p2p_T_w{world}.npy"); meta = np.load(tmp_path / f"p2p_meta_w{world}.npy")
+    ope = importlib.import_module("object-pose-estimation_amd")
+    synth = importlib.import_module("object-pose-estimation_amd.synth")
+    ctx = ope.Context(0)
+    cs = ctx.upload(synth.scene_cloud(ns)); ix = ctx.build_index(ctx.upload(synth.model_surface(nt, 1)))
+    ref = ctx.icp(cs, ix, ope.default_icp_params(max_iterations=max_it, transformation_epsilon=1e-10, euclidean_fitness_epsilon=1e-10, check_every=0))
+    ctx.close()
+    assert meta[0] == ref.iterations and meta[1] == ref.n_corr and meta[2] == ref.state
+    assert meta[3] == pytest.approx(ns / (ns + nt))
+    assert np.linalg.norm(T.astype(np.float64) - ref.T.astype(np.float64)) < 5e-6
+    print(f"peer-to-peer, {world} ranks on one GPU, {ns} x {nt}: {meta[4] * 1e6:.0f} us per iteration")

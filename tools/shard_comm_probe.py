@@ -1,0 +1,29 @@
+"""Developer probe: what the exchange step adds to one rank's iteration on a 1/W slice of the C3 scene: the plain one-GPU
+loop, the RCCL sequence (accumulate -> ncclAllReduce -> update kernel) and the peer-to-peer sequence (accumulate ->
+exchange + update in one launch), each with ONE rank (its own slot is the only one it waits for: the protocol's floor)."""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch  # noqa: F401
+ope = importlib.import_module("object-pose-estimation_amd")
+synth = importlib.import_module("object-pose-estimation_amd.synth")
+sharded = importlib.import_module("object-pose-estimation_amd.sharded")
+scene, model = synth.config_clouds("C3")
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+lo, hi = sharded.shard_range(len(scene), W, 0)
+for mode in ("plain", "rccl", "p2p"):
+    ctx = ope.Context(0)
+    if mode == "rccl":
+        ctx.comm_init(ope.comm_unique_id(), 1, 0); ctx.comm_set_transport(ope.COMM_RCCL)
+    elif mode == "p2p":
+        ctx.comm_p2p_connect([ctx.comm_p2p_open()], 0)
+    ix = ctx.build_index(ctx.upload(model)); cs = ctx.upload(scene[lo:hi])
+    kw = dict(max_iterations=240, mse_threshold_absolute=-1.0, check_every=0)
+    ctx.icp_begin(cs, ix, ope.default_icp_params(**kw), None)
+    ctx.icp_iterate(40); ctx.sync()
+    t0 = time.perf_counter(); ctx.icp_iterate(200); ctx.sync(); dt = time.perf_counter() - t0
+    out = ctx.icp_end()
+    print(f"shard {hi - lo} pts, {mode:5s}: {dt / 200 * 1e6:6.1f} us/iteration (transport {ctx.comm_transport()})", flush=True)
+    if mode != "plain":
+        ctx.comm_destroy()
+    ctx.close()
