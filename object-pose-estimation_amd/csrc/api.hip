@@ -1107,7 +1107,7 @@ int ope_icp_poll(ope_ctx *ctx, ope_icp_result *result) {
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (result) fill_result(ctx, result);
   if (ctx->h_state->comm_error)
-    return set_err(ctx, OPE_ECOMM, "a peer's sums did not arrive within 2 s (peer-to-peer exchange): the run was ended");
+    return set_err(ctx, OPE_ECOMM, "a peer's sums did not arrive within 5 s (peer-to-peer exchange): the run was ended");
   return OPE_OK;
 }
 

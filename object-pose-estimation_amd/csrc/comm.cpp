@@ -160,7 +160,7 @@ int comm_p2p_exchange_update(ope_ctx *ctx, IcpState *d_state, double *d_sums, in
   if (nsums > kP2pMaxSums) return set_err(ctx, OPE_EINVAL, "comm_p2p_exchange_update: too many sums");
   ++ctx->p2p_seq;
   if (ctx->p2p_seq == 0) ctx->p2p_seq = 2;   // 0 is the cleared buffer, and the parity alternation must go on: 0xffffffff (odd) -> 2
-  launch_icp_p2p_update(ctx->stream, d_state, d_sums, nsums, p2p_view(ctx), ctx->p2p_seq, 200000000ull /* 2 s */, true, nullptr);
+  launch_icp_p2p_update(ctx->stream, d_state, d_sums, nsums, p2p_view(ctx), ctx->p2p_seq, 500000000ull /* 5 s */, true, nullptr);
   return OPE_OK;
 }
 
