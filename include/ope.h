@@ -178,8 +178,9 @@ typedef struct {
   int estimator; /* OPE_EST_* */
   /* 0 (default): every block adds its partial sums into the run's sums with fp64 atomics: the addition order, and with
    * it the last bit of the sums (~1e-9 in the final transform after 100 iterations), varies from run to run.
-   * 1: one row of partial sums per block and a fixed-tree reduction: bit-reproducible for a launch geometry, one more
-   * kernel boundary per iteration. */
+   * 1: one row of partial sums per block and a fixed-tree reduction, the tree kernel with its chunks in natural order (no
+   * cost-sorted schedule, no grid kernel: both follow measured times): bit-reproducible from run to run on one GPU model,
+   * at the price of the schedule (launches that fill the GPU take longer). */
   int deterministic_sums;
 } ope_icp_params;
 

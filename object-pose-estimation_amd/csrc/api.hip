@@ -160,7 +160,8 @@ static int switch_kernel(ope_ctx *ctx, bool to_grid, int it_done, uint32_t nch) 
 
 static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   // re-sort the chunks by the cost they measured: after launches 1, 2, 4, ..., 32 and then every 32
-  static const bool no_plan = dev_env("OPE_NO_PLAN") != nullptr;  // developer A/B switch
+  static const bool no_plan_env = dev_env("OPE_NO_PLAN") != nullptr;  // developer A/B switch
+  const bool no_plan = no_plan_env || ctx->run_params.deterministic_sums != 0;
   const int it_done = ctx->acc_launches++;
   const uint32_t nch = (uint32_t)((ctx->run_src->n_valid + 63) / 64);
   static const int plan_every = [] { const char *e = dev_env("OPE_PLAN_EVERY"); return e ? std::max(1, atoi(e)) : 32; }();  // developer sweep
@@ -224,10 +225,6 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
       const int rcp = grid_probe_issue(ctx);
       if (rcp != OPE_OK) return rcp;
     }
-    size_t tb = ctx->plan_tmp_bytes;
-    if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
-                   ctx->d_plan_tmp, tb) != 0)
-      return set_err(ctx, OPE_EHIP, "chunk plan sort failed");
     // Chunks costlier than `factor` x the median chunk are walked by 8-lane groups: a third of the dependent trips for
     // ~2.7x the lane-cycles.  That trade pays while the launch is bound by its slowest wave, i.e. while there are few
     // chunks per resident wave; once the waves are busy for several rounds the extra lane-cycles only lengthen the launch.
@@ -239,6 +236,12 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     const float heavy_factor = heavy_env >= 0.f ? heavy_env
                                : (chunks_per_wave > kHeavyMaxChunksPerWave ? 0.0f : std::min(7.0f, std::max(2.0f, 1.2f + 1.5f * chunks_per_wave)));
     const float load_factor = (heavy_env < 0.f && chunks_per_wave > kHeavyMaxChunksPerWave) ? heavy_load_factor() : 0.0f;
+    // (a one-launch plan — costs bucketed at 16 per octave, counting sort, same rules on the buckets — took 2.5 us per
+    // iteration off the driver's twenty-step window and put 5-9 us on its search kernel: the coarser order is the worse
+    // schedule while the costs still move; measured, not kept)
+    size_t tb = ctx->plan_tmp_bytes;
+    if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch, ctx->d_plan_tmp, tb) != 0)
+      return set_err(ctx, OPE_EHIP, "chunk plan sort failed");
     plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch, heavy_factor, load_factor, (uint32_t)ctx->acc_blocks * (kAccBlock / 64),
                ctx->d_work_counter + 8);
     ctx->plan_valid = true;
@@ -803,8 +806,10 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   }
   ctx->use_grid = false;
   ctx->force_plan_at = -1;
+  // (deterministic_sums: the tree kernel in the chunks' natural order only — which kernel runs when, and which wave takes
+  // which chunk, follow from measured times otherwise, and with them the grouping of the fp64 additions)
   if (p.corr_mode == OPE_CORR_NEAREST && !p.use_reciprocal && tgt->want_grid && src->n_valid > 0 && p.estimator != OPE_EST_POINT_TO_PLANE_LM &&
-      (tgt->grid_mode == 2 || src->n_valid >= kGridMinQueries)) {
+      !p.deterministic_sums && (tgt->grid_mode == 2 || src->n_valid >= kGridMinQueries)) {
     const int rcg = ensure_grid(ctx, tgt);
     if (rcg != OPE_OK) return rcg;
     ctx->use_grid = tgt->has_grid;

@@ -115,7 +115,9 @@ __device__ __forceinline__ void bvh_traverse(const BvhView &t, float qx, float q
 // The walk proper, from a state {node, trail, minb, parked bounds}.  Flat loop: each trip advances every lane by
 // one unit of work (an inner-node step OR a whole leaf scan), then backs up through LDS-parked bounds.  Measured
 // alternatives on C3 (same box, same build otherwise): "while-while" (all lanes walk to a leaf, then scan
-// together) 442 us vs 283 us; one unified 6-load trip per lane state 467 us.
+// together) 442 us vs 283 us; one unified 6-load trip per lane state 467 us; round 2: back up -> step -> leaf scan within
+// one trip for a lane that can flow through (fewer trips, the same phases per trip): tree kernel 155-163 us vs 153-156 on
+// the C3 frame, 97-98 vs 95-97 without clutter (the costly chunks are served by packet and group walks, not by this loop).
 // node_done: `node` has been dealt with already (start by backing up).
 template <class Visitor>
 __device__ __forceinline__ void bvh_walk(const BvhView &t, float qx, float qy, float qz, Visitor &v, float *stk, int stk_stride,

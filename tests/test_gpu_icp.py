@@ -538,3 +538,21 @@ def test_c3_full_size_properties_permutation_and_restart(ctx):
     c30 = ctx.icp(ctx.upload(src), ix, ope.default_icp_params(max_iterations=30, **kw))
     c40 = ctx.icp(ctx.upload(src), ix, ope.default_icp_params(max_iterations=10, **kw), guess=c30.T)
     assert frob(c40.T, a.T) < 1e-5       # final_T is carried in fp64 inside a run and handed over as fp32 here
+
+
+@pytest.mark.gpu
+def test_deterministic_sums_are_bit_reproducible_from_run_to_run():
+    ope = load_pkg()
+    """ope_icp_params.deterministic_sums = 1: fixed-tree reduction of per-block rows, chunks in natural order, tree kernel only
+    — two runs (two contexts) give the same bits; the default mode (atomic block sums, cost-sorted schedule) agrees with it
+    to the 1e-6 the docs state."""
+    src, tgt = synth.config_clouds("C2")
+    outs = []
+    for det in (1, 1, 0):
+        ctx = ope.Context(0)
+        cs = ctx.upload(src); ix = ctx.build_index(ctx.upload(tgt))
+        p = ope.default_icp_params(max_iterations=40, mse_threshold_absolute=-1.0, check_every=0, deterministic_sums=det)
+        outs.append(ctx.icp(cs, ix, p))
+        ctx.close()
+    assert np.array_equal(outs[0].T, outs[1].T) and outs[0].last_mse == outs[1].last_mse and outs[0].n_corr == outs[1].n_corr
+    assert np.linalg.norm(outs[0].T.astype(np.float64) - outs[2].T.astype(np.float64)) < 1e-5
