@@ -248,6 +248,14 @@ template <> struct leaf_rescan_is_harmless<NearestVisitor> { static constexpr bo
 // ahead of the back-up that reaches it keeps 32 more SGPRs alive, which the 80-VGPR build pays with 83 spilled VGPRs.
 constexpr int kPacketMaxLeaves = 6;
 
+// Developer builds count what a packet walk did (tools/chain_probe.py); the product build compiles the counters away.
+struct PacketStats { uint32_t steps, leaves, backups; };
+#ifdef OPE_DEVELOPER
+#define OPE_PKT_COUNT(ps, field) do { if (ps) ++(ps)->field; } while (0)
+#else
+#define OPE_PKT_COUNT(ps, field) do { } while (0)
+#endif
+
 // A 16-byte load through the CONSTANT address space: with a wave-uniform address the compiler selects s_load_dwordx4
 // (scalar cache, result in SGPRs).  Legal because the index is never written while a search kernel runs.
 typedef const __attribute__((address_space(4))) v4f *scalar_ptr_v4f;
@@ -329,7 +337,7 @@ __device__ __forceinline__ void scan_leaf_uniform(const BvhView &t, uint32_t nod
 }
 
 __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, float qy, float qz, bool active, NearestVisitor &v,
-                                                    uint32_t hint, float *stk, int stk_stride) {
+                                                    uint32_t hint, float *stk, int stk_stride, PacketStats *ps = nullptr) {
   const uint32_t leaf0 = 1u << t.depth;
   const int D = t.depth;
   const unsigned long long act = __ballot(active);
@@ -372,16 +380,18 @@ __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, 
       if (__ballot(stk[(31 - __clz(node)) * stk_stride] < v.best) != 0ull) { more = true; break; }
     }
     if (!more) return true;
+    OPE_PKT_COUNT(ps, backups);
     // walk down from there
     for (;;) {
       if (node >= leaf0) {
         bool dup = false;
         for (int q = 0; q < nd; ++q) dup = dup || (seen[q] == node);
-        if (!dup) scan_leaf_uniform(t, node, qx, qy, qz, v);
+        if (!dup) { scan_leaf_uniform(t, node, qx, qy, qz, v); OPE_PKT_COUNT(ps, leaves); }
         break;
       }
       PacketNode cl, cr;
       load_packet_children(t, node, cl, cr);
+      OPE_PKT_COUNT(ps, steps);
       const float d0 = packet_node_bound(cl, qx, qy, qz), d1 = packet_node_bound(cr, qx, qy, qz);
       const unsigned long long n0 = __ballot(d0 < v.best), n1 = __ballot(d1 < v.best);
       if ((n0 | n1) == 0ull) break;

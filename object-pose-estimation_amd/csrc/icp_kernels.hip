@@ -21,6 +21,11 @@
 
 namespace ope {
 
+#ifdef OPE_DEVELOPER
+// tools/chain_probe.py: per chunk {path: 0 per-lane / 1 packet / 2 groups, packet steps, packet leaf scans, packet back-ups}
+__device__ uint32_t *g_chunk_stats = nullptr;
+#endif
+
 typedef const __attribute__((address_space(3))) float *lds_cfloat_ptr;   // a pointer that stays an LDS pointer
 
 // One query's contribution to the wave's running sums {n, Σs, Σt, Σ t sᵀ, Σd²} (+ 27 normal-equation sums with the
@@ -204,10 +209,25 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       const uint32_t h = active ? hint[i] : 0u;
       if (OCT_OK && oct) {
         if (active) bvh_traverse_oct(tgt, x, y, z, v, &s_stk[0][threadIdx.x & ~7u], BLOCK, h);
+#ifdef OPE_DEVELOPER
+        if (g_chunk_stats && lane_id == 0) {   // path, and the longest of the eight slots' walks (same units as chunk_cost)
+          g_chunk_stats[4 * (size_t)chunk] = 2u;
+          atomicMax(g_chunk_stats + 4 * (size_t)chunk + 1, (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4));
+        }
+#endif
       } else {
         // coherent chunks (a handful of start leaves for 64 queries) take one packet walk through the scalar cache
         // (PACKET instantiation: launches that fill the GPU); everything else the per-lane walk from its own leaf
+#ifdef OPE_DEVELOPER
+        PacketStats pst{0, 0, 0};
+        const bool done = PACKET && bvh_traverse_packet(tgt, x, y, z, active, v, h, stk, BLOCK, &pst);
+        if (g_chunk_stats && lane_id == 0) {
+          uint32_t *o = g_chunk_stats + 4 * (size_t)chunk;
+          o[0] = done ? 1u : 0u; o[1] = pst.steps; o[2] = pst.leaves; o[3] = pst.backups;
+        }
+#else
         const bool done = PACKET && bvh_traverse_packet(tgt, x, y, z, active, v, h, stk, BLOCK);
+#endif
         if (!done && active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, h);
       }
       if (owner && v.leaf != h) hint[i] = v.leaf;   // most start leaves survive an iteration: 4 MB of writes saved on C3
@@ -1325,6 +1345,28 @@ void launch_fitness(hipStream_t stream, int nblocks, const CloudView &q, const B
 }  // namespace ope
 
 #ifdef OPE_DEVELOPER   // `make DEVELOPER=1`: instrumentation kernels are not part of the product library
+// tools/chain_probe.py: switch the per-chunk path/packet counters of the tree kernel on (device buffer of 4 words per
+// chunk, handed back by ope_debug_chunk_stats_read) or off (nullptr)
+extern "C" int ope_debug_chunk_stats(ope_ctx *ctx, uint32_t n_chunks, uint32_t *read_into) {
+  static uint32_t *d_buf = nullptr;
+  static uint32_t cap = 0;
+  if (read_into) {
+    if (!d_buf || n_chunks > cap) return OPE_ESTATE;
+    OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OPE_HIP(ctx, hipMemcpy(read_into, d_buf, 16 * (size_t)n_chunks, hipMemcpyDeviceToHost));
+    return OPE_OK;
+  }
+  if (d_buf) { (void)hipFree(d_buf); d_buf = nullptr; cap = 0; }
+  if (n_chunks) {
+    OPE_HIP(ctx, hipMalloc((void **)&d_buf, 16 * (size_t)n_chunks));
+    OPE_HIP(ctx, hipMemset(d_buf, 0, 16 * (size_t)n_chunks));
+    cap = n_chunks;
+  }
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  OPE_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(ope::g_chunk_stats), &d_buf, sizeof d_buf));
+  return OPE_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // Developer instrumentation (tools/visit_stats.py): per-query node / leaf-point visit counts of the
 // private per-lane traversal.  Not part of include/ope.h.
