@@ -15,8 +15,9 @@ namespace ope {
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
-                           uint32_t *, const uint32_t *, bool, int, double *);
+                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *);
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
+void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
 extern bool g_plan_no_alone;
 int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t, void *, size_t &);
@@ -51,7 +52,7 @@ static thread_local std::string g_global_err;
 
 constexpr double kGridMaxTreeShare = 0.03, kGridMinTreeShare = 0.015;
 constexpr size_t kGridMinQueries = 0;
-constexpr float kHeavyLoadFactor = 1.7f;   // launches that fill the GPU: group walks for chunks beyond this multiple of a wave's fair share (C3: 1.45 177 us, 1.6-1.8 157-159, 2.0 168, 2.4 178)
+constexpr float kHeavyLoadFactor = 1.5f;   // launches that fill the GPU: group walks for chunks beyond this multiple of a wave's fair share (C3, slots listed by duration: 1.0 183 us, 1.2 166, 1.45 153, 1.7 157; without the list 1.45 was 174)
 constexpr float kHeavyMaxChunksPerWave = 1.8f;   // beyond this the launch is throughput-bound: no 8-lane group walks
 
 // Developer A/B switches and sweeps (tools/*.py) read the environment only in builds made with -DOPE_DEVELOPER
@@ -244,6 +245,9 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
       return set_err(ctx, OPE_EHIP, "chunk plan sort failed");
     plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch, heavy_factor, load_factor, (uint32_t)ctx->acc_blocks * (kAccBlock / 64),
                ctx->d_work_counter + 8);
+    static const bool no_slot_list = dev_env("OPE_NO_SLOT_LIST") != nullptr;  // developer A/B switch
+    ctx->slot_list_valid = !no_slot_list && ctx->run_params.corr_mode == OPE_CORR_NEAREST && !ctx->run_params.use_reciprocal;
+    if (ctx->slot_list_valid) plan_slots(ctx->stream, ctx->d_chunk_cost_sorted, nch, ctx->d_work_counter + 8, ctx->d_slot_list);
     ctx->plan_valid = true;
   }
   const ope_icp_params &p = ctx->run_params;
@@ -260,7 +264,8 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   const bool packet = !no_packet && nch > packet_min;
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
                         recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
-                        ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr);
+                        ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr,
+                        (ctx->plan_valid && ctx->slot_list_valid) ? ctx->d_slot_list : nullptr);
   if (timed) {
     OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
     ++ctx->prof_used;
@@ -330,7 +335,7 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->grid_probe_event) (void)hipEventDestroy(ctx->grid_probe_event);
   if (ctx->h_grid_probe) (void)hipHostFree(ctx->h_grid_probe);
   for (void *p : {(void *)ctx->d_chunk_cost, (void *)ctx->d_chunk_cost_sorted, (void *)ctx->d_chunk_ids,
-                  (void *)ctx->d_chunk_order, ctx->d_plan_tmp})
+                  (void *)ctx->d_chunk_order, (void *)ctx->d_slot_list, ctx->d_plan_tmp})
     if (p) (void)hipFree(p);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -855,6 +860,9 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
       OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_keys, 4 * nch));
       OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_ids, 4 * nch));
       OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_order, 4 * nch));
+      if (ctx->d_slot_list) (void)hipFree(ctx->d_slot_list);
+      ctx->d_slot_list = nullptr;
+      OPE_HIP(ctx, hipMalloc((void **)&ctx->d_slot_list, 4 * (nch + 7 * (nch / 4 + 1))));   // n chunks + 7 per group-walked chunk (at most n / 4)
       size_t tb = 0;
       if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order,
                      (uint32_t)nch, nullptr, tb) != 0)
@@ -866,6 +874,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     fill_iota(ctx->stream, ctx->d_chunk_ids, (uint32_t)nch);
     OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * nch, ctx->stream));
     ctx->plan_valid = false;
+    ctx->slot_list_valid = false;
     ctx->acc_launches = 0;
   }
   // no start hints yet: the first iteration walks top-down (hints belong to one (src, tgt) pairing)

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
-    const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic) {
+    const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list) {
   if (st->done) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
@@ -157,23 +157,38 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   // The plan's costliest per-lane chunks each outlast the share of work a wave has in a balanced launch (plan_info[5] of
   // them, ranks n_heavy .. n_heavy + n_alone - 1): each gets a wave to itself (waves 0 .. n_alone - 1) and that wave
   // takes nothing else; all other slots are dealt to the remaining waves in snake order.
-  const uint32_t n_alone = chunk_order ? min(min(plan_info[5] + (measuring ? min(plan_info[0], n_chunks) : 0u), n_chunks - n_heavy), n_waves / 2u) : 0u;
-  const uint32_t n_snake = 8u * n_heavy + (n_chunks - n_heavy - n_alone);
+  // With group walks in the plan the slots come as a list in descending order of expected duration (plan_slots_kernel:
+  // the eight slots of a group-walked chunk merged in among the per-lane chunks they are as long as), its first
+  // plan_info[7] entries being the ones that get a wave to themselves.
+  const bool listed = OCT_OK && slot_list != nullptr && chunk_order != nullptr && !measuring && n_heavy > 0u;
+  const uint32_t n_alone = !chunk_order ? 0u
+                           : listed   ? min(plan_info[7], n_waves / 2u)
+                                      : min(min(plan_info[5] + (measuring ? min(plan_info[0], n_chunks) : 0u), n_chunks - n_heavy), n_waves / 2u);
+  const uint32_t n_snake = listed ? (n_chunks + 7u * n_heavy - n_alone) : (8u * n_heavy + (n_chunks - n_heavy - n_alone));
   const uint32_t snake_waves = n_waves - n_alone;
   for (uint32_t round = 0;; ++round) {
     bool oct = false;
     uint32_t ord, sub = 0;
+    uint32_t slot;
     if (wave_id < n_alone) {
       if (round > 0) break;
+      slot = wave_id;
       ord = n_heavy + wave_id;
     } else {
       if (round * snake_waves >= n_snake) break;
       const uint32_t w = wave_id - n_alone;
-      const uint32_t slot = round * snake_waves + ((round & 1u) ? (snake_waves - 1u - w) : w);
+      slot = round * snake_waves + ((round & 1u) ? (snake_waves - 1u - w) : w);
       if (slot >= n_snake) continue;
       oct = slot < 8u * n_heavy;
       ord = oct ? (slot >> 3) : (n_heavy + n_alone + (slot - 8u * n_heavy));
       sub = slot & 7u;
+      slot += n_alone;
+    }
+    if (listed) {
+      const uint32_t e = slot_list[slot];
+      oct = (e >> 31) != 0u;
+      sub = (e >> 28) & 7u;
+      ord = e & 0x0fffffffu;
     }
     const uint32_t chunk = chunk_order ? chunk_order[ord] : ord;
     const uint32_t base = chunk * 64u;
@@ -1242,17 +1257,17 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
                            const BvhView &tgt, const BvhView &srcix, const IcpState *st, double *partials,
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
                            const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
-                           int k_normal_shooting, double *S_atomic) {
+                           int k_normal_shooting, double *S_atomic, const uint32_t *slot_list) {
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS)                                                                       \
   hipLaunchKernelGGL((icp_accumulate_kernel<M, N, R>), dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, \
-                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic)
+                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list)
   if (mode == 0 && !recip && packet) {
     if (nrm)
       hipLaunchKernelGGL((icp_accumulate_kernel<0, true, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic);
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list);
     else
       hipLaunchKernelGGL((icp_accumulate_kernel<0, false, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic);
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list);
     return;
   }
   if (mode == 0) {
@@ -1264,7 +1279,7 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
     // register list takes ~0.5 ms, and held the kernel at two waves per SIMD
 #define OPE_LAUNCH_NS(KR)                                                                                                          \
   hipLaunchKernelGGL((icp_accumulate_kernel<2, true, false, false, KR>), dim3(nblocks), dim3(kKnnBlock), 0, stream, src, tgt, srcix, st, \
-                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic)
+                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list)
     const int k = k_normal_shooting;
     if (k == 10) OPE_LAUNCH_NS(10);
     else if (k <= 4) OPE_LAUNCH_NS(4);

@@ -131,6 +131,8 @@ struct ope_ctx {
   float *d_corr_d2 = nullptr;
   // cost-aware chunk schedule of the accumulate kernel
   uint32_t *d_chunk_cost = nullptr, *d_chunk_cost_sorted = nullptr, *d_chunk_ids = nullptr, *d_chunk_order = nullptr;
+  uint32_t *d_slot_list = nullptr;   // the launch's slots in descending order of expected duration (plan_slots_kernel)
+  bool slot_list_valid = false;
   void *d_plan_tmp = nullptr;
   size_t plan_tmp_bytes = 0, chunk_cap = 0;
   bool plan_valid = false;

@@ -98,7 +98,8 @@ __device__ __forceinline__ uint32_t count_costlier(const uint32_t *cost_sorted_d
 // plan_info[5] = n_alone, the next-costliest chunks that get a wave to themselves: those at or above the fair share L of
 //   the waves that are left, L = (work not yet given away) / (waves not yet given away), iterated to its fixed point.  A
 //   group-walked chunk counts as kOctWork x its per-lane cost (eight slots of about a third of the duration each).
-constexpr double kOctWork = 2.7;
+constexpr float kOctSlotShare = 0.42f;          // one of a group-walked chunk's eight slots lasts about this share of the chunk's per-lane duration (tools/chain_probe.py: 0.39-0.53)
+constexpr double kOctWork = 8.0 * kOctSlotShare;  // wave-time of a group-walked chunk relative to its per-lane walk
 bool g_plan_no_alone = false;   // developer A/B switch (OPE_NO_ALONE, set by api.hip in DEVELOPER builds)
 __device__ __forceinline__ double block_sum_range(const uint32_t *v, uint32_t a, uint32_t b, double *s_sum) {
   double acc = 0.0;
@@ -154,7 +155,51 @@ __global__ __launch_bounds__(256) void plan_heavy_kernel(const uint32_t *cost_so
   if (threadIdx.x == 0) {
     plan_info[0] = nh;
     plan_info[5] = k;
+    // for the merged slot list (plan_slots_kernel): how many of its leading entries get a wave to themselves — the k
+    // per-lane chunks above, plus the slots of group-walked chunks that on their own reach the fair share (rare)
+    const uint32_t w_left = n_waves > k ? n_waves - k : 1u;
+    const float fair = (float)(rest / (double)w_left);
+    uint32_t lo = 0, hi = nh;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) / 2;
+      if (kOctSlotShare * (float)cost_sorted_desc[mid] >= fair && fair > 0.f) lo = mid + 1; else hi = mid;
+    }
+    plan_info[7] = min(k + 8u * lo, n_waves / 2u);
   }
+}
+
+// The launch's slots in descending order of expected duration: a per-lane chunk of rank q counts its cost, each of the
+// eight slots of a group-walked chunk of rank i < n_heavy counts kOctSlotShare x the chunk's cost.  Both sequences are
+// descending already, so every entry finds its place with one binary search in the other (ties: per-lane first).
+// Entry: rank in bits 0-27, slot in bits 28-30, bit 31 = walked by 8-lane groups.
+__global__ __launch_bounds__(256) void plan_slots_kernel(const uint32_t *__restrict__ cost_sorted_desc, uint32_t n, const uint32_t *__restrict__ plan_info,
+                                                         uint32_t *__restrict__ slot_list) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const uint32_t nh = min(plan_info[0], n);
+  const float c = (float)cost_sorted_desc[r];
+  if (r < nh) {
+    const float key = kOctSlotShare * c;
+    uint32_t lo = nh, hi = n;   // first per-lane rank whose cost is below the key
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) / 2;
+      if ((float)cost_sorted_desc[mid] >= key) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t base = 8u * r + (lo - nh);
+#pragma unroll
+    for (uint32_t j = 0; j < 8u; ++j) slot_list[base + j] = r | (j << 28) | 0x80000000u;
+  } else {
+    uint32_t lo = 0, hi = nh;   // first group-walked rank whose key is not above this cost
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) / 2;
+      if (kOctSlotShare * (float)cost_sorted_desc[mid] > c) lo = mid + 1; else hi = mid;
+    }
+    slot_list[(r - nh) + 8u * lo] = r;
+  }
+}
+
+void plan_slots(hipStream_t stream, const uint32_t *cost_sorted_desc, uint32_t n, const uint32_t *plan_info, uint32_t *slot_list) {
+  hipLaunchKernelGGL(plan_slots_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cost_sorted_desc, n, plan_info, slot_list);
 }
 
 void plan_heavy(hipStream_t stream, const uint32_t *cost_sorted_desc, uint32_t n, float factor, float load_factor, uint32_t n_waves,
