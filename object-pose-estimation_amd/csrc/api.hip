@@ -1135,7 +1135,10 @@ int ope_icp_current_transform(ope_ctx *ctx, float out_T[16]) {
 
 int ope_icp_end(ope_ctx *ctx, float out_T[16], ope_icp_result *result) {
   int rc = ope_icp_poll(ctx, result);
-  if (rc != OPE_OK) return rc;
+  if (rc != OPE_OK) {
+    if (ctx && ctx->run_active) abort_run(ctx);   // e.g. a peer that stopped sending: the run is over, the context stays usable
+    return rc;
+  }
   if (out_T)
     for (int i = 0; i < 16; ++i) out_T[i] = (float)ctx->h_state->F[i];
   ctx->run_active = false;
