@@ -62,6 +62,10 @@ def main() -> int:
     ap.add_argument("--no-coarse", action="store_true", help="skip the FPFH + SAC-IA initial alignment (identity start)")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--steady", type=int, default=100, help="iterations timed after the K steps, in the converged regime (reported, not `value`)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N-rank path on a box with ONE GPU: every rank uses device 0, the process group is gloo and the "
+                         "sums travel through the library's peer-to-peer slots (handles passed over gloo; RCCL refuses two ranks on one "
+                         "device).  The JSON line is marked; it is not a measurement of N GPUs")
     args = ap.parse_args()
     # Everything libraries print through fd 1 (RCCL's version banner, for one) goes to stderr; the one JSON line is
     # written to the real stdout at the end.
@@ -85,13 +89,19 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path is HIP-only and has no CPU fallback", file=sys.stderr)
         return 3
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    cdev = "cpu" if args.share_gpu else "cuda"   # where the small tensors of the process-group collectives live
     # launched by torch.distributed.run (even with one rank): go through the process group, so the
     # collective path is the one exercised
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     ope = importlib.import_module("object-pose-estimation_amd")
     synth = importlib.import_module("object-pose-estimation_amd.synth")
@@ -115,15 +125,23 @@ def main() -> int:
         sums = torch.zeros(ope.NUM_SUMS, dtype=torch.float64, device="cuda")   # SVD estimator: exactly OPE_NUM_SUMS doubles are used
         ctx.icp_set_sums_buffer(sums.data_ptr())
     elif launched:
-        ok = torch.ones(1, device="cuda")
+        ok = torch.ones(1, device=cdev)
         try:
-            ids = [ope.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            ctx.comm_init(ids[0], world, rank)
+            if args.share_gpu:
+                handles = [None] * world
+                dist.all_gather_object(handles, ctx.comm_p2p_open())
+                ctx.comm_p2p_connect(handles, rank)
+            else:
+                ids = [ope.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                ctx.comm_init(ids[0], world, rank)
         except Exception as e:  # pragma: no cover - depends on the node's RCCL
             print(f"[rank {rank}] native RCCL init failed ({e}); using torch.distributed", file=sys.stderr)
             ok.zero_()
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # every rank must agree on the transport
+        if float(ok) == 0.0 and args.share_gpu:
+            print("bench.py: --share-gpu needs the peer-to-peer slots and they could not be set up", file=sys.stderr)
+            return 5
         if float(ok) == 0.0:
             try:
                 ctx.comm_destroy()
@@ -197,7 +215,7 @@ def main() -> int:
     if launched and guess is not None:
         # one initial pose for the whole job: every rank computed it from the same inputs, but the ranks must not
         # depend on bit-identical results across devices, so rank 0's is the one that is used
-        g = torch.from_numpy(np.ascontiguousarray(guess)).cuda()
+        g = torch.from_numpy(np.ascontiguousarray(guess)).to(cdev)
         dist.broadcast(g, src=0)
         guess = g.cpu().numpy()
 
@@ -255,7 +273,7 @@ def main() -> int:
 
     if launched:
         vals = [elapsed, kern_avg_ms] + ([steady["ms_per_step"], steady["kernel_ms"]] if steady else [])
-        t = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        t = torch.tensor(vals, dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_avg_ms = float(t[0]), float(t[1])
         if steady:
@@ -317,7 +335,7 @@ def main() -> int:
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks share one GPU, --share-gpu)" if args.share_gpu else ""),
             "config": {"workload": desc, "n_scene": n_scene, "n_model": n_model, "scene_shard_per_gpu": n_local,
                        "parallelism": f"scene-sharded x{world}, model index replicated, 17xfp64 all-reduce/iter"
                                       + (f" ({args.comm}" + ({ope.COMM_P2P: ": peer-to-peer slots", ope.COMM_RCCL: ": ncclAllReduce"}.get(ctx.comm_transport(), "") if not use_torch_comm else "") + ")" if launched else ""),

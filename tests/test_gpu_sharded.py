@@ -325,3 +325,23 @@ def test_peer_to_peer_exchange_gives_up_on_a_missing_peer_instead_of_hanging(tmp
     assert r1[0] == 5 and r1[1] == ""
     assert r0[0] == -1 and "did not arrive" in r0[1], r0
     assert 3.0 < r0[2] < 20.0, r0            # the bounded wait, not a hang (and not an immediate failure either)
+
+
+@pytest.mark.timeout(600)
+def test_bench_rehearsal_of_the_n_rank_path_on_one_gpu():
+    """bench.py's N-rank code path (sharding, the in-library loop with its exchange, max-over-ranks timing, one JSON line from
+    rank 0) run with two ranks that share the box's GPU: `--share-gpu` = gloo process group + peer-to-peer slots."""
+    import json, socket, subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--workload", "C2",
+           "--steps", "10", "--warmup", "3", "--steady", "5", "--no-cpu-baseline", "--no-coarse"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3 and d["value"] > 0
+    assert "peer-to-peer" in d["config"]["parallelism"] and "REHEARSAL" in d["data"]
+    assert d["config"]["scene_shard_per_gpu"] == 50_000 and d["roofline"]["kernel_ms"] > 0
