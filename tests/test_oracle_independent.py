@@ -4,8 +4,9 @@ numpy / scipy (double precision, brute-force neighbourhoods, python dictionaries
 The reference ships no tests or golden vectors and PCL cannot be built here ("parity unpinned"), so the C
 oracle is the checker of every HIP parity test.  These tests are what stands behind the oracle itself for the pieces
 that had no independent cross-check in round 1: NormalEstimation's eigen33, FPFH on a curved
-surface, UniformSampling, SAC-IA's error metric, StatisticalOutlierRemoval.  (kd-tree vs scipy, Umeyama vs numpy SVD,
-the convergence state machine and hand-computed pair features are in test_oracle_kat.py.)"""
+surface, UniformSampling, SAC-IA's error metric, StatisticalOutlierRemoval, and the ICP loop itself (nearest neighbours,
+Umeyama, composition order, the convergence criteria in their order) against a numpy / scipy loop.  (kd-tree vs scipy,
+Umeyama vs numpy SVD, the convergence state machine and hand-computed pair features are in test_oracle_kat.py.)"""
 import importlib
 
 import numpy as np
@@ -212,3 +213,75 @@ def test_statistical_outlier_removal_against_scipy(mean_k, mul):
     edge = np.abs(md - thr) < 1e-6 * thr            # points within rounding of the threshold may fall either way
     assert set(keep) - set(np.flatnonzero(edge)) == set(want) - set(np.flatnonzero(edge))
     assert 0.85 * len(P) < len(keep) < len(P)
+
+
+# ------------------------------------------------------------------ the ICP loop (icp.hpp computeTransformation + DefaultConvergenceCriteria)
+def icp_numpy(src, tgt, max_iterations, transformation_epsilon, fitness_epsilon, max_corr_dist=np.inf, guess=None):
+    """IterativeClosestPoint::computeTransformation as PCL's text has it, in numpy / scipy (fp64 throughout):
+       final = guess; cloud = guess * source
+       repeat: nearest target point of every cloud point (cKDTree), pairs beyond max_corr_dist dropped;
+               fewer than 3 pairs -> NO_CORRESPONDENCES, stop unconverged;
+               T = Umeyama(cloud pairs -> target pairs) without scaling (numpy SVD, reflection fixed through the last
+               singular vector); cloud = T * cloud; final = T * final; ++iterations;
+               DefaultConvergenceCriteria::hasConverged in its order: iterations >= max -> ITERATIONS;
+               cos(angle of T) >= rotation threshold AND |t|^2 <= translation threshold -> TRANSFORM;
+               MSE = mean SQUARED pair distance of THIS iteration's pairs: |mse - prev| < absolute (1e-12) -> ABS_MSE;
+               |mse - prev| / prev < relative -> REL_MSE; prev = mse.
+       The reference wires the thresholds as icp_mod.hpp:164-168 does: rotation threshold = 1 - transformation_epsilon
+       (sic), translation threshold = transformation_epsilon, relative MSE = euclidean_fitness_epsilon."""
+    tree = cKDTree(tgt.astype(np.float64))
+    final = np.eye(4) if guess is None else np.asarray(guess, np.float64)
+    cloud = src.astype(np.float64) @ final[:3, :3].T + final[:3, 3]
+    prev_mse = np.finfo(np.float64).max
+    it, state = 0, "NOT_CONVERGED"
+    while True:
+        d, j = tree.query(cloud)
+        keep = d <= max_corr_dist
+        if keep.sum() < 3:
+            return final, it, False, "NO_CORRESPONDENCES"
+        a, b = cloud[keep], tgt.astype(np.float64)[j[keep]]
+        ca, cb = a.mean(0), b.mean(0)
+        U, S, Vt = np.linalg.svd((b - cb).T @ (a - ca) / len(a))
+        D = np.eye(3)
+        if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+            D[2, 2] = -1
+        R = U @ D @ Vt
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = cb - R @ ca
+        cloud = cloud @ R.T + T[:3, 3]
+        final = T @ final
+        it += 1
+        if it >= max_iterations:
+            return final, it, True, "ITERATIONS"
+        cos_angle = 0.5 * (np.trace(R) - 1.0)
+        if cos_angle >= 1.0 - transformation_epsilon and float(T[:3, 3] @ T[:3, 3]) <= transformation_epsilon:
+            return final, it, True, "TRANSFORM"
+        mse = float(np.mean(d[keep] ** 2))
+        if abs(mse - prev_mse) < 1e-12:
+            return final, it, True, "ABS_MSE"
+        if abs(mse - prev_mse) / prev_mse < fitness_epsilon:
+            return final, it, True, "REL_MSE"
+        prev_mse = mse
+
+
+@pytest.mark.parametrize("teps,feps,max_it", [(1e-10, 1e-6, 80), (1e-5, 0.0, 80), (0.0, 0.0, 7), (1e-12, 1e-3, 80)])
+def test_icp_loop_against_an_independent_numpy_scipy_loop(teps, feps, max_it):
+    """The oracle's loop (oracle/icp.c) against the numpy loop above on a well-conditioned pair: the same stop reason, the
+    same iteration count (+-1 where a threshold is met within rounding: the oracle forms points and distances in float as
+    PCL does, the numpy loop in double) and the same transform to 1e-5."""
+    rng = np.random.default_rng(3)
+    P = synth.bumpy_torus(3000)
+    a, b, c = np.deg2rad([3.0, -2.0, 4.0])
+    Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    Rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+    R = Rz @ Ry @ Rx
+    Q = (P.astype(np.float64) @ R.T + np.array([0.004, -0.003, 0.006]) + rng.normal(0, 2e-4, P.shape)).astype(np.float32)
+    p = oracle.default_icp_params()
+    p.max_iterations = max_it; p.transformation_epsilon = teps; p.euclidean_fitness_epsilon = feps
+    p.acc_mode = 1; p.transform_mode = 1
+    out = oracle.icp(P, Q, p)
+    T, it, conv, state = icp_numpy(P, Q, max_it, teps, feps)
+    names = {0: "NOT_CONVERGED", 1: "ITERATIONS", 2: "TRANSFORM", 3: "ABS_MSE", 4: "REL_MSE", 5: "NO_CORRESPONDENCES"}
+    assert names[out.state] == state and bool(out.converged) == conv
+    assert abs(out.iterations - it) <= (0 if state == "ITERATIONS" else 1)
+    assert np.abs(out.T.astype(np.float64) - T).max() < 1e-5
