@@ -4,8 +4,9 @@ numpy / scipy (double precision, brute-force neighbourhoods, python dictionaries
 The reference ships no tests or golden vectors and PCL cannot be built here ("parity unpinned"), so the C
 oracle is the checker of every HIP parity test.  These tests are what stands behind the oracle itself for the pieces
 that had no independent cross-check in round 1: NormalEstimation's eigen33, FPFH on a curved
-surface, UniformSampling, SAC-IA's error metric, StatisticalOutlierRemoval, and the ICP loop itself (nearest neighbours,
-Umeyama, composition order, the convergence criteria in their order) against a numpy / scipy loop.  (kd-tree vs scipy,
+surface, UniformSampling, SAC-IA's error metric, StatisticalOutlierRemoval, the ICP loop itself (nearest neighbours,
+Umeyama, composition order, the convergence criteria in their order) against a numpy / scipy loop, and normal shooting with
+the surface-normal rejector.  (kd-tree vs scipy,
 Umeyama vs numpy SVD, the convergence state machine and hand-computed pair features are in test_oracle_kat.py.)"""
 import importlib
 
@@ -285,3 +286,49 @@ def test_icp_loop_against_an_independent_numpy_scipy_loop(teps, feps, max_it):
     assert names[out.state] == state and bool(out.converged) == conv
     assert abs(out.iterations - it) <= (0 if state == "ITERATIONS" else 1)
     assert np.abs(out.T.astype(np.float64) - T).max() < 1e-5
+
+
+# ------------------------------------------------------------------ normal shooting + surface-normal rejector (one ICP iteration)
+def test_normal_shooting_and_rejector_against_numpy_scipy():
+    """CorrespondenceEstimationNormalShooting (k nearest by cKDTree, argmin over them of |n x (t - s)|^2, the squared line
+    distance compared with the UNSQUARED max distance as the vendored file does) and CorrespondenceRejectorSurfaceNormal
+    (n_s . n_t > threshold), then the SVD estimator on the survivors: the oracle's first iteration gives the same pairs and
+    the same transform."""
+    rng = np.random.default_rng(11)
+    u = rng.normal(size=(2500, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    rad = 0.08 * (1 + 0.25 * np.sin(3 * u[:, 0]) * np.cos(2 * u[:, 1]))          # a bumpy ball: normals are not radial
+    P = (rad[:, None] * u + np.array([0, 0, 0.6])).astype(np.float32)
+    nP, _ = oracle.normals_knn(P, 20, (0.0, 0.0, 0.0))                           # (normals themselves are pinned above)
+    a = np.deg2rad(2.0)
+    R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    Q = (P.astype(np.float64) @ R.T + [0.002, -0.001, 0.0015]).astype(np.float32)
+    nQ = (nP.astype(np.float64) @ R.T).astype(np.float32)
+    k, thr, max_dist = 20, 0.9, 0.05
+    p = oracle.default_icp_params()
+    p.max_iterations = 1; p.corr_mode = 1; p.k_normal_shooting = k; p.max_corr_dist = max_dist
+    p.use_surface_normal_rej = 1; p.surface_normal_thr = thr; p.acc_mode = 1; p.transform_mode = 1
+    out = oracle.icp(P, Q, p, src_nrm=nP, tgt_nrm=nQ)
+    # numpy / scipy
+    P64, Q64, n64 = P.astype(np.float64), Q.astype(np.float64), nP.astype(np.float64)
+    _, nn = cKDTree(Q64).query(P64, k=k)
+    V = Q64[nn] - P64[:, None, :]
+    C = np.cross(n64[:, None, :], V)
+    line2 = (C * C).sum(2)
+    jmin = line2.argmin(1)
+    match = nn[np.arange(len(P)), jmin]
+    keep = ~(line2[np.arange(len(P)), jmin] > max_dist)                          # squared line distance vs UNSQUARED max distance
+    keep &= (n64 * nQ.astype(np.float64)[match]).sum(1) > thr
+    q_idx = np.nonzero(keep)[0]
+    assert 0.2 * len(P) < len(q_idx) < len(P)                                    # the rejector does reject here
+    assert out.n_corr == len(q_idx)
+    assert np.array_equal(np.sort(out.corr_q), q_idx)
+    order = np.argsort(out.corr_q)
+    # a pair of candidates at (nearly) the same line distance may be told apart differently in float and double: count them
+    assert (out.corr_m[order] != match[q_idx]).mean() < 2e-3
+    a_, b_ = P64[q_idx], Q64[match[q_idx]]
+    ca, cb = a_.mean(0), b_.mean(0)
+    U, S, Vt = np.linalg.svd((b_ - cb).T @ (a_ - ca))
+    D = np.diag([1, 1, np.sign(np.linalg.det(U) * np.linalg.det(Vt))])
+    Rm = U @ D @ Vt
+    T = np.eye(4); T[:3, :3] = Rm; T[:3, 3] = cb - Rm @ ca
+    assert np.abs(out.T.astype(np.float64) - T).max() < 2e-5
