@@ -113,59 +113,64 @@ __device__ __forceinline__ double block_sum_range(const uint32_t *v, uint32_t a,
   }
   return s_sum[0];
 }
-__global__ __launch_bounds__(256) void plan_heavy_kernel(const uint32_t *cost_sorted_desc, uint32_t n, float factor, float load_factor,
-                                                         uint32_t n_waves, uint32_t *plan_info) {
-  __shared__ double s_sum[256];
-  __shared__ uint32_t s_nh, s_k;
-  const double total = block_sum_range(cost_sorted_desc, 0, n, s_sum);
-  if (threadIdx.x == 0) {
-    uint32_t nh = 0;
-    if (n >= 8) {
-      if (factor > 0.f) nh = count_costlier(cost_sorted_desc, n / 4, factor * (float)cost_sorted_desc[n / 2]);
-      else if (load_factor > 0.f) nh = count_costlier(cost_sorted_desc, n / 4, load_factor * (float)(total / (double)max(n_waves, 1u)));
-    }
-    s_nh = nh;
-    s_k = 0;
-  }
+__global__ __launch_bounds__(1024) void plan_heavy_kernel(const uint32_t *cost_sorted_desc, uint32_t n, float factor, float load_factor,
+                                                          uint32_t n_waves, uint32_t *plan_info) {
+  // prefix sums of the sorted costs at a stride of `per` entries (one pass, one block scan); thread 0 then answers every
+  // "cost of the m costliest chunks" with one LDS read and fewer than `per` loads
+  using scan_t = rocprim::block_scan<double, 1024>;
+  __shared__ typename scan_t::storage_type scan_storage;
+  __shared__ double s_pre[1024];
+  const uint32_t per = (n + 1023u) / 1024u;
+  double acc = 0.0;
+  for (uint32_t i = threadIdx.x * per; i < min(n, (threadIdx.x + 1u) * per); ++i) acc += (double)cost_sorted_desc[i];
+  double excl = 0.0;
+  scan_t().exclusive_scan(acc, excl, 0.0, scan_storage);
+  s_pre[threadIdx.x] = excl;
   __syncthreads();
-  const uint32_t nh = s_nh;
-  const double heavy = block_sum_range(cost_sorted_desc, 0, nh, s_sum);
-  // the eight slots of a group-walked chunk are dealt like ordinary chunks; everything but the alone chunks is "the rest"
-  double rest = kOctWork * heavy + (total - heavy);
-  uint32_t k = 0;
-  for (int pass = 0; pass < 4; ++pass) {
-    if (threadIdx.x == 0) {
-      const uint32_t w_left = n_waves > k ? n_waves - k : 1u;
-      const float fair = (float)(rest / (double)w_left);
-      // chunks nh .. n-1 at or above the fair share (descending list: a prefix), at most half the waves
-      uint32_t lo = nh, hi = min(n, nh + n_waves / 2u);
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) / 2;
-        if ((float)cost_sorted_desc[mid] >= fair && fair > 0.f) lo = mid + 1; else hi = mid;
-      }
-      s_k = lo - nh;
-    }
-    __syncthreads();
-    const uint32_t k_new = s_k;
-    if (k_new == k) break;   // (uniform: every thread reads the same s_k)
-    const double alone = block_sum_range(cost_sorted_desc, nh, nh + k_new, s_sum);
-    rest = kOctWork * heavy + (total - heavy) - alone;
-    k = k_new;
+  if (threadIdx.x != 0) return;
+  auto sum_first = [&](uint32_t m) {
+    m = min(m, n);
+    const uint32_t blk = per ? min(m / per, 1023u) : 0u;
+    double v = s_pre[blk];
+    for (uint32_t i = blk * per; i < m; ++i) v += (double)cost_sorted_desc[i];
+    return v;
+  };
+  const double total = sum_first(n);
+  uint32_t nh = 0, k = 0;
+  double rest = total;
+  if (n >= 8) {
+    if (factor > 0.f) nh = count_costlier(cost_sorted_desc, n / 4, factor * (float)cost_sorted_desc[n / 2]);
+    else if (load_factor > 0.f) nh = count_costlier(cost_sorted_desc, n / 4, load_factor * (float)(total / (double)max(n_waves, 1u)));
   }
-  if (threadIdx.x == 0) {
-    plan_info[0] = nh;
-    plan_info[5] = k;
-    // for the merged slot list (plan_slots_kernel): how many of its leading entries get a wave to themselves — the k
-    // per-lane chunks above, plus the slots of group-walked chunks that on their own reach the fair share (rare)
+  const double heavy = sum_first(nh);
+  // the eight slots of a group-walked chunk are dealt like ordinary chunks; everything but the alone chunks is "the rest"
+  rest = kOctWork * heavy + (total - heavy);
+  for (int pass = 0; pass < 4; ++pass) {
     const uint32_t w_left = n_waves > k ? n_waves - k : 1u;
     const float fair = (float)(rest / (double)w_left);
-    uint32_t lo = 0, hi = nh;
+    // chunks nh .. n-1 at or above the fair share (descending list: a prefix), at most half the waves
+    uint32_t lo = nh, hi = min(n, nh + n_waves / 2u);
     while (lo < hi) {
       const uint32_t mid = (lo + hi) / 2;
-      if (kOctSlotShare * (float)cost_sorted_desc[mid] >= fair && fair > 0.f) lo = mid + 1; else hi = mid;
+      if ((float)cost_sorted_desc[mid] >= fair && fair > 0.f) lo = mid + 1; else hi = mid;
     }
-    plan_info[7] = min(k + 8u * lo, n_waves / 2u);
+    const uint32_t k_new = lo - nh;
+    if (k_new == k) break;
+    k = k_new;
+    rest = kOctWork * heavy + (total - heavy) - (sum_first(nh + k) - heavy);
   }
+  plan_info[0] = nh;
+  plan_info[5] = k;
+  // for the merged slot list (plan_slots_kernel): how many of its leading entries get a wave to themselves — the k
+  // per-lane chunks above, plus the slots of group-walked chunks that on their own reach the fair share (rare)
+  const uint32_t w_left = n_waves > k ? n_waves - k : 1u;
+  const float fair = (float)(rest / (double)w_left);
+  uint32_t lo = 0, hi = nh;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) / 2;
+    if (kOctSlotShare * (float)cost_sorted_desc[mid] >= fair && fair > 0.f) lo = mid + 1; else hi = mid;
+  }
+  plan_info[7] = min(k + 8u * lo, n_waves / 2u);
 }
 
 // The launch's slots in descending order of expected duration: a per-lane chunk of rank q counts its cost, each of the
@@ -204,7 +209,7 @@ void plan_slots(hipStream_t stream, const uint32_t *cost_sorted_desc, uint32_t n
 
 void plan_heavy(hipStream_t stream, const uint32_t *cost_sorted_desc, uint32_t n, float factor, float load_factor, uint32_t n_waves,
                 uint32_t *plan_info) {
-  hipLaunchKernelGGL(plan_heavy_kernel, dim3(1), dim3(256), 0, stream, cost_sorted_desc, n, factor, load_factor, n_waves, plan_info);
+  hipLaunchKernelGGL(plan_heavy_kernel, dim3(1), dim3(1024), 0, stream, cost_sorted_desc, n, factor, load_factor, n_waves, plan_info);
   if (g_plan_no_alone) (void)hipMemsetAsync(plan_info + 5, 0, 4, stream);
 }
 
