@@ -54,3 +54,66 @@ def test_bench_refuses_to_run_without_gpu_and_validates_flags():
     assert r.returncode == 3 and "no CPU fallback" in r.stderr
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 2
+
+
+# ------------------------------------------------------------------ the accumulate launch's static schedule (icp_kernels.hip / sampling.hip)
+def _slot_positions(cost_desc, nh, share=np.float32(0.42)):
+    """plan_slots_kernel restated: the position of every slot in the list ordered by expected duration."""
+    n = len(cost_desc); cf = cost_desc.astype(np.float32); pos = {}
+    for r in range(n):
+        if r < nh:
+            key = share * cf[r]; lo, hi = nh, n
+            while lo < hi:
+                mid = (lo + hi) // 2
+                if cf[mid] >= key: lo = mid + 1
+                else: hi = mid
+            for j in range(8):
+                pos[(r, j, True)] = 8 * r + (lo - nh) + j
+        else:
+            lo, hi = 0, nh
+            while lo < hi:
+                mid = (lo + hi) // 2
+                if share * cf[mid] > cf[r]: lo = mid + 1
+                else: hi = mid
+            pos[(r, 0, False)] = (r - nh) + 8 * lo
+    return pos
+
+
+def _wave_slots(n_slots, n_alone, n_waves):
+    """The kernel's loop: waves below n_alone take one slot each, the others the rest in snake order."""
+    out = []
+    sw = n_waves - n_alone
+    n_snake = n_slots - n_alone
+    for w in range(n_waves):
+        if w < n_alone:
+            out.append([w]); continue
+        mine, rnd = [], 0
+        while rnd * sw < n_snake:
+            k = w - n_alone
+            s = rnd * sw + ((sw - 1 - k) if rnd & 1 else k)
+            if s < n_snake:
+                mine.append(n_alone + s)
+            rnd += 1
+        out.append(mine)
+    return out
+
+
+def test_accumulate_schedule_serves_every_slot_exactly_once():
+    """Index arithmetic of the launch schedule, restated in Python: (a) merging the eight slots of every group-walked chunk
+    among the per-lane chunks by expected duration is a bijection onto 0 .. n + 7 nh - 1 and keeps the list in descending
+    order of its keys, ties included; (b) waves-to-themselves plus the snake over the remaining waves visit every slot
+    exactly once for any number of waves."""
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n = int(rng.integers(1, 300)); nh = int(rng.integers(0, n // 4 + 1))
+        cost = np.sort(rng.integers(0, 40, size=n).astype(np.uint32))[::-1]
+        pos = _slot_positions(cost, nh)
+        assert sorted(pos.values()) == list(range(n + 7 * nh))
+        keys = np.empty(n + 7 * nh, np.float32)
+        for (r, j, grp), p in pos.items():
+            keys[p] = np.float32(0.42) * np.float32(cost[r]) if grp else np.float32(cost[r])
+        assert (np.diff(keys) <= 0).all()
+        n_waves = int(rng.choice([8, 16, 64, 256]))
+        n_alone = min(int(rng.integers(0, n + 7 * nh + 1)), n_waves // 2)
+        seen = sorted(s for w in _wave_slots(n + 7 * nh, n_alone, n_waves) for s in w)
+        assert seen == list(range(n + 7 * nh))
