@@ -322,10 +322,16 @@ int ope_remove_nan(ope_ctx *ctx, const ope_cloud *cloud, int32_t *out_idx, size_
 int ope_pass_through(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], int32_t *out_idx,
                      size_t *n_out);
 /* pcl::VoxelGrid::filter with setLeafSize(leaf[0], leaf[1], leaf[2]) (BuildModel processingpcd.cpp:39-52):
- * one centroid per occupied voxel, in ascending voxel index (PCL's output order); xyz only (colours are
- * not carried).  out_xyz has room for 3 floats per finite input point.  OPE_ERANGE where PCL would warn
+ * one centroid per occupied voxel, in ascending voxel index (PCL's output order); xyz only (ope_voxel_grid_rgb
+ * carries the colours).  out_xyz has room for 3 floats per finite input point.  OPE_ERANGE where PCL would warn
  * "Leaf size is too small for the input dataset" and return the input unchanged. */
 int ope_voxel_grid(ope_ctx *ctx, const ope_cloud *cloud, const float leaf[3], float *out_xyz, size_t *n_out);
+/* pcl::VoxelGrid<PointXYZRGB>::filter as ProcessingPcd::getDownSampled runs it (BuildModel processingpcd.cpp:44-59,
+ * downsample_all_data_ = true): besides the centroid, the packed colour is averaged channel by channel in float and
+ * re-packed by truncation, alpha byte 0 (voxel_grid.hpp, "RGB special case").  rgb: the 32 bits of PointXYZRGB::rgb of
+ * every input point, ORIGINAL order; out_rgb: one word per centroid.  rgb == NULL: ope_voxel_grid. */
+int ope_voxel_grid_rgb(ope_ctx *ctx, const ope_cloud *cloud, const float leaf[3], const uint32_t *rgb, float *out_xyz,
+                       uint32_t *out_rgb, size_t *n_out);
 /* pcl::StatisticalOutlierRemoval::filter with setMeanK(mean_k) and setStddevMulThresh(stddev_mul)
  * (ProcessingPcd::getOutlierRemove, DetectAndLocalize processingpcd.cpp:62-77: meanK 30): a point is removed iff its mean
  * distance to its mean_k nearest neighbours exceeds mean + stddev_mul * stddev over the cloud.  ORIGINAL indices of the

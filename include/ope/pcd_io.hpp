@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -67,7 +68,7 @@ template <class PointT> int loadPCDFile(const std::string &file_name, PointCloud
   if (!f) { std::fprintf(stderr, "[ope::io::loadPCDFile] Could not find file '%s'.\n", file_name.c_str()); return -1; }
   std::vector<Field> fields;
   size_t n_points = 0, width = 0, height = 1;
-  bool have_points = false;
+  bool have_points = false, short_line = false;
   std::string data_kind, line;
   while (std::getline(f, line)) {
     if (!line.empty() && line.back() == '\r') line.pop_back();
@@ -80,10 +81,13 @@ template <class PointT> int loadPCDFile(const std::string &file_name, PointCloud
       while (ss >> name) { Field fl; fl.name = name; fields.push_back(fl); }
     } else if (key == "SIZE") {
       for (auto &fl : fields) ss >> fl.size;
+      short_line = short_line || !ss;
     } else if (key == "TYPE") {
       for (auto &fl : fields) ss >> fl.type;
+      short_line = short_line || !ss;
     } else if (key == "COUNT") {
       for (auto &fl : fields) ss >> fl.count;
+      short_line = short_line || !ss;
     } else if (key == "WIDTH") {
       ss >> width;
     } else if (key == "HEIGHT") {
@@ -97,16 +101,42 @@ template <class PointT> int loadPCDFile(const std::string &file_name, PointCloud
   }
   if (fields.empty() || data_kind.empty()) { std::fprintf(stderr, "[ope::io::loadPCDFile] '%s': no FIELDS / DATA line.\n", file_name.c_str()); return -1; }
   if (!have_points) n_points = width * height;
-  int rec = 0;
-  bool any = false;
+  // header values are untrusted input: every field must have a size of 1, 2, 4 or 8 and a count of at least 1 (a short or
+  // garbled SIZE / TYPE / COUNT line leaves a stream error behind or a zero / negative value), and the point count must be
+  // one the file can hold
+  long long rec = 0;
+  bool any = false, bad = short_line;
   for (auto &fl : fields) {
-    fl.file_off = rec;
-    rec += fl.size * fl.count;
+    if (!(fl.size == 1 || fl.size == 2 || fl.size == 4 || fl.size == 8) || fl.count < 1 || fl.count > 65536 ||
+        !(fl.type == 'F' || fl.type == 'U' || fl.type == 'I')) { bad = true; break; }
+    fl.file_off = (int)rec;
+    rec += (long long)fl.size * fl.count;
+    if (rec > (1 << 24)) { bad = true; break; }
     fl.point_off = (fl.count == 1 && fl.size == 4) ? detail::field_map<PointT>::offset(fl.name) : -1;
     any = any || fl.point_off >= 0;
   }
+  if (bad || rec <= 0) { std::fprintf(stderr, "[ope::io::loadPCDFile] '%s': bad SIZE / TYPE / COUNT in the header.\n", file_name.c_str()); return -1; }
   if (!any) { std::fprintf(stderr, "[ope::io::loadPCDFile] '%s': none of its fields exists in the point type.\n", file_name.c_str()); return -1; }
-  cloud.points.assign(n_points, PointT());
+  {
+    // what is left of the file bounds the point count (binary: rec bytes per point; ascii: at least two bytes per value)
+    const std::streampos here = f.tellg();
+    f.seekg(0, std::ios::end);
+    const std::streampos end = f.tellg();
+    f.seekg(here);
+    const unsigned long long left = (here >= 0 && end >= here) ? (unsigned long long)(end - here) : 0ull;
+    const unsigned long long need = data_kind == "binary" ? (unsigned long long)rec : 2ull * fields.size();
+    if (n_points > left / need + 1ull || (data_kind == "binary" && (unsigned long long)n_points * (unsigned long long)rec > left)) {
+      std::fprintf(stderr, "[ope::io::loadPCDFile] '%s': file shorter than its header says.\n", file_name.c_str());
+      return -1;
+    }
+  }
+  try {
+    cloud.points.assign(n_points, PointT());
+  } catch (const std::bad_alloc &) {
+    std::fprintf(stderr, "[ope::io::loadPCDFile] '%s': out of memory for %zu points.\n", file_name.c_str(), n_points);
+    cloud.clear();
+    return -1;
+  }
   if (data_kind == "binary") {
     std::vector<unsigned char> buf((size_t)rec * n_points);
     f.read(reinterpret_cast<char *>(buf.data()), (std::streamsize)buf.size());

@@ -50,9 +50,10 @@ static_assert(sizeof(PointXYZ) == 16 && sizeof(Normal) == 32 && sizeof(PointXYZR
               sizeof(PointXYZRGBNormal) == 48 && sizeof(FPFHSignature33) == 132 && sizeof(Correspondence) == 12,
               "PCL layouts");
 
-template <class T> struct point_traits { static constexpr ptrdiff_t normal_offset = -1; };
-template <> struct point_traits<PointXYZRGBNormal> { static constexpr ptrdiff_t normal_offset = 16; };
-template <> struct point_traits<Normal> { static constexpr ptrdiff_t normal_offset = 0; };
+template <class T> struct point_traits { static constexpr ptrdiff_t normal_offset = -1; static constexpr ptrdiff_t rgb_offset = -1; };
+template <> struct point_traits<PointXYZRGB> { static constexpr ptrdiff_t normal_offset = -1; static constexpr ptrdiff_t rgb_offset = 16; };
+template <> struct point_traits<PointXYZRGBNormal> { static constexpr ptrdiff_t normal_offset = 16; static constexpr ptrdiff_t rgb_offset = 32; };
+template <> struct point_traits<Normal> { static constexpr ptrdiff_t normal_offset = 0; static constexpr ptrdiff_t rgb_offset = -1; };
 
 template <class PointT> struct PointCloud {
   typedef std::shared_ptr<PointCloud<PointT>> Ptr;
@@ -655,7 +656,8 @@ template <class PointT> class PassThrough {
   float lo_ = -FLT_MAX, hi_ = FLT_MAX;
 };
 
-// pcl::VoxelGrid (processingpcd.cpp:44-49): xyz centroids, ascending voxel index; other fields default-initialised.
+// pcl::VoxelGrid (processingpcd.cpp:44-59): centroids in ascending voxel index; point types with a colour get the
+// channel-wise mean of their voxel's colours (PCL's downsample_all_data_ default), other fields are default-initialised.
 template <class PointT> class VoxelGrid {
  public:
   void setInputCloud(const typename PointCloud<PointT>::ConstPtr &c) { input_ = c; }
@@ -666,8 +668,18 @@ template <class PointT> class VoxelGrid {
     if (ctx && input_ && !input_->empty()) {
       auto dev = upload(*input_, false);
       std::vector<float> xyz(3 * input_->size());
+      std::vector<uint32_t> rgb_in, rgb_out;
+      constexpr ptrdiff_t rgb_off = point_traits<PointT>::rgb_offset;
+      if (rgb_off >= 0) {
+        rgb_in.resize(input_->size());
+        rgb_out.resize(input_->size());
+        for (size_t i = 0; i < input_->size(); ++i)
+          std::memcpy(&rgb_in[i], reinterpret_cast<const unsigned char *>(&input_->points[i]) + rgb_off, 4);
+      }
       size_t n = 0;
-      const int rc = dev->h ? ope_voxel_grid(ctx, dev->h, leaf_, xyz.data(), &n) : OPE_EINVAL;
+      const int rc = !dev->h ? OPE_EINVAL
+                     : rgb_off >= 0 ? ope_voxel_grid_rgb(ctx, dev->h, leaf_, rgb_in.data(), xyz.data(), rgb_out.data(), &n)
+                                    : ope_voxel_grid(ctx, dev->h, leaf_, xyz.data(), &n);
       if (rc == OPE_ERANGE) {  // voxel_grid.hpp: warn and hand the input back
         std::fprintf(stderr, "[ope::VoxelGrid::applyFilter] Leaf size is too small for the input dataset. Integer indices would overflow.\n");
         out = *input_;
@@ -675,7 +687,10 @@ template <class PointT> class VoxelGrid {
       }
       if (rc != OPE_OK) { log_error("VoxelGrid", ctx); n = 0; }
       tmp.points.resize(n);
-      for (size_t i = 0; i < n; ++i) { tmp.points[i].x = xyz[3 * i]; tmp.points[i].y = xyz[3 * i + 1]; tmp.points[i].z = xyz[3 * i + 2]; }
+      for (size_t i = 0; i < n; ++i) {
+        tmp.points[i].x = xyz[3 * i]; tmp.points[i].y = xyz[3 * i + 1]; tmp.points[i].z = xyz[3 * i + 2];
+        if (rgb_off >= 0) std::memcpy(reinterpret_cast<unsigned char *>(&tmp.points[i]) + rgb_off, &rgb_out[i], 4);
+      }
       tmp.width = (uint32_t)n;
     }
     out = std::move(tmp);

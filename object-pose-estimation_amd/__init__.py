@@ -163,6 +163,7 @@ ABI = [
     ("ope_remove_nan", C.c_int, [_vp, _vp, _ip, C.POINTER(C.c_size_t)]),
     ("ope_pass_through", C.c_int, [_vp, _vp, _fp, _fp, _ip, C.POINTER(C.c_size_t)]),
     ("ope_voxel_grid", C.c_int, [_vp, _vp, _fp, _fp, C.POINTER(C.c_size_t)]),
+    ("ope_voxel_grid_rgb", C.c_int, [_vp, _vp, _fp, _vp, _fp, _vp, C.POINTER(C.c_size_t)]),
     ("ope_statistical_outlier_removal", C.c_int, [_vp, _vp, C.c_int, C.c_double, _ip, C.POINTER(C.c_size_t), _fp]),
     ("ope_sacia_default_params", None, [C.POINTER(SaciaParams)]),
     ("ope_sacia", C.c_int, [_vp, _vp, _fp, _vp, _vp, _fp, C.POINTER(SaciaParams), _ip, _fp, _dp, _ip]),
@@ -527,13 +528,21 @@ class Context:
         self._chk(lib().ope_pass_through(self.h, cloud.h, _p(lo, _fp), _p(hi, _fp), _p(out, _ip), C.byref(n)))
         return out[: n.value].copy()
 
-    def voxel_grid(self, cloud: "Cloud", leaf) -> np.ndarray:
-        """pcl::VoxelGrid centroids (m,3) in ascending voxel index; OpeError(OPE_ERANGE) where PCL refuses the leaf."""
+    def voxel_grid(self, cloud: "Cloud", leaf, rgb=None):
+        """pcl::VoxelGrid centroids (m,3) in ascending voxel index; OpeError(OPE_ERANGE) where PCL refuses the leaf.
+        rgb (optional, n uint32 = the bits of PointXYZRGB::rgb, input order): also the voxels' colours -> (centroids, colours)."""
         lf = np.ascontiguousarray(np.broadcast_to(np.asarray(leaf, np.float32), (3,)))
         out = np.empty((max(cloud.n, 1), 3), np.float32)
         n = C.c_size_t(0)
-        self._chk(lib().ope_voxel_grid(self.h, cloud.h, _p(lf, _fp), _p(out, _fp), C.byref(n)))
-        return out[: n.value].copy()
+        if rgb is None:
+            self._chk(lib().ope_voxel_grid(self.h, cloud.h, _p(lf, _fp), _p(out, _fp), C.byref(n)))
+            return out[: n.value].copy()
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint32)
+        if rgb.shape != (cloud.n,):
+            raise ValueError("rgb: one packed colour per input point")
+        oc = np.zeros(max(cloud.n, 1), np.uint32)
+        self._chk(lib().ope_voxel_grid_rgb(self.h, cloud.h, _p(lf, _fp), rgb.ctypes.data, _p(out, _fp), oc.ctypes.data, C.byref(n)))
+        return out[: n.value].copy(), oc[: n.value].copy()
 
     def statistical_outlier_removal(self, cloud: "Cloud", mean_k: int = 30, stddev_mul: float = 1.0, return_distances: bool = False):
         """pcl::StatisticalOutlierRemoval (ProcessingPcd::getOutlierRemove): original indices of the inliers, ascending."""

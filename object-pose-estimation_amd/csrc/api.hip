@@ -15,8 +15,12 @@ namespace ope {
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
-                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *);
-void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
+                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, const uint32_t *, const unsigned char *);
+size_t far_plan_tmp_bytes(uint32_t);
+int far_plan(hipStream_t, const float *, const uint32_t *, uint32_t, float, int, unsigned char *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *,
+             void *, size_t);
+void far_chunk_keys(hipStream_t, const uint32_t *, uint32_t, uint32_t, const uint32_t *, uint32_t *);
+void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *, uint32_t);
 void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
 extern bool g_plan_no_alone;
@@ -147,6 +151,7 @@ static int grid_probe_poll(ope_ctx *ctx, int it_done) {
 static int switch_kernel(ope_ctx *ctx, bool to_grid, int it_done, uint32_t nch) {
   ctx->use_grid = to_grid;
   ctx->plan_valid = false;   // chunk ids mean something else to the other kernel
+  ctx->far_valid = false;    // (plan_info[1] is the grid kernel's query count while that kernel runs)
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * (size_t)(nch + 1), ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 8, 0, 8, ctx->stream));
   if (to_grid) {
@@ -220,8 +225,33 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     --ctx->acc_launches;
     return enqueue_accumulate(ctx, atomic_sums);
   }
+  // far list (developer experiment for now): see far_plan, sampling.hip
+  static const bool far_env = dev_env("OPE_FAR") != nullptr;
+  static const float far_thr = [] { const char *e = dev_env("OPE_FAR_THR"); return e ? (float)atof(e) : 0.0025f; }();
+  const bool far_on = far_env && !no_plan && nch > 1 && ctx->run_params.corr_mode == OPE_CORR_NEAREST && !ctx->run_params.use_reciprocal &&
+                      ctx->run_tgt->d_axis2 != nullptr;
   if (!no_plan && nch > 1 && it_done >= 1 &&
       (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0 || it_done == ctx->force_plan_at)) {
+    if (far_on) {
+      const uint32_t nv = (uint32_t)ctx->run_src->n_valid;
+      if (ctx->fo_cap < nv) {
+        for (void *q : {(void *)ctx->d_fo_keys, (void *)ctx->d_fo_keys2, (void *)ctx->d_fo_vals, (void *)ctx->d_far_list, (void *)ctx->d_far_class, ctx->d_fo_tmp})
+          if (q) (void)hipFree(q);
+        ctx->d_fo_keys = ctx->d_fo_keys2 = ctx->d_fo_vals = ctx->d_far_list = nullptr; ctx->d_far_class = nullptr; ctx->d_fo_tmp = nullptr; ctx->fo_cap = 0;
+        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_fo_keys, 4 * (size_t)nv));
+        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_fo_keys2, 4 * (size_t)nv));
+        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_fo_vals, 4 * (size_t)nv));
+        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_far_list, 4 * (size_t)nv));
+        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_far_class, (size_t)nv));
+        ctx->fo_tmp_bytes = far_plan_tmp_bytes(nv);
+        OPE_HIP(ctx, hipMalloc(&ctx->d_fo_tmp, ctx->fo_tmp_bytes));
+        ctx->fo_cap = nv;
+      }
+      if (far_plan(ctx->stream, ctx->d_corr_d2, ctx->d_hint, nv, far_thr * far_thr, ctx->run_tgt->depth, ctx->d_far_class, ctx->d_fo_keys, ctx->d_fo_keys2,
+                   ctx->d_fo_vals, ctx->d_far_list, ctx->d_work_counter + 8, ctx->d_fo_tmp, ctx->fo_tmp_bytes) != 0)
+        return set_err(ctx, OPE_EHIP, "far plan sort failed");
+      ctx->far_valid = true;
+    }
     if (ctx->grid_auto && it_done >= 8) {
       const int rcp = grid_probe_issue(ctx);
       if (rcp != OPE_OK) return rcp;
@@ -243,13 +273,20 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     // (rocPRIM sorts these few keys with a block sort and four or five merge launches, ~40 us; a one-block
     // rocprim::block_radix_sort of the 15 625 keys took 63 us on its single CU: measured, not kept)
     size_t tb = ctx->plan_tmp_bytes;
-    if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch, ctx->d_plan_tmp, tb) != 0)
+    // with a far list the plan covers the Morton chunks 0 .. nch-1 and the far chunks nch .. (at most as many again)
+    const uint32_t nch_plan = ctx->far_valid ? 2u * nch : nch;
+    const uint32_t *plan_keys = ctx->d_chunk_cost;
+    if (ctx->far_valid) {
+      far_chunk_keys(ctx->stream, ctx->d_chunk_cost, nch, nch_plan, ctx->d_work_counter + 8, ctx->d_chunk_keys);
+      plan_keys = ctx->d_chunk_keys;
+    }
+    if (chunk_plan(ctx->stream, plan_keys, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch_plan, ctx->d_plan_tmp, tb) != 0)
       return set_err(ctx, OPE_EHIP, "chunk plan sort failed");
-    plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch, heavy_factor, load_factor, (uint32_t)ctx->acc_blocks * (kAccBlock / 64),
-               ctx->d_work_counter + 8);
+    plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch_plan, heavy_factor, load_factor, (uint32_t)ctx->acc_blocks * (kAccBlock / 64),
+               ctx->d_work_counter + 8, ctx->far_valid ? nch : 0u);
     static const bool no_slot_list = dev_env("OPE_NO_SLOT_LIST") != nullptr;  // developer A/B switch
     ctx->slot_list_valid = !no_slot_list && ctx->run_params.corr_mode == OPE_CORR_NEAREST && !ctx->run_params.use_reciprocal;
-    if (ctx->slot_list_valid) plan_slots(ctx->stream, ctx->d_chunk_cost_sorted, nch, ctx->d_work_counter + 8, ctx->d_slot_list);
+    if (ctx->slot_list_valid) plan_slots(ctx->stream, ctx->d_chunk_cost_sorted, nch_plan, ctx->d_work_counter + 8, ctx->d_slot_list);
     ctx->plan_valid = true;
   }
   const ope_icp_params &p = ctx->run_params;
@@ -267,7 +304,8 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
                         recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
                         ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr,
-                        (ctx->plan_valid && ctx->slot_list_valid) ? ctx->d_slot_list : nullptr);
+                        (ctx->plan_valid && ctx->slot_list_valid) ? ctx->d_slot_list : nullptr, ctx->far_valid ? ctx->d_far_list : nullptr,
+                        ctx->far_valid ? ctx->d_far_class : nullptr);
   if (timed) {
     OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
     ++ctx->prof_used;
@@ -338,6 +376,8 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->h_grid_probe) (void)hipHostFree(ctx->h_grid_probe);
   for (void *p : {(void *)ctx->d_chunk_cost, (void *)ctx->d_chunk_cost_sorted, (void *)ctx->d_chunk_ids,
                   (void *)ctx->d_chunk_order, (void *)ctx->d_slot_list, ctx->d_plan_tmp})
+    if (p) (void)hipFree(p);
+  for (void *p : {(void *)ctx->d_fo_keys, (void *)ctx->d_fo_keys2, (void *)ctx->d_fo_vals, (void *)ctx->d_far_list, (void *)ctx->d_far_class, ctx->d_fo_tmp})
     if (p) (void)hipFree(p);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -751,6 +791,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
 // is a cache over the same points).
 static int ensure_grid(ope_ctx *ctx, const ope_index *cix) {
   ope_index *ix = const_cast<ope_index *>(cix);
+  std::lock_guard<std::mutex> lock(ix->grid_mutex);   // contexts or threads that share the index: one of them builds, the others wait
   if (ix->has_grid || !ix->want_grid || !ix->d_pts) return OPE_OK;
   TraceRange r(ctx, "grid_build");
   const hipError_t eg = build_grid_device(ctx->stream, ix->d_pts, ix->d_nrm, ix->n, ix->bb_lo, ix->bb_hi, ix->grid_fill, (uint32_t)std::max(ix->grid_max_cells, 0), &ix->grid, &ix->d_gpts, &ix->d_gnrm,
@@ -760,6 +801,8 @@ static int ensure_grid(ope_ctx *ctx, const ope_index *cix) {
   float amax = 0.f;
   for (int d = 0; d < 3; ++d) amax = std::max({amax, std::fabs(ix->bb_lo[d]), std::fabs(ix->bb_hi[d])});
   ix->grid.eps = 4e-7f * amax + 1e-30f;
+  // the build ran on this context's stream: finished before another context's stream may read it
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ix->has_grid = true;
   return OPE_OK;
 }
@@ -776,6 +819,8 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   if (!ctx || !src) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: bad argument");
   // Registration::initCompute: "No input target dataset was given!" (registration_mod.hpp:73-77)
   if (!tgt) return set_err(ctx, OPE_EEMPTY, "ope_icp_begin: no input target dataset was given");
+  if (ctx->p2p_broken)
+    return set_err(ctx, OPE_ECOMM, "ope_icp_begin: the peer-to-peer communicator timed out in an earlier run and must be re-created (ope_comm_destroy, then ope_comm_init_rank or ope_comm_p2p_open/connect)");
   ope_icp_params p;
   ope_icp_default_params(&p);
   if (params) p = *params;
@@ -816,7 +861,8 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   // (deterministic_sums: the tree kernel in the chunks' natural order only — which kernel runs when, and which wave takes
   // which chunk, follow from measured times otherwise, and with them the grouping of the fp64 additions)
   if (p.corr_mode == OPE_CORR_NEAREST && !p.use_reciprocal && tgt->want_grid && src->n_valid > 0 && p.estimator != OPE_EST_POINT_TO_PLANE_LM &&
-      !p.deterministic_sums && (tgt->grid_mode == 2 || src->n_valid >= kGridMinQueries)) {
+      !p.deterministic_sums && (tgt->grid_mode == 2 || src->n_valid >= kGridMinQueries) &&
+      (tgt->has_grid || tgt->grid_mode == 2 || p.max_iterations > 1)) {   // a one-pass run (the facade's stand-alone determineCorrespondences) does not pay for a grid build
     const int rcg = ensure_grid(ctx, tgt);
     if (rcg != OPE_OK) return rcg;
     ctx->use_grid = tgt->has_grid;
@@ -847,7 +893,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   // every slot starts as "no correspondence" (non-finite points never get written)
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_corr_match, 0xff, sizeof(int32_t) * std::max<size_t>(src->n, 1), ctx->stream));
   {
-    const size_t nch = (src->n_valid + 63) / 64 + 1;
+    const size_t nch = 2 * ((src->n_valid + 63) / 64 + 1);   // Morton chunks + as many far chunks at most
     if (ctx->chunk_cap < nch) {
       for (void *p : {(void *)ctx->d_chunk_cost, (void *)ctx->d_chunk_cost_sorted, (void *)ctx->d_chunk_ids,
                       (void *)ctx->d_chunk_order, ctx->d_plan_tmp})
@@ -877,6 +923,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * nch, ctx->stream));
     ctx->plan_valid = false;
     ctx->slot_list_valid = false;
+    ctx->far_valid = false;
     ctx->acc_launches = 0;
   }
   // no start hints yet: the first iteration walks top-down (hints belong to one (src, tgt) pairing)
@@ -1122,8 +1169,13 @@ int ope_icp_poll(ope_ctx *ctx, ope_icp_result *result) {
   OPE_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (result) fill_result(ctx, result);
-  if (ctx->h_state->comm_error)
-    return set_err(ctx, OPE_ECOMM, "a peer's sums did not arrive within 5 s (peer-to-peer exchange): the run was ended");
+  if (ctx->h_state->comm_error) {
+    // the ranks' sequence numbers no longer agree and the slots hold the words of the aborted exchange: a later run could
+    // accept them as fresh.  The communicator is unusable from here on (ope_icp_begin refuses) until it is re-created.
+    ctx->p2p_ok = false;
+    ctx->p2p_broken = true;
+    return set_err(ctx, OPE_ECOMM, "a peer's sums did not arrive within 5 s (peer-to-peer exchange): the run was ended; re-create the communicator (ope_comm_destroy, then ope_comm_init_rank or ope_comm_p2p_open/connect) before the next sharded run");
+  }
   return OPE_OK;
 }
 

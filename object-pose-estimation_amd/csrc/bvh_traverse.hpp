@@ -224,6 +224,7 @@ struct NearestVisitor {
   uint32_t pos;   // reordered target position of the best point, kNoPos if none
   uint32_t leaf;  // heap id of the leaf that holds it (next iteration's start hint)
   __device__ __forceinline__ bool prune(float bound) const { return !(bound < best); }
+  __device__ __forceinline__ float bound() const { return best; }   // a subtree is worth entering iff its lower bound is below this
   __device__ __forceinline__ void point(float d, const v4f &, uint32_t i, uint32_t lf) {
     if (d < best) { best = d; pos = i; leaf = lf; }
   }
@@ -336,22 +337,68 @@ __device__ __forceinline__ void scan_leaf_uniform(const BvhView &t, uint32_t nod
   v.leaf = (v.pos != pos0) ? node : v.leaf;
 }
 
-__device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, float qy, float qz, bool active, NearestVisitor &v,
-                                                    uint32_t hint, float *stk, int stk_stride, PacketStats *ps = nullptr) {
+// The same scan for visitors that must be shown every point exactly once (k-nearest lists): guarded batches of four.
+template <class Visitor>
+__device__ __forceinline__ void scan_leaf_uniform_once(const BvhView &t, uint32_t node, float qx, float qy, float qz, Visitor &v) {
+  const uint32_t j = node - (1u << t.depth);
+  const uint32_t s = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
+  const uint32_t e = (uint32_t)(((unsigned long long)(j + 1) * t.n) >> t.depth);
+  for (uint32_t i = s; i < e; i += 4) {
+    // a batch may run past the leaf (guarded) and, at the last leaf, into the kPtsPad zeroed entries
+    const float4 *p = t.pts + i;
+    const v4f p0 = ld16_scalar(p), p1 = ld16_scalar(p + 1), p2 = ld16_scalar(p + 2), p3 = ld16_scalar(p + 3);
+    v.point(sq_dist3(__fsub_rn(qx, p0.x), __fsub_rn(qy, p0.y), __fsub_rn(qz, p0.z)), p0, i, node);
+    if (i + 1 < e) v.point(sq_dist3(__fsub_rn(qx, p1.x), __fsub_rn(qy, p1.y), __fsub_rn(qz, p1.z)), p1, i + 1, node);
+    if (i + 2 < e) v.point(sq_dist3(__fsub_rn(qx, p2.x), __fsub_rn(qy, p2.y), __fsub_rn(qz, p2.z)), p2, i + 2, node);
+    if (i + 3 < e) v.point(sq_dist3(__fsub_rn(qx, p3.x), __fsub_rn(qy, p3.y), __fsub_rn(qz, p3.z)), p3, i + 3, node);
+  }
+}
+template <class Visitor>
+__device__ __forceinline__ void packet_scan_leaf(const BvhView &t, uint32_t node, float qx, float qy, float qz, Visitor &v) {
+  if constexpr (leaf_rescan_is_harmless<Visitor>::value) scan_leaf_uniform(t, node, qx, qy, qz, v);
+  else scan_leaf_uniform_once(t, node, qx, qy, qz, v);
+}
+
+// force: the chunk is a piece of the far list (queries sorted by start leaf): it takes the packet walk whatever its
+// number of distinct start leaves — the first kPacketMaxLeaves are scanned by everybody, a lane whose own start leaf is
+// not among them scans it privately (1-NN visitors; a point seen twice changes nothing), and a lane without a start
+// leaf simply starts from its initial bound.
+template <class Visitor>
+__device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, float qy, float qz, bool active, Visitor &v,
+                                                    uint32_t hint, float *stk, int stk_stride, bool force = false, PacketStats *ps = nullptr) {
   const uint32_t leaf0 = 1u << t.depth;
   const int D = t.depth;
   const unsigned long long act = __ballot(active);
-  if (t.axis2 == nullptr || act == 0ull || __ballot(active && hint == 0u) != 0ull) return false;
+  if (t.axis2 == nullptr || act == 0ull) return false;
+  if (!force && __ballot(active && hint == 0u) != 0ull) return false;
   // the distinct start leaves, scanned by every lane
   uint32_t seen[kPacketMaxLeaves];
   int nd = 0;
-  unsigned long long todo = act;
+  unsigned long long todo = __ballot(active && hint != 0u);
+  if (todo == 0ull) return false;
   while (todo != 0ull) {
-    if (nd == kPacketMaxLeaves) return false;
+    if (nd == kPacketMaxLeaves) {
+      if (!force) return false;
+      break;
+    }
     const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)hint, (int)__builtin_ctzll(todo));
-    scan_leaf_uniform(t, L, qx, qy, qz, v);
+    packet_scan_leaf(t, L, qx, qy, qz, v);
     todo &= ~__ballot(hint == L);
     seen[nd++] = L;
+  }
+  if constexpr (leaf_rescan_is_harmless<Visitor>::value) {
+    if (todo != 0ull) {
+      // lanes whose start leaf was not among the shared ones: their own leaf, privately (divergent gathers, a few lanes)
+      if ((todo >> (threadIdx.x & 63u)) & 1ull) {
+        const uint32_t j = hint - leaf0;
+        const uint32_t s = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
+        const uint32_t e = (uint32_t)(((unsigned long long)(j + 1) * t.n) >> t.depth);
+        for (uint32_t i = s; i < e; ++i) {
+          const v4f p = ld16(t.pts + i);
+          v.point(sq_dist3(__fsub_rn(qx, p.x), __fsub_rn(qy, p.y), __fsub_rn(qz, p.z)), p, i, hint);
+        }
+      }
+    }
   }
   // per-lane bounds of the first leaf's ancestor siblings (that leaf plus those D subtrees cover the tree), two
   // scalar fetches (24 SGPRs) in flight, parked like the per-lane walk parks them
@@ -371,13 +418,13 @@ __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, 
   }
   for (;;) {
     // back up to the deepest pending sibling that ANY lane can still improve in (inactive lanes carry best = -inf)
-    if (__ballot(minb < v.best) == 0ull) return true;
+    if (__ballot(minb < v.bound()) == 0ull) return true;
     bool more = false;
     while (trail != 0u) {
       const int k = __builtin_ctz(trail);
       node = (node >> k) ^ 1u;
       trail = (trail >> k) & ~1u;
-      if (__ballot(stk[(31 - __clz(node)) * stk_stride] < v.best) != 0ull) { more = true; break; }
+      if (__ballot(stk[(31 - __clz(node)) * stk_stride] < v.bound()) != 0ull) { more = true; break; }
     }
     if (!more) return true;
     OPE_PKT_COUNT(ps, backups);
@@ -386,14 +433,14 @@ __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, 
       if (node >= leaf0) {
         bool dup = false;
         for (int q = 0; q < nd; ++q) dup = dup || (seen[q] == node);
-        if (!dup) { scan_leaf_uniform(t, node, qx, qy, qz, v); OPE_PKT_COUNT(ps, leaves); }
+        if (!dup) { packet_scan_leaf(t, node, qx, qy, qz, v); OPE_PKT_COUNT(ps, leaves); }
         break;
       }
       PacketNode cl, cr;
       load_packet_children(t, node, cl, cr);
       OPE_PKT_COUNT(ps, steps);
       const float d0 = packet_node_bound(cl, qx, qy, qz), d1 = packet_node_bound(cr, qx, qy, qz);
-      const unsigned long long n0 = __ballot(d0 < v.best), n1 = __ballot(d1 < v.best);
+      const unsigned long long n0 = __ballot(d0 < v.bound()), n1 = __ballot(d1 < v.bound());
       if ((n0 | n1) == 0ull) break;
       // nearer child first by majority; the other one is parked if any lane wants it
       const bool right = (n0 == 0ull) || (n1 != 0ull && 2 * __popcll(__ballot(d1 < d0) & act) > __popcll(act));
@@ -555,6 +602,7 @@ struct KnnRegVisitor {
     leaf = 0;
   }
   __device__ __forceinline__ bool prune(float bound) const { return !(bound < d[K - 1]); }
+  __device__ __forceinline__ float bound() const { return d[K - 1]; }
   __device__ __forceinline__ void point(float dist, const v4f &, uint32_t i, uint32_t lf) {
     const bool ins = dist < d[K - 1];
     if (__ballot(ins) == 0ull) return;

@@ -65,6 +65,7 @@ void p2p_teardown(ope_ctx *ctx) {
   if (ctx->p2p_mine) { (void)hipFree(ctx->p2p_mine); ctx->p2p_mine = nullptr; }
   if (ctx->p2p_scratch) { (void)hipFree(ctx->p2p_scratch); ctx->p2p_scratch = nullptr; }
   ctx->p2p_ok = false;
+  ctx->p2p_broken = false;
   ctx->p2p_seq = 0;
 }
 
@@ -82,6 +83,9 @@ static bool p2p_alloc(ope_ctx *ctx, hipIpcMemHandle_t *handle) {
 }
 static bool p2p_map_peers(ope_ctx *ctx, const hipIpcMemHandle_t *handles, int nranks, int rank) {
   bool ok = ctx->p2p_mine != nullptr && nranks >= 1 && nranks <= kP2pMaxRanks && rank >= 0 && rank < nranks;
+  // a second connect on the same buffer: the earlier mappings are closed first (they would leak otherwise)
+  for (int p = 0; p < kP2pMaxRanks; ++p)
+    if (ctx->p2p_peer[p]) { (void)hipIpcCloseMemHandle(ctx->p2p_peer[p]); ctx->p2p_peer[p] = nullptr; }
   for (int p = 0; p < nranks && ok; ++p) {
     if (p == rank) continue;
     if (hipIpcOpenMemHandle(&ctx->p2p_peer[p], handles[p], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { ctx->p2p_peer[p] = nullptr; ok = false; }
@@ -117,13 +121,11 @@ static void p2p_setup_over_rccl(ope_ctx *ctx) {
   Rccl &r = rccl();
   const int n = ctx->comm_nranks;
   unsigned char *d_handles = nullptr;
-  int *d_ok = nullptr;
-  if (hipMalloc((void **)&d_handles, sizeof(hipIpcMemHandle_t) * (size_t)(n + 1)) != hipSuccess || hipMalloc((void **)&d_ok, sizeof(int)) != hipSuccess) {
-    // (the peers' collectives below would wait for this rank: like any other allocation failure at set-up, not recoverable)
-    if (d_handles) (void)hipFree(d_handles);
-    (void)hipGetLastError();
-    return;
-  }
+  // the verdict word lives in the context's own scratch block (allocated with the context), so that a rank whose
+  // allocations fail here still takes part in every collective below and votes "no": its peers must not wait for it
+  int *d_ok = reinterpret_cast<int *>(ctx->d_work_counter + 60);
+  const bool have_mem = hipMalloc((void **)&d_handles, sizeof(hipIpcMemHandle_t) * (size_t)(n + 1)) == hipSuccess;
+  if (!have_mem) { d_handles = nullptr; (void)hipGetLastError(); }
   ncclComm_t comm = (ncclComm_t)ctx->nccl_comm;
   auto agree = [&](bool mine_ok) {   // min over ranks
     int v = mine_ok ? 1 : 0, out = 0;
@@ -135,7 +137,7 @@ static void p2p_setup_over_rccl(ope_ctx *ctx) {
   };
   hipIpcMemHandle_t mine{};
   std::vector<hipIpcMemHandle_t> handles((size_t)std::max(n, 1));
-  bool ok = agree(n >= 2 && n <= kP2pMaxRanks && r.AllGather && p2p_alloc(ctx, &mine));
+  bool ok = agree(have_mem && n >= 2 && n <= kP2pMaxRanks && r.AllGather && p2p_alloc(ctx, &mine));
   if (ok) {
     unsigned char *d_mine = d_handles + sizeof(hipIpcMemHandle_t) * (size_t)n;
     const bool step = hipMemcpyAsync(d_mine, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
@@ -145,8 +147,7 @@ static void p2p_setup_over_rccl(ope_ctx *ctx) {
     ok = agree(step && p2p_map_peers(ctx, handles.data(), n, ctx->comm_rank));
   }
   if (ok) ok = agree(p2p_self_test(ctx));
-  (void)hipFree(d_handles);
-  (void)hipFree(d_ok);
+  if (d_handles) (void)hipFree(d_handles);
   if (ok) ctx->p2p_ok = true;
   else p2p_teardown(ctx);
   (void)hipGetLastError();
@@ -247,6 +248,9 @@ int ope_comm_p2p_connect(ope_ctx *ctx, const char *handles, int nranks, int rank
   if (!ctx || !handles || nranks < 1 || nranks > kP2pMaxRanks || rank < 0 || rank >= nranks)
     return set_err(ctx, OPE_EINVAL, "ope_comm_p2p_connect: bad argument (at most 8 ranks)");
   if (!ctx->p2p_mine) return set_err(ctx, OPE_ESTATE, "ope_comm_p2p_connect: ope_comm_p2p_open first");
+  if (ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_comm_p2p_connect: a run is in progress");
+  if (ctx->p2p_ok || ctx->p2p_broken)
+    return set_err(ctx, OPE_ESTATE, "ope_comm_p2p_connect: this buffer has been connected already; ope_comm_p2p_open makes a fresh one (slots and sequence numbers start over)");
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<hipIpcMemHandle_t> hs((size_t)nranks);
   for (int p = 0; p < nranks; ++p) std::memcpy(&hs[(size_t)p], handles + (size_t)p * OPE_P2P_HANDLE_BYTES, sizeof(hipIpcMemHandle_t));

@@ -60,19 +60,27 @@ __global__ __launch_bounds__(256) void run_start_kernel(const unsigned long long
 __global__ __launch_bounds__(256) void centroid_kernel(CloudView c, const unsigned long long *__restrict__ keys,
                                                         const uint32_t *__restrict__ vals, const uint32_t *__restrict__ flags,
                                                         const uint32_t *__restrict__ slot, uint32_t n_valid,
-                                                        float *__restrict__ out_xyz) {
+                                                        float *__restrict__ out_xyz, const uint32_t *__restrict__ rgb_orig,
+                                                        uint32_t *__restrict__ out_rgb) {
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n_valid || flags[p] == 0u) return;
   const unsigned long long vox = keys[p] >> 32;
-  float sx = 0.f, sy = 0.f, sz = 0.f;
+  float sx = 0.f, sy = 0.f, sz = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
   uint32_t j = p;
   for (; j < n_valid && (keys[j] >> 32) == vox; ++j) {
     const float4 q = c.xyzw[vals[j]];
     sx = __fadd_rn(sx, q.x); sy = __fadd_rn(sy, q.y); sz = __fadd_rn(sz, q.z);
+    if (rgb_orig) {
+      // voxel_grid.hpp "RGB special case": the channels of pcl::RGB join the centroid vector as three floats
+      const uint32_t v = rgb_orig[(uint32_t)__float_as_int(q.w)];
+      cr = __fadd_rn(cr, (float)((v >> 16) & 255u)); cg = __fadd_rn(cg, (float)((v >> 8) & 255u)); cb = __fadd_rn(cb, (float)(v & 255u));
+    }
   }
   const float r = __fdiv_rn(1.0f, (float)(j - p));
   float *o = out_xyz + 3 * (size_t)slot[p];
   o[0] = __fmul_rn(sx, r); o[1] = __fmul_rn(sy, r); o[2] = __fmul_rn(sz, r);
+  if (rgb_orig)   // (static_cast<int>(r) << 16) | (static_cast<int>(g) << 8) | static_cast<int>(b)
+    out_rgb[slot[p]] = ((uint32_t)(int)__fmul_rn(cr, r) << 16) | ((uint32_t)(int)__fmul_rn(cg, r) << 8) | (uint32_t)(int)__fmul_rn(cb, r);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -199,7 +207,12 @@ extern "C" int ope_pass_through(ope_ctx *ctx, const ope_cloud *cloud, const floa
 }
 
 extern "C" int ope_voxel_grid(ope_ctx *ctx, const ope_cloud *cloud, const float leaf[3], float *out_xyz, size_t *n_out) {
-  if (!ctx || !cloud || !leaf || !out_xyz || !n_out || !(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0))
+  return ope_voxel_grid_rgb(ctx, cloud, leaf, nullptr, out_xyz, nullptr, n_out);
+}
+
+extern "C" int ope_voxel_grid_rgb(ope_ctx *ctx, const ope_cloud *cloud, const float leaf[3], const uint32_t *rgb, float *out_xyz,
+                                  uint32_t *out_rgb, size_t *n_out) {
+  if (!ctx || !cloud || !leaf || !out_xyz || !n_out || !(leaf[0] > 0) || !(leaf[1] > 0) || !(leaf[2] > 0) || (rgb && !out_rgb))
     return set_err(ctx, OPE_EINVAL, "ope_voxel_grid: bad argument");
   *n_out = 0;
   const size_t n = cloud->n, nv = cloud->n_valid;
@@ -219,9 +232,13 @@ extern "C" int ope_voxel_grid(ope_ctx *ctx, const ope_cloud *cloud, const float 
   unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
   uint32_t *d_vals = nullptr, *d_vals2 = nullptr, *d_flags = nullptr, *d_slot = nullptr;
   float *d_out = nullptr;
+  uint32_t *d_rgb = nullptr, *d_out_rgb = nullptr;
   void *d_tmp = nullptr;
   uint32_t count = 0;
   hipError_t e = hipMalloc((void **)&d_keys, 8 * n);
+  if (e == hipSuccess && rgb) e = hipMalloc((void **)&d_rgb, 4 * n);
+  if (e == hipSuccess && rgb) e = hipMalloc((void **)&d_out_rgb, 4 * nv);
+  if (e == hipSuccess && rgb) e = hipMemcpyAsync(d_rgb, rgb, 4 * n, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMalloc((void **)&d_keys2, 8 * n);
   if (e == hipSuccess) e = hipMalloc((void **)&d_vals, 4 * n);
   if (e == hipSuccess) e = hipMalloc((void **)&d_vals2, 4 * n);
@@ -247,14 +264,15 @@ extern "C" int ope_voxel_grid(ope_ctx *ctx, const ope_cloud *cloud, const float 
     }
     if (e == hipSuccess) {
       hipLaunchKernelGGL(centroid_kernel, dim3(nb), dim3(256), 0, ctx->stream, cloud->view(), d_keys2, d_vals2, d_flags, d_slot,
-                         (uint32_t)nv, d_out);
+                         (uint32_t)nv, d_out, d_rgb, d_out_rgb);
       e = hipMemcpyAsync(&count, d_slot + n, 4, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && count) e = hipMemcpy(out_xyz, d_out, 12 * (size_t)count, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && count && rgb) e = hipMemcpy(out_rgb, d_out_rgb, 4 * (size_t)count, hipMemcpyDeviceToHost);
   }
   for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_vals, (void *)d_vals2, (void *)d_flags, (void *)d_slot, (void *)d_out,
-                  d_tmp})
+                  (void *)d_rgb, (void *)d_out_rgb, d_tmp})
     if (p) (void)hipFree(p);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_voxel_grid: ") + hipGetErrorString(e));
   *n_out = count;

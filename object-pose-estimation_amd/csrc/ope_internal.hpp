@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -153,6 +154,12 @@ struct ope_ctx {
   bool grid_auto = false;                 // the run may move between the grid and the tree kernel (ope_index_params.grid == 1)
   bool measuring_flag = false;   // plan_info[4] as last written (enqueue_accumulate)
   int force_plan_at = -1;                 // launch at which the tree kernel re-plans after taking over from the grid kernel
+  // far list of the tree kernel's launches (sampling.hip: far_plan)
+  uint32_t *d_fo_keys = nullptr, *d_fo_keys2 = nullptr, *d_fo_vals = nullptr, *d_far_list = nullptr;
+  unsigned char *d_far_class = nullptr;
+  void *d_fo_tmp = nullptr;
+  size_t fo_cap = 0, fo_tmp_bytes = 0;
+  bool far_valid = false;
   size_t corr_cap = 0;
   ope::IcpState *h_state = nullptr;  // pinned
   const ope_cloud *run_src = nullptr;   // cleared by ope_cloud_free / ope_index_free of the handle they point at
@@ -178,6 +185,7 @@ struct ope_ctx {
   unsigned long long *p2p_mine = nullptr;
   void *p2p_peer[ope::kP2pMaxRanks] = {};
   bool p2p_ok = false;
+  bool p2p_broken = false;       // an exchange timed out: the ranks' sequence numbers no longer agree; the communicator must be re-created
   int comm_transport = 0;        // OPE_COMM_AUTO / RCCL / P2P as requested
   uint32_t p2p_seq = 0;          // sequence number of the last exchange (never 0 in a slot)
   double *p2p_scratch = nullptr; // kP2pMaxSums doubles for the self-test
@@ -230,6 +238,7 @@ struct ope_index {
   uint32_t *d_cell_start = nullptr, *d_gpos = nullptr;
   ope::GridView grid{};
   bool has_grid = false, want_grid = false;
+  std::mutex grid_mutex;   // the lazy grid build (ensure_grid) may be reached from several contexts sharing the index
   int grid_mode = 1;   // ope_index_params.grid: 0 off, 1 automatic (falls back to the tree kernel on clutter-heavy sources), 2 always
   float grid_fill = 0.f;
   int grid_max_cells = 0;

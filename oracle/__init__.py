@@ -145,6 +145,7 @@ def _declare(L):
     L.orc_fitness.restype = C.c_double
     L.orc_fitness.argtypes = [_fp, C.c_int, _fp, C.c_int, _fp, C.c_double, C.POINTER(C.c_int)]
     L.orc_icp_partial_sums.argtypes = [_fp, C.c_int, C.c_void_p, _fp, _fp, C.c_double, _dp, _dp]
+    L.orc_icp_partial_sums_mt.argtypes = [_fp, C.c_int, C.c_void_p, _fp, _fp, C.c_double, _dp, C.c_int, _dp]
     L.orc_transform_points.argtypes = [_fp, C.c_int, _fp, _fp]
     L.orc_transform_normals.argtypes = [_fp, C.c_int, _fp, _fp]
     L.orc_normals_knn.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, _fp]
@@ -157,6 +158,8 @@ def _declare(L):
     L.orc_pass_through.argtypes = [_fp, C.c_int, _fp, _fp, _ip]
     L.orc_voxel_grid.restype = C.c_int
     L.orc_voxel_grid.argtypes = [_fp, C.c_int, _fp, _fp]
+    L.orc_voxel_grid_rgb.restype = C.c_int
+    L.orc_voxel_grid_rgb.argtypes = [_fp, C.c_void_p, C.c_int, _fp, _fp, C.c_void_p]
     L.orc_statistical_outlier_removal.restype = C.c_int
     L.orc_statistical_outlier_removal.argtypes = [_fp, C.c_int, C.c_int, C.c_double, _ip, _fp]
     L.orc_uniform_sampling.restype = C.c_int
@@ -328,13 +331,17 @@ def fitness(src, tgt, T, max_range: float = np.finfo(np.float64).max):
     return v, n.value
 
 
-def icp_partial_sums(src, tree: KdTree, T, max_corr_dist, pivot) -> np.ndarray:
+def icp_partial_sums(src, tree: KdTree, T, max_corr_dist, pivot, n_threads: int = 1) -> np.ndarray:
     src = _f32(src, 3)
     t = colmajor(T)
     pv = np.ascontiguousarray(pivot, np.float64)
     S = np.empty(17, np.float64)
-    lib().orc_icp_partial_sums(_p(src, _fp), len(src), tree.h, _p(tree.xyz, _fp), _p(t, _fp), max_corr_dist,
-                               _p(pv, _dp), _p(S, _dp))
+    if n_threads > 1:
+        lib().orc_icp_partial_sums_mt(_p(src, _fp), len(src), tree.h, _p(tree.xyz, _fp), _p(t, _fp), max_corr_dist,
+                                      _p(pv, _dp), int(n_threads), _p(S, _dp))
+    else:
+        lib().orc_icp_partial_sums(_p(src, _fp), len(src), tree.h, _p(tree.xyz, _fp), _p(t, _fp), max_corr_dist,
+                                   _p(pv, _dp), _p(S, _dp))
     return S
 
 
@@ -395,13 +402,20 @@ def pass_through(xyz, lo, hi) -> np.ndarray:
     return out[:n].copy()
 
 
-def voxel_grid(xyz, leaf):
-    """pcl::VoxelGrid centroids in ascending voxel index; None when PCL would refuse the leaf size."""
+def voxel_grid(xyz, leaf, rgb=None):
+    """pcl::VoxelGrid centroids in ascending voxel index; None when PCL would refuse the leaf size.
+    rgb (optional, n uint32: the bits of PointXYZRGB::rgb): also the per-voxel colours -> (centroids, colours)."""
     xyz = _f32(xyz, 3)
     lf = np.ascontiguousarray(np.broadcast_to(np.asarray(leaf, np.float32), (3,)))
     out = np.empty((max(len(xyz), 1), 3), np.float32)
-    n = lib().orc_voxel_grid(_p(xyz, _fp), len(xyz), _p(lf, _fp), _p(out, _fp))
-    return None if n < 0 else out[:n].copy()
+    if rgb is None:
+        n = lib().orc_voxel_grid(_p(xyz, _fp), len(xyz), _p(lf, _fp), _p(out, _fp))
+        return None if n < 0 else out[:n].copy()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint32)
+    assert rgb.shape == (len(xyz),)
+    oc = np.zeros(max(len(xyz), 1), np.uint32)
+    n = lib().orc_voxel_grid_rgb(_p(xyz, _fp), rgb.ctypes.data, len(xyz), _p(lf, _fp), _p(out, _fp), oc.ctypes.data)
+    return None if n < 0 else (out[:n].copy(), oc[:n].copy())
 
 
 def statistical_outlier_removal(xyz, mean_k: int = 30, stddev_mul: float = 1.0, return_distances: bool = False):

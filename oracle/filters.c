@@ -14,6 +14,7 @@
  */
 #include <float.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "ope_oracle.h"
@@ -58,7 +59,7 @@ static int vg_cmp(const void *a, const void *b) {
  * PCL sorts (voxel, point) pairs on the voxel index alone with std::sort, which leaves the order of the
  * float additions inside a voxel unspecified; it is fixed here to ascending input index.  The centroid is
  * sum * (1 / count): Eigen 3.2's operator/= on a float vector multiplies by the reciprocal. */
-int orc_voxel_grid(const float *xyz, int n, const float leaf[3], float *out_xyz) {
+static int voxel_grid_impl(const float *xyz, const uint32_t *rgb, int n, const float leaf[3], float *out_xyz, uint32_t *out_rgb) {
   float inv[3], mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int d = 0; d < 3; ++d) inv[d] = 1.0f / leaf[d];
   int any = 0;
@@ -93,14 +94,24 @@ int orc_voxel_grid(const float *xyz, int n, const float leaf[3], float *out_xyz)
   int cnt = 0;
   for (int i = 0; i < m;) {
     int j = i;
-    float c[3] = {0.f, 0.f, 0.f};
+    float c[3] = {0.f, 0.f, 0.f}, col[3] = {0.f, 0.f, 0.f};
     while (j < m && cv[j].key == cv[i].key) {
       const float *p = xyz + 3 * cv[j].idx;
       c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
+      if (rgb) {
+        /* voxel_grid.hpp, "RGB special case": the three channels of pcl::RGB (memory order b, g, r, a) enter the centroid
+         * vector as floats of their own and are averaged like every other field */
+        const uint32_t v = rgb[cv[j].idx];
+        col[0] += (float)((v >> 16) & 255u); col[1] += (float)((v >> 8) & 255u); col[2] += (float)(v & 255u);
+      }
       ++j;
     }
     const float r = 1.0f / (float)(j - i);
     out_xyz[3 * cnt] = c[0] * r; out_xyz[3 * cnt + 1] = c[1] * r; out_xyz[3 * cnt + 2] = c[2] * r;
+    if (rgb) {
+      /* "pack r/g/b into rgb": int rgb = (static_cast<int>(r) << 16) | (static_cast<int>(g) << 8) | static_cast<int>(b) */
+      out_rgb[cnt] = ((uint32_t)(int)(col[0] * r) << 16) | ((uint32_t)(int)(col[1] * r) << 8) | (uint32_t)(int)(col[2] * r);
+    }
     ++cnt;
     i = j;
   }
@@ -155,4 +166,15 @@ int orc_statistical_outlier_removal(const float *xyz, int n, int mean_k, double 
     for (int i = 0; i < n; ++i) out_dist[i] = dist[i];
   free(dist);
   return m;
+}
+
+int orc_voxel_grid(const float *xyz, int n, const float leaf[3], float *out_xyz) {
+  return voxel_grid_impl(xyz, NULL, n, leaf, out_xyz, NULL);
+}
+
+/* VoxelGrid<PointXYZRGB>::applyFilter with downsample_all_data_ = true, the default (ProcessingPcd::getDownSampled,
+ * BuildModel/src/processingpcd.cpp:44-59): besides xyz the packed colour is averaged channel by channel in float and
+ * re-packed by truncation, alpha byte 0.  rgb / out_rgb: the 32 bits of PointXYZRGB::rgb. */
+int orc_voxel_grid_rgb(const float *xyz, const uint32_t *rgb, int n, const float leaf[3], float *out_xyz, uint32_t *out_rgb) {
+  return voxel_grid_impl(xyz, rgb, n, leaf, out_xyz, out_rgb);
 }

@@ -20,6 +20,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -440,6 +441,37 @@ void orc_icp_partial_sums(const float *src_xyz, int ns, const orc_kdtree *tgt_tr
       for (int c = 0; c < 3; ++c) S[7 + 3 * r + c] += t[r] * s[c];
     S[16] += d;
   }
+}
+
+/* The same pass over `n_threads` contiguous slices of the source, one POSIX thread each, the slices' sums added in slice
+ * order ("also reported with all cores").  The kd-tree is read-only during a search. */
+typedef struct {
+  const float *src; int ns; const orc_kdtree *tree; const float *tgt; const float *T; double mcd; const double *pivot; double S[17];
+} ps_job;
+static void *ps_worker(void *arg) {
+  ps_job *j = (ps_job *)arg;
+  orc_icp_partial_sums(j->src, j->ns, j->tree, j->tgt, j->T, j->mcd, j->pivot, j->S);
+  return NULL;
+}
+void orc_icp_partial_sums_mt(const float *src_xyz, int ns, const orc_kdtree *tgt_tree, const float *tgt_xyz, const float T[16],
+                             double max_corr_dist, const double pivot[3], int n_threads, double S[17]) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 1024) n_threads = 1024;
+  ps_job *jobs = (ps_job *)calloc((size_t)n_threads, sizeof(ps_job));
+  pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+  char *started = (char *)calloc((size_t)n_threads, 1);
+  for (int t = 0; t < n_threads; ++t) {
+    const long long a = (long long)ns * t / n_threads, b = (long long)ns * (t + 1) / n_threads;
+    jobs[t] = (ps_job){src_xyz + 3 * a, (int)(b - a), tgt_tree, tgt_xyz, T, max_corr_dist, pivot, {0}};
+    started[t] = pthread_create(&th[t], NULL, ps_worker, &jobs[t]) == 0;
+    if (!started[t]) ps_worker(&jobs[t]);   /* could not start a thread: do the slice here */
+  }
+  for (int k = 0; k < 17; ++k) S[k] = 0;
+  for (int t = 0; t < n_threads; ++t) {
+    if (started[t]) pthread_join(th[t], NULL);
+    for (int k = 0; k < 17; ++k) S[k] += jobs[t].S[k];
+  }
+  free(jobs); free(th); free(started);
 }
 
 int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt_xyz, const float *tgt_nrm, int nt,

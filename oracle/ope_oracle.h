@@ -188,6 +188,9 @@ double orc_fitness(const float *src_xyz, int ns, const float *tgt_xyz, int nt,
 void orc_icp_partial_sums(const float *src_xyz, int ns, const orc_kdtree *tgt_tree,
                           const float *tgt_xyz, const float T[16], double max_corr_dist,
                           const double pivot[3], double S[17]);
+/* the same over n_threads contiguous slices of the source, one thread each (the all-core CPU figure of bench.py) */
+void orc_icp_partial_sums_mt(const float *src_xyz, int ns, const orc_kdtree *tgt_tree, const float *tgt_xyz, const float T[16],
+                             double max_corr_dist, const double pivot[3], int n_threads, double S[17]);
 
 /* pcl::transformPointCloud (float math): out = R*p + t; non-finite points
  * are copied through unchanged (icp_mod.hpp:71-72,104-105). */
@@ -223,6 +226,8 @@ int orc_uniform_sampling(const float *xyz, int n, float leaf, int32_t *out_idx);
 int orc_remove_nan(const float *xyz, int n, int32_t *out_idx);
 int orc_pass_through(const float *xyz, int n, const float lo[3], const float hi[3], int32_t *out_idx);
 int orc_voxel_grid(const float *xyz, int n, const float leaf[3], float *out_xyz);
+/* the same with the packed colour of PointXYZRGB carried (channel-wise float mean, truncated; processingpcd.cpp:44-59) */
+int orc_voxel_grid_rgb(const float *xyz, const uint32_t *rgb, int n, const float leaf[3], float *out_xyz, uint32_t *out_rgb);
 /* pcl::StatisticalOutlierRemoval (ProcessingPcd::getOutlierRemove, processingpcd.cpp:62-77: setMeanK(30),
  * setStddevMulThresh(threshold)): indices of the inliers in input order; out_dist (optional) the per-point mean distance. */
 int orc_statistical_outlier_removal(const float *xyz, int n, int mean_k, double stddev_mul, int32_t *out_idx, float *out_dist);

@@ -253,6 +253,21 @@ def test_voxel_grid_equals_oracle(ctx, n, leaf):
     np.testing.assert_array_equal(got, want)      # same voxel order, same float additions in the same order
 
 
+@pytest.mark.parametrize("n,leaf", [(1, 0.01), (5000, 0.05), (200_000, 0.01)])
+def test_voxel_grid_with_colours_equals_oracle(ctx, n, leaf):
+    """VoxelGrid<PointXYZRGB> as ProcessingPcd::getDownSampled runs it (BuildModel processingpcd.cpp:44-59): channel-wise
+    float mean of the packed colours, truncated, alpha 0; centroids unchanged by the colour channel."""
+    x = _cloud_with_holes(n, 11 * n + 3)
+    rgb = np.random.default_rng(n).integers(0, 2 ** 32, n, dtype=np.uint32)   # alpha byte set on purpose: it must come out 0
+    c = ctx.upload(x)
+    got_xyz, got_rgb = ctx.voxel_grid(c, leaf, rgb)
+    want_xyz, want_rgb = oracle.voxel_grid(x, leaf, rgb)
+    np.testing.assert_array_equal(got_xyz, want_xyz)
+    np.testing.assert_array_equal(got_rgb, want_rgb)
+    np.testing.assert_array_equal(got_xyz, ctx.voxel_grid(c, leaf))
+    assert (got_rgb >> 24 == 0).all()
+
+
 def test_voxel_grid_on_model_surface_and_refused_leaf(ctx):
     ope = load_pkg()
     m = synth.model_surface(100_000, 1)

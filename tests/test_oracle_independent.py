@@ -332,3 +332,36 @@ def test_normal_shooting_and_rejector_against_numpy_scipy():
     Rm = U @ D @ Vt
     T = np.eye(4); T[:3, :3] = Rm; T[:3, 3] = cb - Rm @ ca
     assert np.abs(out.T.astype(np.float64) - T).max() < 2e-5
+
+
+def test_voxel_grid_colours_against_a_dictionary_of_voxels():
+    """VoxelGrid<PointXYZRGB> (BuildModel processingpcd.cpp:44-59) restated with a python dictionary: voxel index from
+    floor(x / leaf) - min_b, centroid = float sum * (1 / count), colour = channel-wise float mean truncated, alpha 0."""
+    rng = np.random.default_rng(3)
+    x = (rng.random((4000, 3), dtype=np.float32) * np.float32(0.2) - np.float32(0.05)).astype(np.float32)
+    x[::97] = np.nan
+    rgb = rng.integers(0, 2 ** 32, len(x), dtype=np.uint32)
+    leaf = np.float32(0.013)
+    inv = np.float32(1.0) / leaf
+    fin = np.isfinite(x).all(1)
+    mn, mx = x[fin].min(0), x[fin].max(0)
+    min_b = np.floor(mn * inv).astype(np.int64)
+    div_b = np.floor(mx * inv).astype(np.int64) - min_b + 1
+    vox = {}
+    for i in np.nonzero(fin)[0]:
+        ijk = (np.floor(x[i] * inv) - min_b.astype(np.float32)).astype(np.int64)
+        vox.setdefault(int(ijk[0] + ijk[1] * div_b[0] + ijk[2] * div_b[0] * div_b[1]), []).append(i)
+    want_xyz, want_rgb = [], []
+    for key in sorted(vox):
+        acc = np.zeros(3, np.float32); col = np.zeros(3, np.float32)
+        for i in vox[key]:
+            acc = acc + x[i]
+            v = int(rgb[i])
+            col = col + np.array([(v >> 16) & 255, (v >> 8) & 255, v & 255], np.float32)
+        r = np.float32(1.0) / np.float32(len(vox[key]))
+        want_xyz.append(acc * r)
+        c = (col * r).astype(np.int64)
+        want_rgb.append((int(c[0]) << 16) | (int(c[1]) << 8) | int(c[2]))
+    got_xyz, got_rgb = oracle.voxel_grid(x, float(leaf), rgb)
+    np.testing.assert_array_equal(got_xyz, np.array(want_xyz, np.float32))
+    np.testing.assert_array_equal(got_rgb, np.array(want_rgb, np.uint32))
