@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OPE_ABI_VERSION 2
+#define OPE_ABI_VERSION 3
 
 enum {
   OPE_OK = 0,
@@ -182,7 +182,13 @@ typedef struct {
    * cost-sorted schedule, no grid kernel: both follow measured times): bit-reproducible from run to run on one GPU model,
    * at the price of the schedule (launches that fill the GPU take longer). */
   int deterministic_sums;
+  /* Which walk the OBB-tree kernel uses for the 64-query chunks of a 1-NN run.  OPE_WALK_AUTO (0, default): launches that
+   * fill the GPU take one packet walk per coherent chunk and private per-lane walks for the rest, smaller launches
+   * per-lane walks only.  OPE_WALK_LANE (1) / OPE_WALK_PACKET (2) force the instantiation (every walk is exact: the choice
+   * moves time, and lets a test pin each kernel by name, see ope_icp_kernel_launches). */
+  int tree_walk;
 } ope_icp_params;
+enum { OPE_WALK_AUTO = 0, OPE_WALK_LANE = 1, OPE_WALK_PACKET = 2 };
 
 typedef struct {
   int iterations;        /* nr_iterations_ */
@@ -195,6 +201,12 @@ typedef struct {
 } ope_icp_result;
 
 void ope_icp_default_params(ope_icp_params *p);
+
+/* How many accumulate launches of the current (or last) run each search kernel served: the bucketed grid kernel, the
+ * OBB-tree kernel in its per-lane and in its packet instantiation, the k-NN (normal shooting) kernel.  A run may move
+ * between kernels (ope_index_params.grid = 1); tests use this to assert which kernel their comparison exercised. */
+enum { OPE_KERNEL_GRID = 0, OPE_KERNEL_TREE_LANE = 1, OPE_KERNEL_TREE_PACKET = 2, OPE_KERNEL_KNN = 3, OPE_KERNEL_KINDS = 4 };
+int ope_icp_kernel_launches(const ope_ctx *ctx, int64_t counts[OPE_KERNEL_KINDS]);
 
 /* Registration::align(output, guess) -> IterativeClosestPoint::computeTransformation
  * (registration_mod.hpp:176-219, icp_mod.hpp:119-272).  guess may be NULL (identity).

@@ -67,6 +67,7 @@ class IcpParams(C.Structure):
         ("check_every", C.c_int),
         ("estimator", C.c_int),
         ("deterministic_sums", C.c_int),
+        ("tree_walk", C.c_int),
     ]
 
 
@@ -143,6 +144,7 @@ ABI = [
     ("ope_icp_current_transform", C.c_int, [_vp, _fp]),
     ("ope_icp_end", C.c_int, [_vp, _fp, C.POINTER(IcpResult)]),
     ("ope_icp_set_global_sizes", C.c_int, [_vp, C.c_int64, C.c_int64]),
+    ("ope_icp_kernel_launches", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("ope_icp_correspondences", C.c_int, [_vp, _ip, _ip, _fp, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ope_icp_last_incremental", C.c_int, [_vp, _fp]),
     ("ope_reject_pairs", C.c_int, [_vp, C.c_int, _fp, _fp, C.c_size_t, C.c_double, C.POINTER(C.c_ubyte)]),
@@ -405,6 +407,12 @@ class Context:
         r = IcpResult()
         self._chk(lib().ope_icp_end(self.h, _p(T, _fp), C.byref(r)))
         return IcpOut(from_colmajor(T), r.iterations, bool(r.converged), r.state, r.last_mse, r.n_corr, r.align_strength)
+
+    def icp_kernel_launches(self) -> dict:
+        """Accumulate launches of the current / last run per search kernel: {'grid', 'tree_lane', 'tree_packet', 'knn'}."""
+        c = (C.c_int64 * 4)()
+        self._chk(lib().ope_icp_kernel_launches(self.h, c))
+        return dict(zip(("grid", "tree_lane", "tree_packet", "knn"), (int(v) for v in c)))
 
     def icp_set_global_sizes(self, n_src_total: int, n_tgt_total: int):
         self._chk(lib().ope_icp_set_global_sizes(self.h, n_src_total, n_tgt_total))

@@ -15,12 +15,8 @@ namespace ope {
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
-                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, const uint32_t *, const unsigned char *);
-size_t far_plan_tmp_bytes(uint32_t);
-int far_plan(hipStream_t, const float *, const uint32_t *, uint32_t, float, int, unsigned char *, uint32_t *, uint32_t *, uint32_t *, uint32_t *, uint32_t *,
-             void *, size_t);
-void far_chunk_keys(hipStream_t, const uint32_t *, uint32_t, uint32_t, const uint32_t *, uint32_t *);
-void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *, uint32_t);
+                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *);
+void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
 void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
 extern bool g_plan_no_alone;
@@ -151,7 +147,6 @@ static int grid_probe_poll(ope_ctx *ctx, int it_done) {
 static int switch_kernel(ope_ctx *ctx, bool to_grid, int it_done, uint32_t nch) {
   ctx->use_grid = to_grid;
   ctx->plan_valid = false;   // chunk ids mean something else to the other kernel
-  ctx->far_valid = false;    // (plan_info[1] is the grid kernel's query count while that kernel runs)
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * (size_t)(nch + 1), ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 8, 0, 8, ctx->stream));
   if (to_grid) {
@@ -209,6 +204,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     }
     const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
     if (timed) OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], ctx->stream));
+    ++ctx->kernel_launches[OPE_KERNEL_GRID];
     launch_icp_accumulate_grid(ctx->stream, ctx->acc_blocks, nrm, ctx->run_src->view(), ctx->run_tgt->view(), ctx->run_tgt->grid, ctx->d_state,
                                ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_hint, ctx->d_ghint, ctx->d_qorder, ctx->d_qclass,
                                ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8,
@@ -225,33 +221,8 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     --ctx->acc_launches;
     return enqueue_accumulate(ctx, atomic_sums);
   }
-  // far list (developer experiment for now): see far_plan, sampling.hip
-  static const bool far_env = dev_env("OPE_FAR") != nullptr;
-  static const float far_thr = [] { const char *e = dev_env("OPE_FAR_THR"); return e ? (float)atof(e) : 0.0025f; }();
-  const bool far_on = far_env && !no_plan && nch > 1 && ctx->run_params.corr_mode == OPE_CORR_NEAREST && !ctx->run_params.use_reciprocal &&
-                      ctx->run_tgt->d_axis2 != nullptr;
   if (!no_plan && nch > 1 && it_done >= 1 &&
       (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0 || it_done == ctx->force_plan_at)) {
-    if (far_on) {
-      const uint32_t nv = (uint32_t)ctx->run_src->n_valid;
-      if (ctx->fo_cap < nv) {
-        for (void *q : {(void *)ctx->d_fo_keys, (void *)ctx->d_fo_keys2, (void *)ctx->d_fo_vals, (void *)ctx->d_far_list, (void *)ctx->d_far_class, ctx->d_fo_tmp})
-          if (q) (void)hipFree(q);
-        ctx->d_fo_keys = ctx->d_fo_keys2 = ctx->d_fo_vals = ctx->d_far_list = nullptr; ctx->d_far_class = nullptr; ctx->d_fo_tmp = nullptr; ctx->fo_cap = 0;
-        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_fo_keys, 4 * (size_t)nv));
-        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_fo_keys2, 4 * (size_t)nv));
-        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_fo_vals, 4 * (size_t)nv));
-        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_far_list, 4 * (size_t)nv));
-        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_far_class, (size_t)nv));
-        ctx->fo_tmp_bytes = far_plan_tmp_bytes(nv);
-        OPE_HIP(ctx, hipMalloc(&ctx->d_fo_tmp, ctx->fo_tmp_bytes));
-        ctx->fo_cap = nv;
-      }
-      if (far_plan(ctx->stream, ctx->d_corr_d2, ctx->d_hint, nv, far_thr * far_thr, ctx->run_tgt->depth, ctx->d_far_class, ctx->d_fo_keys, ctx->d_fo_keys2,
-                   ctx->d_fo_vals, ctx->d_far_list, ctx->d_work_counter + 8, ctx->d_fo_tmp, ctx->fo_tmp_bytes) != 0)
-        return set_err(ctx, OPE_EHIP, "far plan sort failed");
-      ctx->far_valid = true;
-    }
     if (ctx->grid_auto && it_done >= 8) {
       const int rcp = grid_probe_issue(ctx);
       if (rcp != OPE_OK) return rcp;
@@ -273,20 +244,13 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     // (rocPRIM sorts these few keys with a block sort and four or five merge launches, ~40 us; a one-block
     // rocprim::block_radix_sort of the 15 625 keys took 63 us on its single CU: measured, not kept)
     size_t tb = ctx->plan_tmp_bytes;
-    // with a far list the plan covers the Morton chunks 0 .. nch-1 and the far chunks nch .. (at most as many again)
-    const uint32_t nch_plan = ctx->far_valid ? 2u * nch : nch;
-    const uint32_t *plan_keys = ctx->d_chunk_cost;
-    if (ctx->far_valid) {
-      far_chunk_keys(ctx->stream, ctx->d_chunk_cost, nch, nch_plan, ctx->d_work_counter + 8, ctx->d_chunk_keys);
-      plan_keys = ctx->d_chunk_keys;
-    }
-    if (chunk_plan(ctx->stream, plan_keys, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch_plan, ctx->d_plan_tmp, tb) != 0)
+    if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch, ctx->d_plan_tmp, tb) != 0)
       return set_err(ctx, OPE_EHIP, "chunk plan sort failed");
-    plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch_plan, heavy_factor, load_factor, (uint32_t)ctx->acc_blocks * (kAccBlock / 64),
-               ctx->d_work_counter + 8, ctx->far_valid ? nch : 0u);
+    plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch, heavy_factor, load_factor, (uint32_t)ctx->acc_blocks * (kAccBlock / 64),
+               ctx->d_work_counter + 8);
     static const bool no_slot_list = dev_env("OPE_NO_SLOT_LIST") != nullptr;  // developer A/B switch
     ctx->slot_list_valid = !no_slot_list && ctx->run_params.corr_mode == OPE_CORR_NEAREST && !ctx->run_params.use_reciprocal;
-    if (ctx->slot_list_valid) plan_slots(ctx->stream, ctx->d_chunk_cost_sorted, nch_plan, ctx->d_work_counter + 8, ctx->d_slot_list);
+    if (ctx->slot_list_valid) plan_slots(ctx->stream, ctx->d_chunk_cost_sorted, nch, ctx->d_work_counter + 8, ctx->d_slot_list);
     ctx->plan_valid = true;
   }
   const ope_icp_params &p = ctx->run_params;
@@ -300,12 +264,13 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   static const bool no_packet = dev_env("OPE_NO_PACKET") != nullptr;  // developer A/B switch
   static const int packet_min_env = [] { const char *e = dev_env("OPE_PACKET_MIN_CHUNKS"); return e ? atoi(e) : -1; }();  // developer sweep
   const uint32_t packet_min = packet_min_env >= 0 ? (uint32_t)packet_min_env : (uint32_t)ctx->n_cu * 4u * (uint32_t)kAccWavesPerSimd;
-  const bool packet = !no_packet && nch > packet_min;
+  const bool packet = p.tree_walk == OPE_WALK_PACKET ? (ctx->run_tgt->d_axis2 != nullptr && p.corr_mode == OPE_CORR_NEAREST && !recip)
+                      : p.tree_walk == OPE_WALK_LANE ? false : (!no_packet && nch > packet_min);
+  ++ctx->kernel_launches[p.corr_mode != OPE_CORR_NEAREST ? OPE_KERNEL_KNN : (packet && !recip) ? OPE_KERNEL_TREE_PACKET : OPE_KERNEL_TREE_LANE];
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
                         recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
                         ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr,
-                        (ctx->plan_valid && ctx->slot_list_valid) ? ctx->d_slot_list : nullptr, ctx->far_valid ? ctx->d_far_list : nullptr,
-                        ctx->far_valid ? ctx->d_far_class : nullptr);
+                        (ctx->plan_valid && ctx->slot_list_valid) ? ctx->d_slot_list : nullptr);
   if (timed) {
     OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
     ++ctx->prof_used;
@@ -376,8 +341,6 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->h_grid_probe) (void)hipHostFree(ctx->h_grid_probe);
   for (void *p : {(void *)ctx->d_chunk_cost, (void *)ctx->d_chunk_cost_sorted, (void *)ctx->d_chunk_ids,
                   (void *)ctx->d_chunk_order, (void *)ctx->d_slot_list, ctx->d_plan_tmp})
-    if (p) (void)hipFree(p);
-  for (void *p : {(void *)ctx->d_fo_keys, (void *)ctx->d_fo_keys2, (void *)ctx->d_fo_vals, (void *)ctx->d_far_list, (void *)ctx->d_far_class, ctx->d_fo_tmp})
     if (p) (void)hipFree(p);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->h_state) (void)hipHostFree(ctx->h_state);
@@ -776,6 +739,13 @@ void ope_icp_default_params(ope_icp_params *p) {
   p->check_every = 10;
   p->estimator = OPE_EST_SVD;
   p->deterministic_sums = 0;
+  p->tree_walk = OPE_WALK_AUTO;
+}
+
+int ope_icp_kernel_launches(const ope_ctx *ctx, int64_t counts[OPE_KERNEL_KINDS]) {
+  if (!ctx || !counts) return OPE_EINVAL;
+  for (int k = 0; k < OPE_KERNEL_KINDS; ++k) counts[k] = ctx->kernel_launches[k];
+  return OPE_OK;
 }
 
 int ope_icp_set_global_sizes(ope_ctx *ctx, int64_t n_src_total, int64_t n_tgt_total) {
@@ -830,6 +800,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   if (need_src_nrm && !src->d_nrm) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: source normals required but absent");
   if (p.estimator != OPE_EST_SVD && p.estimator != OPE_EST_POINT_TO_PLANE_LLS && p.estimator != OPE_EST_POINT_TO_PLANE_LM)
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown estimator");
+  if (p.tree_walk < OPE_WALK_AUTO || p.tree_walk > OPE_WALK_PACKET) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown tree_walk");
   if ((p.estimator == OPE_EST_POINT_TO_PLANE_LLS || p.estimator == OPE_EST_POINT_TO_PLANE_LM) && !tgt->d_nrm)
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: the point-to-plane estimator needs target normals (build the index from a cloud with normals)");
   if (p.use_surface_normal_rej && !tgt->d_nrm)
@@ -893,7 +864,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   // every slot starts as "no correspondence" (non-finite points never get written)
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_corr_match, 0xff, sizeof(int32_t) * std::max<size_t>(src->n, 1), ctx->stream));
   {
-    const size_t nch = 2 * ((src->n_valid + 63) / 64 + 1);   // Morton chunks + as many far chunks at most
+    const size_t nch = (src->n_valid + 63) / 64 + 1;
     if (ctx->chunk_cap < nch) {
       for (void *p : {(void *)ctx->d_chunk_cost, (void *)ctx->d_chunk_cost_sorted, (void *)ctx->d_chunk_ids,
                       (void *)ctx->d_chunk_order, ctx->d_plan_tmp})
@@ -923,8 +894,8 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * nch, ctx->stream));
     ctx->plan_valid = false;
     ctx->slot_list_valid = false;
-    ctx->far_valid = false;
     ctx->acc_launches = 0;
+    for (int64_t &k : ctx->kernel_launches) k = 0;
   }
   // no start hints yet: the first iteration walks top-down (hints belong to one (src, tgt) pairing)
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_hint, 0, sizeof(uint32_t) * std::max<size_t>(src->n, 1), ctx->stream));
@@ -997,7 +968,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     // ... but never more blocks than the GPU holds at once: the surplus would start when the first blocks end
     const bool nrm = p.use_surface_normal_rej || p.use_self_occluded_rej || p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
     const uint32_t nch0 = (uint32_t)((src->n_valid + 63) / 64);
-    const bool packet = nch0 > (uint32_t)ctx->n_cu * 4u * (uint32_t)kAccWavesPerSimd;
+    const bool packet = p.tree_walk == OPE_WALK_PACKET ? true : p.tree_walk == OPE_WALK_LANE ? false : nch0 > (uint32_t)ctx->n_cu * 4u * (uint32_t)kAccWavesPerSimd;
     const int per_cu = icp_accumulate_blocks_per_cu(nrm, packet, tgt->has_grid && tgt->grid_mode == 2);
     if (per_cu > 0) ctx->acc_blocks = std::min(ctx->acc_blocks, per_cu * ctx->n_cu);
   }

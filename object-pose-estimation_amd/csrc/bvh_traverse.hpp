@@ -126,6 +126,35 @@ __device__ __forceinline__ void bvh_walk(const BvhView &t, float qx, float qy, f
   for (;;) {
     if (node_done) {
       node_done = false;
+#ifdef OPE_STEP2
+    } else if (node < (leaf0 >> 1)) {
+      // two levels per trip: the four grandchildren (192 contiguous bytes) instead of the two children — a descent that
+      // dies after one or two levels (most do) costs one dependent trip instead of two; the bound of a child is the
+      // smaller of its two children's bounds (tighter than its own box)
+      v.on_node();
+      const float4 *o = t.nodes + 12 * (size_t)node;
+      const v4f a0 = ld16(o), a1 = ld16(o + 1), a2 = ld16(o + 2), b0 = ld16(o + 3), b1 = ld16(o + 4), b2 = ld16(o + 5);
+      const v4f e0 = ld16(o + 6), e1 = ld16(o + 7), e2 = ld16(o + 8), f0 = ld16(o + 9), f1 = ld16(o + 10), f2 = ld16(o + 11);
+      const float d00 = obb_dist2(a0, a1, a2, qx, qy, qz), d01 = obb_dist2(b0, b1, b2, qx, qy, qz);
+      const float d10 = obb_dist2(e0, e1, e2, qx, qy, qz), d11 = obb_dist2(f0, f1, f2, qx, qy, qz);
+      const float lb0 = fminf(d00, d01), lb1 = fminf(d10, d11);
+      const bool go1 = lb1 < lb0;
+      const float cn = go1 ? lb1 : lb0, cf = go1 ? lb0 : lb1;
+      if (!v.prune(cn)) {
+        const uint32_t child = 2 * node + (go1 ? 1u : 0u);
+        const bool pc = !v.prune(cf);
+        trail = (trail << 1) | (pc ? 1u : 0u);
+        if (pc) { stk[(31 - __clz(child)) * stk_stride] = cf; minb = fminf(minb, cf); }
+        const float g0 = go1 ? d10 : d00, g1 = go1 ? d11 : d01;
+        const bool right = g1 < g0;
+        const float gf = right ? g0 : g1;
+        node = 2 * child + (right ? 1u : 0u);
+        const bool pg = !v.prune(gf);
+        trail = (trail << 1) | (pg ? 1u : 0u);
+        if (pg) { stk[(31 - __clz(node)) * stk_stride] = gf; minb = fminf(minb, gf); }
+        continue;
+      }
+#endif
     } else if (node < leaf0) {
       v.on_node();
       v4f c0, c1, c2, c3, c4, c5;
@@ -359,46 +388,23 @@ __device__ __forceinline__ void packet_scan_leaf(const BvhView &t, uint32_t node
   else scan_leaf_uniform_once(t, node, qx, qy, qz, v);
 }
 
-// force: the chunk is a piece of the far list (queries sorted by start leaf): it takes the packet walk whatever its
-// number of distinct start leaves — the first kPacketMaxLeaves are scanned by everybody, a lane whose own start leaf is
-// not among them scans it privately (1-NN visitors; a point seen twice changes nothing), and a lane without a start
-// leaf simply starts from its initial bound.
 template <class Visitor>
 __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, float qy, float qz, bool active, Visitor &v,
-                                                    uint32_t hint, float *stk, int stk_stride, bool force = false, PacketStats *ps = nullptr) {
+                                                    uint32_t hint, float *stk, int stk_stride, PacketStats *ps = nullptr) {
   const uint32_t leaf0 = 1u << t.depth;
   const int D = t.depth;
   const unsigned long long act = __ballot(active);
-  if (t.axis2 == nullptr || act == 0ull) return false;
-  if (!force && __ballot(active && hint == 0u) != 0ull) return false;
+  if (t.axis2 == nullptr || act == 0ull || __ballot(active && hint == 0u) != 0ull) return false;
   // the distinct start leaves, scanned by every lane
   uint32_t seen[kPacketMaxLeaves];
   int nd = 0;
-  unsigned long long todo = __ballot(active && hint != 0u);
-  if (todo == 0ull) return false;
+  unsigned long long todo = act;
   while (todo != 0ull) {
-    if (nd == kPacketMaxLeaves) {
-      if (!force) return false;
-      break;
-    }
+    if (nd == kPacketMaxLeaves) return false;
     const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)hint, (int)__builtin_ctzll(todo));
     packet_scan_leaf(t, L, qx, qy, qz, v);
     todo &= ~__ballot(hint == L);
     seen[nd++] = L;
-  }
-  if constexpr (leaf_rescan_is_harmless<Visitor>::value) {
-    if (todo != 0ull) {
-      // lanes whose start leaf was not among the shared ones: their own leaf, privately (divergent gathers, a few lanes)
-      if ((todo >> (threadIdx.x & 63u)) & 1ull) {
-        const uint32_t j = hint - leaf0;
-        const uint32_t s = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
-        const uint32_t e = (uint32_t)(((unsigned long long)(j + 1) * t.n) >> t.depth);
-        for (uint32_t i = s; i < e; ++i) {
-          const v4f p = ld16(t.pts + i);
-          v.point(sq_dist3(__fsub_rn(qx, p.x), __fsub_rn(qy, p.y), __fsub_rn(qz, p.z)), p, i, hint);
-        }
-      }
-    }
   }
   // per-lane bounds of the first leaf's ancestor siblings (that leaf plus those D subtrees cover the tree), two
   // scalar fetches (24 SGPRs) in flight, parked like the per-lane walk parks them

@@ -99,8 +99,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
-    const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list,
-    const uint32_t *__restrict__ far_list, const unsigned char *__restrict__ far_class) {
+    const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list) {
   if (st->done) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
@@ -150,15 +149,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   // by 8-lane groups (bvh_traverse_oct); all other chunks take one slot and one lane per query.
   const uint32_t n_waves = gridDim.x * (BLOCK / 64);
   const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-  // Far class (far_plan, sampling.hip): queries whose previous match is further away than a few leaf widths (clutter) are
-  // taken out of their Morton chunks (far_class[i] = 1: the lane sits out) and served from far_list, which holds them
-  // sorted by the leaf of their previous match: queries that share a start leaf walk nearly the same nodes wherever they
-  // are themselves, so each 64-entry piece of that list is ONE packet walk — where the Morton neighbours of a clutter point
-  // start from dozens of leaves and take 64 private walks of 50-100 dependent trips.  Far chunks have the ids
-  // n_near_chunks + f; both kinds are costed and scheduled alike.  The split moves work between lanes, never a result.
-  const uint32_t n_near_chunks = (src.n_valid + 63u) / 64u;
-  const uint32_t n_far = (OCT_OK && far_list != nullptr) ? min(plan_info[1], src.n_valid) : 0u;
-  const uint32_t n_chunks = n_near_chunks + (n_far + 63u) / 64u;
+  const uint32_t n_chunks = (src.n_valid + 63u) / 64u;
   // plan_info[4] != 0: a measuring launch (the one before a plan step) — every chunk takes the per-lane walk, so that the
   // costs the plan sorts are all of one kind and none is older than one launch
   const bool measuring = chunk_order && plan_info[4] != 0u;
@@ -200,25 +191,11 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       ord = e & 0x0fffffffu;
     }
     const uint32_t chunk = chunk_order ? chunk_order[ord] : ord;
-    if (chunk >= n_chunks) continue;   // (a far chunk of an earlier plan that no longer exists)
-    const bool far_chunk = chunk >= n_near_chunks;
-    const uint32_t base = (far_chunk ? chunk - n_near_chunks : chunk) * 64u;
+    const uint32_t base = chunk * 64u;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-    const uint32_t qpos = oct ? (base + sub * 8u + (lane_id >> 3)) : (base + lane_id);
-    uint32_t i;
-    bool active;
-    if (far_chunk) {
-      active = qpos < n_far;
-      i = far_list[active ? qpos : base];
-    } else {
-      i = min(qpos, src.n_valid - 1u);
-      active = qpos < src.n_valid && !(n_far != 0u && far_class[i] != 0);
-    }
+    const uint32_t i = oct ? (base + sub * 8u + (lane_id >> 3)) : (base + lane_id);
+    const bool active = i < src.n_valid;
     const bool owner = active && (!oct || (lane_id & 7u) == 0u);  // the one lane that reports a query
-    if (n_far != 0u && __ballot(active) == 0ull) {   // a Morton chunk whose queries are all served from the far list
-      if (lane_id == 0 && !oct) chunk_cost[chunk] = 0u;
-      continue;
-    }
     // (the pointer keeps its LDS address space: through a generic pointer these became flat_loads, which take the
     // vector-memory path and wait on both counters)
     lds_cfloat_ptr cst = (lds_cfloat_ptr)s_const;
@@ -226,13 +203,13 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     float F[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) F[k] = cst[k];
-    const float4 s = src.xyzw[i];
+    const float4 s = src.xyzw[active ? i : base];
     const float x = xform_row(F + 0, s.x, s.y, s.z);
     const float y = xform_row(F + 4, s.x, s.y, s.z);
     const float z = xform_row(F + 8, s.x, s.y, s.z);
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (NRM && src.nrm != nullptr) {
-      const float4 n4 = src.nrm[i];
+      const float4 n4 = src.nrm[active ? i : base];
       nx = rot_row(F + 0, n4.x, n4.y, n4.z);
       ny = rot_row(F + 4, n4.x, n4.y, n4.z);
       nz = rot_row(F + 8, n4.x, n4.y, n4.z);
@@ -258,13 +235,13 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
         // (PACKET instantiation: launches that fill the GPU); everything else the per-lane walk from its own leaf
 #ifdef OPE_DEVELOPER
         PacketStats pst{0, 0, 0};
-        const bool done = PACKET && bvh_traverse_packet(tgt, x, y, z, active, v, h, stk, BLOCK, far_chunk, &pst);
+        const bool done = PACKET && bvh_traverse_packet(tgt, x, y, z, active, v, h, stk, BLOCK, &pst);
         if (g_chunk_stats && lane_id == 0) {
           uint32_t *o = g_chunk_stats + 4 * (size_t)chunk;
           o[0] = done ? 1u : 0u; o[1] = pst.steps; o[2] = pst.leaves; o[3] = pst.backups;
         }
 #else
-        const bool done = PACKET && bvh_traverse_packet(tgt, x, y, z, active, v, h, stk, BLOCK, far_chunk);
+        const bool done = PACKET && bvh_traverse_packet(tgt, x, y, z, active, v, h, stk, BLOCK);
 #endif
         if (!done && active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, h);
       }
@@ -567,7 +544,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
       // scalar cache, everything else the per-lane walk (icp_accumulate_kernel)
       const uint32_t h = need_tree ? hint[i] : 0u;
       NearestVisitor v{need_tree ? (gpos != kNoPos ? nextafterf(best, INFINITY) : best) : -INFINITY, kNoPos, 0};
-      const bool done = tree_part && bvh_traverse_packet(tgt, x, y, z, need_tree, v, h, stk, BLOCK, false);
+      const bool done = tree_part && bvh_traverse_packet(tgt, x, y, z, need_tree, v, h, stk, BLOCK);
       if (!done && need_tree) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, h);
       if (need_tree) {
         if (v.pos != kNoPos) { best = v.best; gpos = grid.gpos_of_bvhpos[v.pos]; }
@@ -1283,18 +1260,17 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
                            const BvhView &tgt, const BvhView &srcix, const IcpState *st, double *partials,
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
                            const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
-                           int k_normal_shooting, double *S_atomic, const uint32_t *slot_list, const uint32_t *far_list,
-                           const unsigned char *far_class) {
+                           int k_normal_shooting, double *S_atomic, const uint32_t *slot_list) {
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS)                                                                       \
   hipLaunchKernelGGL((icp_accumulate_kernel<M, N, R>), dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, \
-                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, far_list, far_class)
+                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list)
   if (mode == 0 && !recip && packet) {
     if (nrm)
       hipLaunchKernelGGL((icp_accumulate_kernel<0, true, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, far_list, far_class);
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list);
     else
       hipLaunchKernelGGL((icp_accumulate_kernel<0, false, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, far_list, far_class);
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list);
     return;
   }
   if (mode == 0) {
@@ -1306,7 +1282,7 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
     // register list takes ~0.5 ms, and held the kernel at two waves per SIMD
 #define OPE_LAUNCH_NS(KR)                                                                                                          \
   hipLaunchKernelGGL((icp_accumulate_kernel<2, true, false, false, KR>), dim3(nblocks), dim3(kKnnBlock), 0, stream, src, tgt, srcix, st, \
-                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, far_list, far_class)
+                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list)
     const int k = k_normal_shooting;
     if (k == 10) OPE_LAUNCH_NS(10);
     else if (k <= 4) OPE_LAUNCH_NS(4);

@@ -138,6 +138,7 @@ struct ope_ctx {
   size_t plan_tmp_bytes = 0, chunk_cap = 0;
   bool plan_valid = false;
   int acc_launches = 0;
+  int64_t kernel_launches[OPE_KERNEL_KINDS] = {0, 0, 0, 0};   // per search kernel, this run (ope_icp_kernel_launches)
   uint32_t *d_hint = nullptr;       // per sorted query: leaf (heap id) of the previous iteration's match, 0 = none
   // grid path of the 1-NN search (icp_accumulate_grid_kernel)
   uint32_t *d_ghint = nullptr;      // per sorted query: 1 + position of the previous match in the grid-sorted points, 0 = none
@@ -154,12 +155,6 @@ struct ope_ctx {
   bool grid_auto = false;                 // the run may move between the grid and the tree kernel (ope_index_params.grid == 1)
   bool measuring_flag = false;   // plan_info[4] as last written (enqueue_accumulate)
   int force_plan_at = -1;                 // launch at which the tree kernel re-plans after taking over from the grid kernel
-  // far list of the tree kernel's launches (sampling.hip: far_plan)
-  uint32_t *d_fo_keys = nullptr, *d_fo_keys2 = nullptr, *d_fo_vals = nullptr, *d_far_list = nullptr;
-  unsigned char *d_far_class = nullptr;
-  void *d_fo_tmp = nullptr;
-  size_t fo_cap = 0, fo_tmp_bytes = 0;
-  bool far_valid = false;
   size_t corr_cap = 0;
   ope::IcpState *h_state = nullptr;  // pinned
   const ope_cloud *run_src = nullptr;   // cleared by ope_cloud_free / ope_index_free of the handle they point at

@@ -113,10 +113,8 @@ __device__ __forceinline__ double block_sum_range(const uint32_t *v, uint32_t a,
   }
   return s_sum[0];
 }
-// far_nch != 0: the list covers far_nch Morton chunks and ceil(plan_info[1] / 64) far chunks (entries beyond those are zeros)
-__global__ __launch_bounds__(1024) void plan_heavy_kernel(const uint32_t *cost_sorted_desc, uint32_t n_list, float factor, float load_factor,
-                                                          uint32_t n_waves, uint32_t *plan_info, uint32_t far_nch) {
-  const uint32_t n = far_nch ? min(n_list, far_nch + (plan_info[1] + 63u) / 64u) : n_list;
+__global__ __launch_bounds__(1024) void plan_heavy_kernel(const uint32_t *cost_sorted_desc, uint32_t n, float factor, float load_factor,
+                                                          uint32_t n_waves, uint32_t *plan_info) {
   // prefix sums of the sorted costs at a stride of `per` entries (one pass, one block scan); thread 0 then answers every
   // "cost of the m costliest chunks" with one LDS read and fewer than `per` loads
   using scan_t = rocprim::block_scan<double, 1024>;
@@ -210,8 +208,8 @@ void plan_slots(hipStream_t stream, const uint32_t *cost_sorted_desc, uint32_t n
 }
 
 void plan_heavy(hipStream_t stream, const uint32_t *cost_sorted_desc, uint32_t n, float factor, float load_factor, uint32_t n_waves,
-                uint32_t *plan_info, uint32_t far_nch) {
-  hipLaunchKernelGGL(plan_heavy_kernel, dim3(1), dim3(1024), 0, stream, cost_sorted_desc, n, factor, load_factor, n_waves, plan_info, far_nch);
+                uint32_t *plan_info) {
+  hipLaunchKernelGGL(plan_heavy_kernel, dim3(1), dim3(1024), 0, stream, cost_sorted_desc, n, factor, load_factor, n_waves, plan_info);
   if (g_plan_no_alone) (void)hipMemsetAsync(plan_info + 5, 0, 4, stream);
 }
 
@@ -325,60 +323,6 @@ size_t grid_plan_tmp_bytes(uint32_t n_valid, uint32_t nch) {
   (void)rocprim::radix_sort_pairs_desc(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                        (size_t)std::max<uint32_t>(nch, 1), 0, 32, (hipStream_t) nullptr);
   return std::max<size_t>(std::max(a, b), 16);
-}
-
-// ---- far list of the tree kernel's launches (icp_accumulate_kernel)
-// A query is FAR when its previous match lies beyond `thr2` (clutter: its tree walk is long).  far_class[i] = 1 takes it
-// out of its Morton chunk; far_list holds the far queries in ascending order of the leaf that held their previous match
-// (queries that share a start leaf walk nearly the same nodes, so that 64 of them are one packet walk);
-// plan_info[1] = their number.  One radix sort of all keys (near queries carry the largest key and sort behind the list).
-__global__ __launch_bounds__(256) void far_keys_kernel(const float *__restrict__ corr_d2, const uint32_t *__restrict__ hint, uint32_t n_valid, float thr2,
-                                                       uint32_t near_key, unsigned char *__restrict__ far_class, uint32_t *__restrict__ keys,
-                                                       uint32_t *__restrict__ vals, uint32_t *__restrict__ plan_info) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  bool far_q = false;
-  if (i < n_valid) {
-    const uint32_t h = hint[i];
-    far_q = h != 0u && corr_d2[i] > thr2;   // (no previous match: the query stays in its Morton chunk)
-    far_class[i] = far_q ? 1 : 0;
-    keys[i] = far_q ? h : near_key;
-    vals[i] = i;
-  }
-  const unsigned long long m = __ballot(far_q);
-  if ((threadIdx.x & 63u) == 0u && m != 0ull) atomicAdd(plan_info + 1, (uint32_t)__popcll(m));
-}
-
-size_t far_plan_tmp_bytes(uint32_t n) {
-  size_t b = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                  (size_t)std::max<uint32_t>(n, 1), 0, 32, (hipStream_t) nullptr);
-  return std::max<size_t>(b, 16);
-}
-
-// keys / keys_out / vals: scratch of n_valid words each.  depth: tree depth (leaf ids are heap ids < 2^(depth + 1)).
-int far_plan(hipStream_t stream, const float *corr_d2, const uint32_t *hint, uint32_t n_valid, float thr2, int depth, unsigned char *far_class,
-             uint32_t *keys, uint32_t *keys_out, uint32_t *vals, uint32_t *far_list, uint32_t *plan_info, void *tmp, size_t tmp_bytes) {
-  if (n_valid == 0) return 0;
-  if (hipMemsetAsync(plan_info + 1, 0, 4, stream) != hipSuccess) return -1;
-  const uint32_t near_key = 1u << (depth + 1);   // above every leaf id
-  hipLaunchKernelGGL(far_keys_kernel, dim3((n_valid + 255) / 256), dim3(256), 0, stream, corr_d2, hint, n_valid, thr2, near_key, far_class, keys, vals,
-                     plan_info);
-  size_t tb = tmp_bytes;
-  const hipError_t e = rocprim::radix_sort_pairs(tmp, tb, keys, keys_out, vals, far_list, (size_t)n_valid, 0, (unsigned)(depth + 2), stream);
-  return e == hipSuccess ? 0 : -1;
-}
-
-// sort keys of the chunk plan when far chunks exist: ids nch .. nch + ceil(n_far / 64) - 1 are the far chunks of this plan;
-// every existing chunk carries max(cost, 1), everything else 0, so that the existing ones are a prefix of the descending order
-__global__ __launch_bounds__(256) void far_chunk_keys_kernel(const uint32_t *__restrict__ cost, uint32_t nch, uint32_t n_total, const uint32_t *__restrict__ plan_info,
-                                                             uint32_t *__restrict__ keys) {
-  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= n_total) return;
-  const uint32_t nfc = (plan_info[1] + 63u) / 64u;
-  keys[c] = (c < nch || c - nch < nfc) ? max(cost[c], 1u) : 0u;
-}
-void far_chunk_keys(hipStream_t stream, const uint32_t *cost, uint32_t nch, uint32_t n_total, const uint32_t *plan_info, uint32_t *keys) {
-  hipLaunchKernelGGL(far_chunk_keys_kernel, dim3((n_total + 255) / 256), dim3(256), 0, stream, cost, nch, n_total, plan_info, keys);
 }
 
 void fill_iota(hipStream_t stream, uint32_t *v, uint32_t n) {

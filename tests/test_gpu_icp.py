@@ -197,6 +197,26 @@ def gpu_icp(ctx, src, tgt, src_nrm=None, tgt_nrm=None, guess=None, **kw):
     return ctx.icp(cs, ix, ope.default_icp_params(**kw), guess), cs, ix
 
 
+# Every search kernel is pinned by NAME: the index's grid mode and ope_icp_params.tree_walk force the kernel, and
+# ope_icp_kernel_launches says which kernel served the launches the comparison rests on.
+KERNELS = {"grid": dict(grid=2, tree_walk=0), "tree_lane": dict(grid=0, tree_walk=1), "tree_packet": dict(grid=0, tree_walk=2)}
+
+
+def assert_only_kernel(ctx, kernel, launches):
+    c = ctx.icp_kernel_launches()
+    assert c[kernel] == launches and sum(c.values()) == launches, (kernel, launches, c)
+
+
+def gpu_icp_on(ctx, kernel, src, tgt, guess=None, **kw):
+    """ICP with convergence disabled by the caller, on the named search kernel (asserted)."""
+    ope = load_pkg()
+    cs = ctx.upload(src)
+    ix = ctx.build_index(ctx.upload(tgt), grid=KERNELS[kernel]["grid"])
+    out = ctx.icp(cs, ix, ope.default_icp_params(tree_walk=KERNELS[kernel]["tree_walk"], **kw), guess)
+    assert_only_kernel(ctx, kernel, out.iterations)
+    return out, cs, ix
+
+
 def orc_params(**kw):
     p = oracle.default_icp_params()
     for k, v in kw.items():
@@ -244,13 +264,18 @@ def test_icp_matches_oracle_on_synthetic_scene(ctx, ns, nt):
     assert frob(out.T, Tinv) < 0.2
 
 
-def test_icp_fixed_iterations_per_iteration_parity(ctx):
-    """Convergence disabled: exactly K iterations, transform compared after every K."""
+@pytest.mark.parametrize("kernel", ["auto", "grid", "tree_lane", "tree_packet"])
+def test_icp_fixed_iterations_per_iteration_parity(ctx, kernel):
+    """Convergence disabled: exactly K iterations, transform compared after every K — on each search kernel by name."""
     src = synth.scene_cloud(30000)
     tgt = synth.model_surface(8000, 1)
     for K in (1, 2, 5, 17):
         kw = dict(max_iterations=K, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0)
-        out, _, _ = gpu_icp(ctx, src, tgt, mse_threshold_absolute=-1.0, **kw)
+        if kernel == "auto":
+            out, _, _ = gpu_icp(ctx, src, tgt, mse_threshold_absolute=-1.0, **kw)
+            assert sum(ctx.icp_kernel_launches().values()) == K
+        else:
+            out, _, _ = gpu_icp_on(ctx, kernel, src, tgt, mse_threshold_absolute=-1.0, **kw)
         ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, mse_threshold_absolute=-1.0, **kw))
         assert out.iterations == ref.iterations == K and out.state == ref.state == 1 and out.converged
         assert frob(out.T, ref.T) < 2e-5, K
@@ -472,46 +497,82 @@ def test_point_to_plane_needs_target_normals(ctx):
     assert e.value.code == ope.OPE_EINVAL
 
 
-def test_icp_large_launch_packet_walk_matches_oracle(ctx):
-    """A launch that fills the GPU (> 6144 chunks of 64 queries on an MI355X) runs the PACKET instantiation:
-    coherent chunks take one wave-uniform walk through the scalar cache.  Same exact correspondences."""
-    src = synth.scene_cloud(420_000)
-    tgt = synth.model_surface(20_000, 1)
-    kw = dict(max_iterations=4, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0)
-    out, cs, ix = gpu_icp(ctx, src, tgt, **kw)
-    ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw))
+_LARGE = {}
+
+
+def _large_case():
+    """420 k queries (> 6144 chunks of 64: a launch that fills an MI355X) against 20 k model points; the oracle's 4-iteration
+    run is computed once for all kernels."""
+    if not _LARGE:
+        src = synth.scene_cloud(420_000)
+        tgt = synth.model_surface(20_000, 1)
+        kw = dict(max_iterations=4, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0)
+        _LARGE.update(src=src, tgt=tgt, kw=kw, ref=oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw)), tree=oracle.KdTree(tgt))
+    return _LARGE
+
+
+@pytest.mark.parametrize("kernel", ["grid", "tree_lane", "tree_packet"])
+def test_icp_large_launch_each_kernel_matches_oracle_d2_bit_exact(ctx, kernel):
+    """Each of the three 1-NN kernels, forced by name and asserted through ope_icp_kernel_launches, on a launch that fills
+    the GPU: the trajectory against oracle.icp, and the squared distances of a launch that starts from known start leaves /
+    grid hints BIT FOR BIT against oracle.KdTree searching with the same transform.  (tree_packet is the instantiation the
+    bench times: coherent chunks take one wave-uniform walk through the scalar cache.)"""
+    ope = load_pkg()
+    c = _large_case()
+    src, tgt, kw, ref = c["src"], c["tgt"], c["kw"], c["ref"]
+    out, cs, ix = gpu_icp_on(ctx, kernel, src, tgt, **kw)
     assert out.iterations == ref.iterations == 4
     assert frob(out.T, ref.T) < 1e-5                       # north_star tolerance is 1e-4
     q, m, d = ctx.icp_correspondences(len(src))
     assert len(q) == ref.n_corr == len(src)
-    same = m == ref.corr_m
-    assert same.mean() > 0.9999
-    # the last iteration's squared distances: same unfused fp32 arithmetic wherever the transforms agree to the bit
+    assert (m == ref.corr_m).mean() > 0.9999
     np.testing.assert_allclose(d, ref.corr_d2, rtol=2e-3, atol=1e-10)
-    # bit for bit: the second iteration (start leaves known -> packet walks) searches with the transform the first
-    # one produced; the oracle searching with that very transform must see identical squared distances
-    ope = load_pkg()
-    ctx.icp_begin(cs, ix, ope.default_icp_params(**{**kw, "max_iterations": 2}), None)
+    # bit for bit: launches 2 and 3 (start leaves / previous matches known) search with the transforms launches 1 and 2
+    # produced; the oracle searching with those very transforms must see identical squared distances
+    params = ope.default_icp_params(tree_walk=KERNELS[kernel]["tree_walk"], **{**kw, "max_iterations": 3})
+    ctx.icp_begin(cs, ix, params, None)
     ctx.icp_iterate(1)
-    T1 = ctx.icp_current_transform()
-    ctx.icp_iterate(1)
-    two = ctx.icp_end()
-    q2, m2, d2 = ctx.icp_correspondences(len(src))
-    oi, od, _ = oracle.KdTree(tgt).knn(oracle.transform_points(src, T1), 1)
-    np.testing.assert_array_equal(d2, od[:, 0])
-    diff = m2 != oi[:, 0]
-    assert diff.mean() < 1e-4                              # exact fp32 distance ties may pick another index
-    assert two.iterations == 2
+    for it in (2, 3):
+        Tprev = ctx.icp_current_transform()
+        ctx.icp_iterate(1)
+        ctx.icp_current_transform()                        # (synchronises: the correspondences below are launch `it`'s)
+        q2, m2, d2 = ctx.icp_correspondences(len(src))
+        oi, od, _ = c["tree"].knn(oracle.transform_points(src, Tprev), 1)
+        np.testing.assert_array_equal(d2, od[:, 0])
+        assert (m2 != oi[:, 0]).mean() < 1e-4              # exact fp32 distance ties may pick another index
+    assert_only_kernel(ctx, kernel, 3)
+    assert ctx.icp_end().iterations == 3
 
 
-def test_c3_full_size_iterations_match_oracle(ctx):
+def test_icp_large_launch_default_kernel_choice_matches_oracle(ctx):
+    """The same case with the library's own choice (grid = 1: the run starts on the grid kernel and may move to the tree
+    kernel when the device-side count of far queries says so): whatever ran, the result is the oracle's."""
+    c = _large_case()
+    out, cs, ix = gpu_icp(ctx, c["src"], c["tgt"], **c["kw"])
+    assert frob(out.T, c["ref"].T) < 1e-5
+    k = ctx.icp_kernel_launches()
+    assert sum(k.values()) == 4 and k["knn"] == 0, k
+
+
+_C3REF = {}
+
+
+@pytest.mark.parametrize("kernel", ["auto", "grid", "tree_lane", "tree_packet"])
+def test_c3_full_size_iterations_match_oracle(ctx, kernel):
     """BASELINE.json's headline configuration at full size (1 M scene points vs 100 k model points): three ICP
-    iterations on the HIP path (chunk plan, group walks, packet walks all active from the second iteration on)
-    against the CPU oracle; tolerance = north_star's 1e-4 Frobenius on the 4x4 (observed ~1e-6)."""
+    iterations on each search kernel by name (and on the library's own choice) against the CPU oracle; chunk plan,
+    group walks and packet walks are active from the second iteration on.  Tolerance = north_star's 1e-4 Frobenius on the
+    4x4 (observed ~1e-6)."""
     src, tgt = synth.config_clouds("C3")
     kw = dict(max_iterations=3, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0)
-    out, cs, ix = gpu_icp(ctx, src, tgt, **kw)
-    ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw))
+    if kernel == "auto":
+        out, cs, ix = gpu_icp(ctx, src, tgt, **kw)
+        assert sum(ctx.icp_kernel_launches().values()) == 3
+    else:
+        out, cs, ix = gpu_icp_on(ctx, kernel, src, tgt, **kw)
+    if not _C3REF:
+        _C3REF["ref"] = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw))
+    ref = _C3REF["ref"]
     assert out.iterations == ref.iterations == 3
     assert frob(out.T, ref.T) <= 1e-4
     assert out.n_corr == ref.n_corr == len(src)

@@ -6,16 +6,19 @@ import ctypes as C, importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ope = importlib.import_module("object-pose-estimation_amd")
+if os.environ.get("PROBE_LIB"):   # an A/B build: make -C object-pose-estimation_amd VARIANT=<name> ...
+    ope.LIB_PATH = os.path.join(os.path.dirname(ope.LIB_PATH), f"libope_hip_{os.environ['PROBE_LIB']}.so")
 synth = importlib.import_module("object-pose-estimation_amd.synth")
 modes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["steady"]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 grid = int(os.environ.get("PROBE_GRID", "0"))
-label = " ".join(f"{k[4:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith("OPE_")) or "defaults"
+label = " ".join([f"lib={os.environ['PROBE_LIB']}"] * bool(os.environ.get("PROBE_LIB")) + [f"{k[4:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith("OPE_")]) or "defaults"
 tgt = synth.model_surface(100_000, 1)
 gt = np.linalg.inv(synth.ground_truth_pose()).astype(np.float32)
 src = synth.scene_cloud(1_000_000, clutter_frac=0.10)
 nch = (len(src) + 63) // 64
-nch2 = 2 * nch + 2   # Morton chunks, then the far chunks of the plan
+fshift = int(os.environ.get('OPE_FAR_SHIFT', '6'))
+nch2 = nch + (nch << (6 - fshift)) + 2   # Morton chunks, then the far chunks of the plan
 TICK_US = 16 / 2400.0
 
 
@@ -78,7 +81,8 @@ if "chunks" in modes:
     assert L.ope_debug_chunk_stats(ctx.h, 0, None) == 0
     us = cost.astype(np.float64) * TICK_US
     print(f"[{label}] chunks: measuring launch {km/kn*1e3:.1f} us; sum of chunk time {us.sum()/1e3:.1f} ms = {us.sum()/6144:.1f} us per wave")
-    path = st[:, 0]
+    path = st[:, 0] & 255
+    span = st[:, 0] >> 8
     for name, code in (("per-lane", 0), ("packet", 1), ("groups", 2)):
         m = (path == code) & (us > 0)
         if m.any():
@@ -86,11 +90,16 @@ if "chunks" in modes:
                   f" share of chunk time {us[m].sum()/us.sum():.2f}" + (f"; node steps {st[m,1].mean():.1f} (max {st[m,1].max()}), leaf scans {st[m,2].mean():.1f}, back-ups {st[m,3].mean():.1f}" if code == 1 else ""))
     print(f"    plan_info {info.tolist()}")
     if os.environ.get("OPE_FAR"):
-        nfc = (int(info[1]) + 63) // 64
+        nfc = (int(info[1]) + (1 << fshift) - 1) >> fshift
         for a, b, nm in ((nch, nch + nfc, f"far chunks ({info[1]} queries)"), (0, nch, "Morton chunks (near lanes only)")):
             m = np.zeros(nch2, bool); m[a:b] = True
             m &= us > 0
             pk = m & (path == 1)
             print(f"    {nm}: {m.sum()} chunks with work, packet {pk.sum()}, duration mean {us[m].mean():.1f} us p50 {np.percentile(us[m],50):.1f} p99 {np.percentile(us[m],99):.1f} max {us[m].max():.1f}, sum {us[m].sum()/1e3:.1f} ms"
                   + (f"; packet node steps {st[pk,1].mean():.1f} (max {st[pk,1].max()}) leaf scans {st[pk,2].mean():.1f} back-ups {st[pk,3].mean():.1f}" if pk.any() else ""))
+            if pk.any():
+                for lo_, hi_ in ((0, 8), (8, 32), (32, 128), (128, 512), (512, 1 << 24)):
+                    q = pk & (span >= lo_) & (span < hi_)
+                    if q.any():
+                        print(f"        start-leaf span [{lo_},{hi_}): {q.sum()} chunks, {us[q].mean():.1f} us mean, {us[q].max():.1f} max, node steps {st[q,1].mean():.1f}")
     ctx.icp_end(); ctx.close()
