@@ -59,6 +59,8 @@ def main() -> int:
     ap.add_argument("--leaf", type=int, default=0, help="index leaf size override (0 = library default)")
     ap.add_argument("--no-grid", action="store_true", help="OBB tree only (A/B against the bucketed search)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ns", action="store_true", help="skip the normal-shooting leg (the correspondence estimation the reference's "
+                                                          "estimateFinePose really installs), reported beside `value` at N = 1")
     ap.add_argument("--no-coarse", action="store_true", help="skip the FPFH + SAC-IA initial alignment (identity start)")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--steady", type=int, default=100, help="iterations timed after the K steps, in the converged regime (reported, not `value`)")
@@ -169,20 +171,21 @@ def main() -> int:
         ctx.profile_kernels(True)
         t_c = time.perf_counter()
         stage = {}
+        # every stage hands its survivors on as a device-resident cloud (ope_*_cloud): no host round trip between the stages
         frame = ctx.upload(scene)
         lo_w, hi_w = synth.workspace_limits(0.01)
-        t1 = time.perf_counter(); crop = ctx.pass_through(frame, lo_w, hi_w); cluster = scene[crop]
-        t2 = time.perf_counter(); inl = ctx.statistical_outlier_removal(ctx.upload(cluster), 30, 1.0); cluster = cluster[inl]
+        t1 = time.perf_counter(); crop_c, _ = ctx.pass_through_cloud(frame, lo_w, hi_w)
+        t2 = time.perf_counter(); cluster, _ = ctx.statistical_outlier_removal_cloud(crop_c, 30, 1.0)
         t3 = time.perf_counter()
-        stage["frame"] = {"points": int(len(scene)), "pass_through_kept": int(len(crop)), "pass_through_ms": (t2 - t1) * 1e3,
-                          "outlier_removal_kept": int(len(inl)), "outlier_removal_ms": (t3 - t2) * 1e3}
+        stage["frame"] = {"points": int(len(scene)), "upload_ms": (t1 - t_c) * 1e3, "pass_through_kept": int(crop_c.n), "pass_through_ms": (t2 - t1) * 1e3,
+                          "outlier_removal_kept": int(cluster.n), "outlier_removal_ms": (t3 - t2) * 1e3}
         feats, kclouds = [], []
-        for name, cloud in (("cluster", cluster), ("model", model)):
-            t1 = time.perf_counter(); full = ctx.upload(cloud); keep = ctx.uniform_sampling(full, 0.01)
-            t2 = time.perf_counter(); kc = ctx.upload(cloud[keep]); ctx.normals(kc, 30)
+        for name, full in (("cluster", cluster), ("model", ix.cloud)):
+            t1 = time.perf_counter(); kc, _ = ctx.uniform_sampling_cloud(full, 0.01)
+            t2 = time.perf_counter(); ctx.normals(kc, 30, fetch=False)
             t3 = time.perf_counter(); feats.append(ctx.fpfh(kc, 0.03))
             t4 = time.perf_counter()
-            stage[name] = {"points": int(len(cloud)), "keypoints": int(len(keep)), "uniform_sampling_ms": (t2 - t1) * 1e3,
+            stage[name] = {"points": int(full.n), "keypoints": int(kc.n), "uniform_sampling_ms": (t2 - t1) * 1e3,
                            "normals_ms": (t3 - t2) * 1e3, "fpfh_ms": (t4 - t3) * 1e3}
             kclouds.append(kc)
         t5 = time.perf_counter()
@@ -271,6 +274,35 @@ def main() -> int:
     out = ctx.icp_end()
     assert out.iterations == W + K + S, (out.iterations, W, K, S)
 
+    # ---- beside `value`: the configuration estimateFinePose / getIcpNormal really run (poseestimator.cpp:242-246,331-337;
+    # regmeshpcd.cpp:140-159): normal shooting over the k = 20 nearest + the surface-normal rejector at 0.7, SVD estimator,
+    # on the same clouds (normals k = 30 as subSampleAndCalculateNormals attaches them, :153), from the same coarse pose.
+    ns_leg = None
+    if world == 1 and args.workload == "C3" and not args.no_ns:
+        t0 = time.perf_counter()
+        ctx.normals(cs, 30, fetch=False)
+        cmn = ctx.upload(model); ctx.normals(cmn, 30, fetch=False)
+        ixn = ctx.build_index(cmn, leaf_size=args.leaf or None)
+        ctx.sync(); t_prep = time.perf_counter() - t0
+        Wn, Kn = 10, 30
+        pn = ope.default_icp_params(max_iterations=Wn + Kn + 1, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0,
+                                    check_every=0, corr_mode=ope.CORR_NORMAL_SHOOTING, k_normal_shooting=20, use_surface_normal_rej=1, surface_normal_thr=0.7)
+        ctx.icp_begin(cs, ixn, pn, guess)
+        ctx.icp_iterate(Wn); ctx.sync()
+        ctx.icp_profile(Kn)
+        t0 = time.perf_counter(); ctx.icp_iterate(Kn); ctx.sync(); dtn = time.perf_counter() - t0
+        kmn, knn = ctx.icp_profile_read(); ctx.icp_profile(0)
+        on = ctx.icp_end()
+        kms = kmn / max(knn, 1)
+        ns_bytes = 60.0 * n_scene + 24.0 * n_model      # SURVEY 8d, "with normals": 60 B per source point + 24 B per target point
+        ns_gbs = ns_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        ns_leg = {"workload": "C3-ns: the same clouds, normal shooting k = 20 + surface-normal rejector 0.7 (estimateFinePose's correspondence estimation), SVD estimator",
+                  "steps": Kn, "warmup": Wn, "ms_per_step": dtn / Kn * 1e3, "iterations_per_s": Kn / dtn, "n_corr": int(on.n_corr),
+                  "normals_and_index_ms": t_prep * 1e3,
+                  "roofline": {"bound": "hbm", "achieved": ns_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ns_gbs / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "icp_accumulate_kernel<2,true,false,*,20>", "kernel_ms": kms, "launches_timed": knn,
+                               "algorithmic_bytes_per_launch": ns_bytes}}
+
     if launched:
         vals = [elapsed, kern_avg_ms] + ([steady["ms_per_step"], steady["kernel_ms"]] if steady else [])
         t = torch.tensor(vals, dtype=torch.float64, device=cdev)
@@ -313,13 +345,13 @@ def main() -> int:
             # kernel's average)
             ix2 = ctx.build_index(ctx.upload(model), leaf_size=args.leaf or None, grid=2)
             t0 = time.perf_counter()
-            cc = ctx.upload(cluster)
+            cc = cluster                                   # the device-resident cluster the front end left behind
             p2 = ope.default_icp_params(max_iterations=100, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0,
                                         mse_threshold_absolute=-1.0, check_every=0)
             o2 = ctx.icp(cc, ix2, p2, guess)
             e2 = float(np.linalg.norm(o2.T.astype(np.float64) - gt_inv))
             checks.update({"cluster_icp_pose_error_vs_ground_truth_frobenius": e2, "cluster_icp_bound": 1e-2,
-                           "cluster_points": int(len(cluster)), "cluster_icp_ms_100_iterations_incl_upload": (time.perf_counter() - t0) * 1e3})
+                           "cluster_points": int(cluster.n), "cluster_icp_ms_100_iterations": (time.perf_counter() - t0) * 1e3})
             ok = ok and e2 < 1e-2
         checks["passed"] = bool(ok)
         line = {
@@ -349,6 +381,8 @@ def main() -> int:
                        "steady_state": steady},
             "pose_check": checks,
         }
+        if ns_leg is not None:
+            line["normal_shooting_leg"] = ns_leg
         if coarse is not None:
             line["coarse_stage"] = coarse
         if world == 1 and not args.no_cpu_baseline:

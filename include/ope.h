@@ -97,6 +97,11 @@ int ope_cloud_set_normals(ope_ctx *ctx, ope_cloud *cloud, const float *normals_x
 int ope_cloud_concat(ope_ctx *ctx, const ope_cloud *a, const float T_a[16], const ope_cloud *b, ope_cloud **out);
 /* xyz of a cloud in ORIGINAL order (n*3 floats): the way out for clouds made by ope_cloud_concat. */
 int ope_cloud_download(ope_ctx *ctx, const ope_cloud *cloud, float *out_xyz);
+/* A new cloud from n ORIGINAL indices of `cloud` (host array, any order, repeats allowed), gathered on the device: the new
+ * cloud's original order is the order of idx; normals attached to `cloud` are carried.  What `cloud[idx]` would be after an
+ * upload, without the trip through the host (the hand-over between the stages in front of the path:
+ * rosinterface.cpp:212-213 -> poseestimator.cpp:141-156). */
+int ope_cloud_select(ope_ctx *ctx, const ope_cloud *cloud, const int32_t *idx, size_t n, ope_cloud **out);
 size_t ope_cloud_size(const ope_cloud *cloud);
 void ope_cloud_free(ope_cloud *cloud);
 
@@ -247,6 +252,8 @@ int ope_icp_set_global_sizes(ope_ctx *ctx, int64_t n_src_total, int64_t n_tgt_to
  * returns the summed kernel time and the number of launches timed since ope_icp_profile. */
 int ope_icp_profile(ope_ctx *ctx, int max_launches);
 int ope_icp_profile_read(ope_ctx *ctx, double *total_ms, int *n_launches);
+/* The same per launch: ms[i] = duration of the i-th timed launch (at most cap of them), *n_out their number. */
+int ope_icp_profile_launches(ope_ctx *ctx, float *ms, size_t cap, size_t *n_out);
 
 /* Last iteration's post-rejection correspondences, compacted in query order
  * (pcl::Correspondences: index_query, index_match, distance = squared L2).  OPE_ESTATE when there is no finished
@@ -351,6 +358,17 @@ int ope_voxel_grid_rgb(ope_ctx *ctx, const ope_cloud *cloud, const float leaf[3]
  * out_mean_dist (optional, n floats, ORIGINAL order): the per-point mean distances. */
 int ope_statistical_outlier_removal(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double stddev_mul, int32_t *out_idx,
                                     size_t *n_out, float *out_mean_dist);
+
+/* Device-resident forms of the filters above: the survivors are handed on as a new cloud (*out, as ope_cloud_select of the
+ * indices the host form returns would build it), so that crop -> outlier removal -> key points -> normals -> FPFH -> SAC-IA
+ * runs without a host round trip per stage.  out_idx (optional, room for every point) receives the same ORIGINAL indices
+ * as the host form; n_out (optional) their number. */
+int ope_remove_nan_cloud(ope_ctx *ctx, const ope_cloud *cloud, ope_cloud **out, int32_t *out_idx, size_t *n_out);
+int ope_pass_through_cloud(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], ope_cloud **out, int32_t *out_idx,
+                           size_t *n_out);
+int ope_statistical_outlier_removal_cloud(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double stddev_mul, ope_cloud **out,
+                                          int32_t *out_idx, size_t *n_out);
+int ope_uniform_sampling_cloud(ope_ctx *ctx, const ope_cloud *cloud, float leaf, ope_cloud **out, int32_t *out_idx, size_t *n_out);
 
 typedef struct {
   int max_iterations;      /* 400  (poseestimator.cpp:55) */

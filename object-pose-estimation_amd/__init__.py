@@ -145,6 +145,12 @@ ABI = [
     ("ope_icp_end", C.c_int, [_vp, _fp, C.POINTER(IcpResult)]),
     ("ope_icp_set_global_sizes", C.c_int, [_vp, C.c_int64, C.c_int64]),
     ("ope_icp_kernel_launches", C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    ("ope_icp_profile_launches", C.c_int, [_vp, _fp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("ope_cloud_select", C.c_int, [_vp, _vp, _ip, C.c_size_t, C.POINTER(_vp)]),
+    ("ope_remove_nan_cloud", C.c_int, [_vp, _vp, C.POINTER(_vp), _ip, C.POINTER(C.c_size_t)]),
+    ("ope_pass_through_cloud", C.c_int, [_vp, _vp, _fp, _fp, C.POINTER(_vp), _ip, C.POINTER(C.c_size_t)]),
+    ("ope_statistical_outlier_removal_cloud", C.c_int, [_vp, _vp, C.c_int, C.c_double, C.POINTER(_vp), _ip, C.POINTER(C.c_size_t)]),
+    ("ope_uniform_sampling_cloud", C.c_int, [_vp, _vp, C.c_float, C.POINTER(_vp), _ip, C.POINTER(C.c_size_t)]),
     ("ope_icp_correspondences", C.c_int, [_vp, _ip, _ip, _fp, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ope_icp_last_incremental", C.c_int, [_vp, _fp]),
     ("ope_reject_pairs", C.c_int, [_vp, C.c_int, _fp, _fp, C.c_size_t, C.c_double, C.POINTER(C.c_ubyte)]),
@@ -308,6 +314,36 @@ class Context:
         self._chk(lib().ope_cloud_concat(self.h, a.h, _p(t, _fp), b.h, C.byref(h)))
         return Cloud(self, h, a.n + b.n)
 
+    def select(self, cloud: "Cloud", idx) -> "Cloud":
+        """cloud[idx] as a new device-resident cloud (gathered on the device; normals carried)."""
+        idx = np.ascontiguousarray(idx, np.int32)
+        h = _vp()
+        self._chk(lib().ope_cloud_select(self.h, cloud.h, _p(idx, _ip), len(idx), C.byref(h)))
+        return Cloud(self, h, len(idx))
+
+    def _filter_cloud(self, fn, cloud, args, want_idx):
+        """device-resident form of a filter: (new Cloud, indices or None)"""
+        out = np.empty(max(cloud.n, 1), np.int32) if want_idx else None
+        n = C.c_size_t(0)
+        h = _vp()
+        self._chk(fn(self.h, cloud.h, *args, C.byref(h), _p(out, _ip), C.byref(n)))
+        return Cloud(self, h, n.value), (out[: n.value].copy() if want_idx else None)
+
+    def remove_nan_cloud(self, cloud: "Cloud", want_idx: bool = False):
+        return self._filter_cloud(lib().ope_remove_nan_cloud, cloud, (), want_idx)
+
+    def pass_through_cloud(self, cloud: "Cloud", lo, hi, want_idx: bool = False):
+        lo = np.ascontiguousarray(lo, np.float32); hi = np.ascontiguousarray(hi, np.float32)
+        if lo.shape != (3,) or hi.shape != (3,):
+            raise ValueError("pass_through: lo and hi are 3-vectors")
+        return self._filter_cloud(lib().ope_pass_through_cloud, cloud, (_p(lo, _fp), _p(hi, _fp)), want_idx)
+
+    def statistical_outlier_removal_cloud(self, cloud: "Cloud", mean_k: int = 30, stddev_mul: float = 1.0, want_idx: bool = False):
+        return self._filter_cloud(lib().ope_statistical_outlier_removal_cloud, cloud, (mean_k, stddev_mul), want_idx)
+
+    def uniform_sampling_cloud(self, cloud: "Cloud", leaf: float, want_idx: bool = False):
+        return self._filter_cloud(lib().ope_uniform_sampling_cloud, cloud, (leaf,), want_idx)
+
     def download(self, cloud: "Cloud") -> np.ndarray:
         out = np.empty((cloud.n, 3), np.float32)
         self._chk(lib().ope_cloud_download(self.h, cloud.h, _p(out, _fp)))
@@ -407,6 +443,13 @@ class Context:
         r = IcpResult()
         self._chk(lib().ope_icp_end(self.h, _p(T, _fp), C.byref(r)))
         return IcpOut(from_colmajor(T), r.iterations, bool(r.converged), r.state, r.last_mse, r.n_corr, r.align_strength)
+
+    def icp_profile_launches(self, cap: int = 4096) -> np.ndarray:
+        """HIP-event duration (ms) of each accumulate launch timed since icp_profile(n)."""
+        ms = np.empty(cap, np.float32)
+        n = C.c_size_t(0)
+        self._chk(lib().ope_icp_profile_launches(self.h, _p(ms, _fp), cap, C.byref(n)))
+        return ms[: n.value].copy()
 
     def icp_kernel_launches(self) -> dict:
         """Accumulate launches of the current / last run per search kernel: {'grid', 'tree_lane', 'tree_packet', 'knn'}."""

@@ -15,7 +15,7 @@ namespace ope {
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
-                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *);
+                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *);
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
 void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
@@ -37,7 +37,8 @@ hipError_t build_grid_device(hipStream_t, const float4 *, const float4 *, size_t
                              float4 **, float4 **, uint32_t **, uint32_t **);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
 void launch_icp_update(hipStream_t, IcpState *, double *, int, const float *);
-int lm_point_to_plane(ope_ctx *, const CloudView &, const BvhView &, const int32_t *, double *, long long, float[16], int *);
+void launch_lm_stats(hipStream_t, int, const CloudView &, const BvhView &, const IcpState *, const int32_t *, double *);
+void launch_icp_lm_update(hipStream_t, IcpState *, double *, double *);
 void launch_lm_pos_to_orig(hipStream_t, const BvhView &, int32_t *, uint32_t);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
 void launch_knn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int, int32_t *, float *);
@@ -47,6 +48,7 @@ void launch_pairs_svd(hipStream_t, const float *, const float *, uint32_t, doubl
 int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count);
 bool comm_uses_p2p(const ope_ctx *ctx);
 int comm_p2p_exchange_update(ope_ctx *ctx, IcpState *d_state, double *d_sums, int nsums);
+int comm_p2p_exchange(ope_ctx *ctx, double *d_sums, int nsums);
 
 static thread_local std::string g_global_err;
 
@@ -170,7 +172,11 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     // the launch before a plan step measures: no 8-lane group walks (their chunks would keep the cost of the last
     // per-lane walk they had, however old), flagged to the kernels through plan_info[4]
     const int nx = it_done + 1;
-    const bool measuring = !no_plan && nch > 1 && ((((nx & (nx - 1)) == 0 && nx <= plan_every) || nx % plan_every == 0 || nx == ctx->force_plan_at));
+    // (round 3: a group-walked chunk reports an estimate of its per-lane cost, icp_accumulate_kernel, so the tree kernel no
+    // longer needs measuring launches; the grid kernel's tree part still takes them.  OPE_MEASURING=1: developer A/B)
+    static const bool measuring_env = dev_env("OPE_MEASURING") != nullptr;
+    const bool measuring = (ctx->use_grid || measuring_env) && !no_plan && nch > 1 &&
+                           ((((nx & (nx - 1)) == 0 && nx <= plan_every) || nx % plan_every == 0 || nx == ctx->force_plan_at));
     if (measuring != ctx->measuring_flag) {
       OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 12, measuring ? 0x01 : 0x00, 4, ctx->stream));
       ctx->measuring_flag = measuring;
@@ -270,7 +276,8 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
                         recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
                         ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr,
-                        (ctx->plan_valid && ctx->slot_list_valid) ? ctx->d_slot_list : nullptr);
+                        (ctx->plan_valid && ctx->slot_list_valid) ? ctx->d_slot_list : nullptr,
+                        p.corr_mode == OPE_CORR_NORMAL_SHOOTING ? ctx->d_knn_rk : nullptr);
   if (timed) {
     OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
     ++ctx->prof_used;
@@ -313,6 +320,7 @@ int ope_ctx_create(ope_ctx **out, int device_ordinal) {
   if (hipMalloc(&ctx->d_state, sizeof(IcpState)) != hipSuccess ||
       hipMalloc(&ctx->d_partials, sizeof(double) * kNumSumsMax * kAccMaxBlocks) != hipSuccess ||
       hipMalloc((void **)&ctx->d_work_counter, 256) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_lm_stats, sizeof(double) * 96) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState)) != hipSuccess) {
     ope_ctx_destroy(ctx);
     return set_err(nullptr, OPE_ENOMEM, "context allocation failed");
@@ -332,9 +340,11 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->d_state) (void)hipFree(ctx->d_state);
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
   if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
+  if (ctx->d_lm_stats) (void)hipFree(ctx->d_lm_stats);
   if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
   if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
   if (ctx->d_hint) (void)hipFree(ctx->d_hint);
+  if (ctx->d_knn_rk) (void)hipFree(ctx->d_knn_rk);
   for (void *p : {(void *)ctx->d_ghint, (void *)ctx->d_qorder, (void *)ctx->d_qclass, ctx->d_part_tmp, (void *)ctx->d_chunk_keys})
     if (p) (void)hipFree(p);
   if (ctx->grid_probe_event) (void)hipEventDestroy(ctx->grid_probe_event);
@@ -897,6 +907,12 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     ctx->acc_launches = 0;
     for (int64_t &k : ctx->kernel_launches) k = 0;
   }
+  if (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && ctx->knn_rk_cap < std::max<size_t>(src->n, 1)) {
+    if (ctx->d_knn_rk) (void)hipFree(ctx->d_knn_rk);
+    ctx->d_knn_rk = nullptr; ctx->knn_rk_cap = 0;
+    OPE_HIP(ctx, hipMalloc((void **)&ctx->d_knn_rk, sizeof(float) * std::max<size_t>(src->n, 1)));
+    ctx->knn_rk_cap = std::max<size_t>(src->n, 1);
+  }
   // no start hints yet: the first iteration walks top-down (hints belong to one (src, tgt) pairing)
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_hint, 0, sizeof(uint32_t) * std::max<size_t>(src->n, 1), ctx->stream));
 
@@ -948,6 +964,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   if (ctx->d_sums_ext)
     OPE_HIP(ctx, hipMemsetAsync(ctx->d_sums_ext, 0, sizeof(double) * (p.estimator == OPE_EST_POINT_TO_PLANE_LLS ? kNumSumsMax : kNumSums), ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 256, ctx->stream));
+  OPE_HIP(ctx, hipMemsetAsync(ctx->d_lm_stats, 0, sizeof(double) * 96, ctx->stream));
   ctx->measuring_flag = false;
   // partial-sum rows of blocks that do not exist in this run must read as zero
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_partials, 0, sizeof(double) * kNumSumsMax * kAccMaxBlocks, ctx->stream));
@@ -1023,32 +1040,23 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
     if (rc != OPE_OK) return rc;
     TraceRange r_red(ctx, "reduce");
     if (ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LM) {
-      if (sharded && !ctx->nccl_comm)
-        return set_err(ctx, OPE_EINVAL, "ope_icp_iterate: the LM estimator reduces through RCCL (ope_comm_init_rank); a communicator made by ope_comm_p2p_connect carries the SVD and LLS estimators");
-      // correspondences are in place (corr_match = index positions); their 17 sums give n and the MSE
+      // correspondences are in place (corr_match = index positions); their 17 sums give n and the MSE, one more pass gives
+      // the 91 sums the minimiser works on (lm.hip); in sharded runs both sets are summed over the ranks; the minimisation
+      // and the update step are one launch (icp_lm_update_kernel).  Nothing synchronises the host.
       if (!atomic)
         launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
+      launch_lm_stats(ctx->stream, ctx->n_cu, ctx->run_src->view(), ctx->run_tgt->view(), ctx->d_state, ctx->d_corr_match, ctx->d_lm_stats);
       if (sharded) {
-        rc = comm_allreduce_sums(ctx, sums_ptr(ctx), kNumSums);
+        if (comm_uses_p2p(ctx)) {
+          rc = comm_p2p_exchange(ctx, sums_ptr(ctx), kNumSums);
+          if (rc == OPE_OK) rc = comm_p2p_exchange(ctx, ctx->d_lm_stats, 91);
+        } else {
+          rc = comm_allreduce_sums(ctx, sums_ptr(ctx), kNumSums);
+          if (rc == OPE_OK) rc = comm_allreduce_sums(ctx, ctx->d_lm_stats, 91);
+        }
         if (rc != OPE_OK) return rc;
       }
-      double n_corr = 0;
-      int done = 0;
-      OPE_HIP(ctx, hipMemcpyAsync(&n_corr, sums_ptr(ctx), sizeof n_corr, hipMemcpyDeviceToHost, ctx->stream));
-      OPE_HIP(ctx, hipMemcpyAsync(&done, reinterpret_cast<unsigned char *>(ctx->d_state) + offsetof(IcpState, done), sizeof done, hipMemcpyDeviceToHost, ctx->stream));
-      OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (done) continue;   // the accumulate launch was a no-op: the run has ended
-      float Tk[16];
-      int nfev = 0;
-      rc = ensure_scratch(ctx, 1 << 16);
-      if (rc != OPE_OK) return rc;
-      double *d_lm = reinterpret_cast<double *>(static_cast<unsigned char *>(ctx->d_scratch) + 1024);
-      float *d_Tk = reinterpret_cast<float *>(static_cast<unsigned char *>(ctx->d_scratch) + 2048);
-      rc = lm_point_to_plane(ctx, ctx->run_src->view(), ctx->run_tgt->view(), ctx->d_corr_match, d_lm, (long long)n_corr, Tk, &nfev);
-      if (rc != OPE_OK) return rc;
-      OPE_HIP(ctx, hipMemcpyAsync(d_Tk, Tk, sizeof Tk, hipMemcpyHostToDevice, ctx->stream));
-      launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), kNumSums, d_Tk);
-      OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));   // Tk lives on this stack frame until the copy has been issued and consumed
+      launch_icp_lm_update(ctx->stream, ctx->d_state, sums_ptr(ctx), ctx->d_lm_stats);
       continue;
     }
     if (sharded) {
@@ -1101,6 +1109,15 @@ int ope_icp_profile_read(ope_ctx *ctx, double *total_ms, int *n_launches) {
   }
   if (total_ms) *total_ms = tot;
   if (n_launches) *n_launches = (int)ctx->prof_used;
+  return OPE_OK;
+}
+
+int ope_icp_profile_launches(ope_ctx *ctx, float *ms, size_t cap, size_t *n_out) {
+  if (!ctx || !n_out || (cap && !ms)) return OPE_EINVAL;
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t n = std::min(cap, ctx->prof_used);
+  for (size_t i = 0; i < n; ++i) OPE_HIP(ctx, hipEventElapsedTime(ms + i, ctx->prof_events[2 * i], ctx->prof_events[2 * i + 1]));
+  *n_out = n;
   return OPE_OK;
 }
 

@@ -601,9 +601,11 @@ struct KnnRegVisitor {
   uint32_t p[K];
   int count;
   uint32_t leaf;   // leaf of the current nearest entry (next iteration's start hint)
-  __device__ __forceinline__ void init(bool active) {
+  // bound: only points strictly closer than this can enter the list (+inf: plain k-NN; a finite value that is known to
+  // lie above the K-th neighbour's distance gives the same list and prunes from the first box on)
+  __device__ __forceinline__ void init(bool active, float bound = INFINITY) {
 #pragma unroll
-    for (int j = 0; j < K; ++j) { d[j] = active ? INFINITY : -INFINITY; p[j] = 0; }
+    for (int j = 0; j < K; ++j) { d[j] = active ? bound : -INFINITY; p[j] = 0; }
     count = 0;
     leaf = 0;
   }

@@ -165,6 +165,16 @@ int comm_p2p_exchange_update(ope_ctx *ctx, IcpState *d_state, double *d_sums, in
   return OPE_OK;
 }
 
+// the exchange alone, in place: every rank ends up with the rank-ordered totals (the LM estimator's two sets of sums)
+int comm_p2p_exchange(ope_ctx *ctx, double *d_sums, int nsums) {
+  if (!comm_uses_p2p(ctx)) return set_err(ctx, OPE_ECOMM, "comm_p2p_exchange: peer-to-peer slots are not set up");
+  if (nsums > kP2pMaxSums) return set_err(ctx, OPE_EINVAL, "comm_p2p_exchange: too many sums");
+  ++ctx->p2p_seq;
+  if (ctx->p2p_seq == 0) ctx->p2p_seq = 2;
+  launch_icp_p2p_update(ctx->stream, ctx->d_state, d_sums, nsums, p2p_view(ctx), ctx->p2p_seq, 500000000ull /* 5 s */, false, d_sums);
+  return OPE_OK;
+}
+
 int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count) {
   Rccl &r = rccl();
   if (!r.h || !ctx->nccl_comm) return set_err(ctx, OPE_ECOMM, "comm_allreduce_sums: communicator not initialised");

@@ -157,9 +157,11 @@ __global__ __launch_bounds__(256) void reject_pairs_kernel(int kind, const float
   keep[i] = ok ? 1 : 0;
 }
 
-static int box_filter(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], int32_t *out_idx,
-                      size_t *n_out, const char *who) {
-  *n_out = 0;
+// survivors' ORIGINAL indices in input order, left on the device (*d_out_ret, caller frees); count on the host
+static int box_filter_dev(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], int32_t **d_out_ret, unsigned int *count_ret,
+                          const char *who) {
+  *d_out_ret = nullptr;
+  *count_ret = 0;
   const size_t n = cloud->n;
   if (n == 0) return OPE_OK;
   OPE_HIP(ctx, hipSetDevice(ctx->device));
@@ -181,13 +183,54 @@ static int box_filter(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], c
     if (e == hipSuccess) e = rocprim::select(d_tmp, tb, iota, d_flags, d_out, d_count, n, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess && count) e = hipMemcpy(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost);
   }
-  for (void *p : {(void *)d_flags, (void *)d_out, (void *)d_count, d_tmp})
+  for (void *p : {(void *)d_flags, (void *)d_count, d_tmp})
     if (p) (void)hipFree(p);
+  if (e != hipSuccess) {
+    if (d_out) (void)hipFree(d_out);
+    return set_err(ctx, OPE_EHIP, std::string(who) + ": " + hipGetErrorString(e));
+  }
+  *d_out_ret = d_out;
+  *count_ret = count;
+  return OPE_OK;
+}
+
+static int box_filter(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], int32_t *out_idx,
+                      size_t *n_out, const char *who) {
+  *n_out = 0;
+  int32_t *d_out = nullptr;
+  unsigned int count = 0;
+  const int rc = box_filter_dev(ctx, cloud, lo, hi, &d_out, &count, who);
+  if (rc != OPE_OK) return rc;
+  hipError_t e = hipSuccess;
+  if (count) e = hipMemcpy(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost);
+  if (d_out) (void)hipFree(d_out);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string(who) + ": " + hipGetErrorString(e));
   *n_out = count;
   return OPE_OK;
+}
+
+// the same with the survivors handed on as a device-resident cloud (and, optionally, their indices to the host)
+static int box_filter_cloud(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], ope_cloud **out, int32_t *out_idx,
+                            size_t *n_out, const char *who) {
+  *out = nullptr;
+  if (n_out) *n_out = 0;
+  int32_t *d_out = nullptr;
+  unsigned int count = 0;
+  int rc = box_filter_dev(ctx, cloud, lo, hi, &d_out, &count, who);
+  if (rc != OPE_OK) return rc;
+  hipError_t e = hipSuccess;
+  if (count && out_idx) e = hipMemcpyAsync(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream);
+  rc = e == hipSuccess ? select_cloud_device(ctx, cloud, d_out, count, out) : set_err(ctx, OPE_EHIP, std::string(who) + ": " + hipGetErrorString(e));
+  if (d_out) (void)hipFree(d_out);
+  if (rc == OPE_OK && n_out) *n_out = count;
+  return rc;
+}
+
+// keep[i] = !(dist[i] > thr), by ORIGINAL index (non-finite points carry distance 0 and pass: PCL quirk)
+__global__ __launch_bounds__(256) void sor_flags_kernel(const float *__restrict__ dist, uint32_t n, double thr, unsigned char *__restrict__ keep) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) keep[i] = !((double)dist[i] > thr) ? 1 : 0;
 }
 
 }  // namespace ope
@@ -279,23 +322,29 @@ extern "C" int ope_voxel_grid_rgb(ope_ctx *ctx, const ope_cloud *cloud, const fl
   return OPE_OK;
 }
 
-extern "C" int ope_statistical_outlier_removal(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double stddev_mul,
-                                               int32_t *out_idx, size_t *n_out, float *out_mean_dist) {
-  if (!ctx || !cloud || !out_idx || !n_out || mean_k < 1 || mean_k + 1 > kKnnMaxK)
-    return set_err(ctx, OPE_EINVAL, "ope_statistical_outlier_removal: bad argument (1 <= mean_k <= 31)");
-  *n_out = 0;
+// Core of StatisticalOutlierRemoval.  want_cloud: the inliers as a device-resident cloud (*out_cloud); out_idx (optional):
+// their ORIGINAL indices on the host.
+static int sor_core(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double stddev_mul, int32_t *out_idx, size_t *n_out, float *out_mean_dist,
+                    bool want_cloud, ope_cloud **out_cloud) {
+  if (n_out) *n_out = 0;
+  if (out_cloud) *out_cloud = nullptr;
   const size_t n = cloud->n;
-  if (n == 0) return OPE_OK;
+  if (n == 0) return want_cloud ? select_cloud_device(ctx, cloud, nullptr, 0, out_cloud) : OPE_OK;
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<float> dist(n, 0.0f);
+  float *d_dist = nullptr;
+  OPE_HIP(ctx, hipMalloc((void **)&d_dist, 4 * n));
+  struct FreeDist { float *p; ~FreeDist() { if (p) (void)hipFree(p); } } free_dist{d_dist};
   if (cloud->n_valid > 0) {
     TraceRange r(ctx, "sor");
     ope_index *ix = nullptr;
-    int rc = ope_index_build(ctx, cloud, nullptr, &ix);
+    ope_index_params ip;
+    ope_index_default_params(&ip);
+    ip.grid = 0;   // this index serves one k-NN pass
+    int rc = ope_index_build(ctx, cloud, &ip, &ix);
     if (rc != OPE_OK) return rc;
-    float *d_dist = nullptr;
-    hipError_t e = hipMalloc((void **)&d_dist, 4 * n);
-    if (e == hipSuccess) {
+    hipError_t e = hipSuccess;
+    {
       const int nblocks = (int)std::min<size_t>((n + kKnnBlock - 1) / kKnnBlock, 8192);
       // algorithmic bytes, by analogy with the normals: read the point, gather k neighbours, write one float
       KernelTimer kt(ctx, "sor_mean_distance_kernel", (double)cloud->n_valid * (12.0 + 12.0 * (mean_k + 1) + 4.0));
@@ -308,24 +357,79 @@ extern "C" int ope_statistical_outlier_removal(ope_ctx *ctx, const ope_cloud *cl
       e = hipMemcpyAsync(dist.data(), d_dist, 4 * n, hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
-    if (d_dist) (void)hipFree(d_dist);
     ope_index_free(ix);
     if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_statistical_outlier_removal: ") + hipGetErrorString(e));
+  } else {
+    OPE_HIP(ctx, hipMemsetAsync(d_dist, 0, 4 * n, ctx->stream));
   }
   // mean and standard deviation of the distance vector: the reference's own sequential double sums over the points in
-  // input order (4 bytes per point through the host: the survivors' indices take the same way out)
+  // input order (4 bytes per point through the host)
   double sum = 0.0, sq_sum = 0.0;
   for (size_t i = 0; i < n; ++i) { sum += dist[i]; sq_sum += (double)dist[i] * (double)dist[i]; }
   const double valid = (double)cloud->n_valid;
   const double mean = sum / valid;
   const double variance = (sq_sum - sum * sum / valid) / (valid - 1.0);
   const double thr = mean + stddev_mul * std::sqrt(variance);
-  size_t m = 0;
-  for (size_t i = 0; i < n; ++i)
-    if (!((double)dist[i] > thr)) out_idx[m++] = (int32_t)i;   // non-finite points carry distance 0 and pass (PCL quirk)
-  *n_out = m;
   if (out_mean_dist) std::memcpy(out_mean_dist, dist.data(), 4 * n);
-  return OPE_OK;
+  if (!want_cloud) {
+    size_t m = 0;
+    for (size_t i = 0; i < n; ++i)
+      if (!((double)dist[i] > thr)) out_idx[m++] = (int32_t)i;   // non-finite points carry distance 0 and pass (PCL quirk)
+    *n_out = m;
+    return OPE_OK;
+  }
+  // the inliers stay on the device: flags from the same comparison, compacted in input order
+  unsigned char *d_flags = nullptr;
+  int32_t *d_sel = nullptr;
+  unsigned int *d_count = nullptr;
+  void *d_tmp = nullptr;
+  unsigned int count = 0;
+  hipError_t e = hipMalloc((void **)&d_flags, n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_sel, 4 * n);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_count, 4);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(sor_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_dist, (uint32_t)n, thr, d_flags);
+    rocprim::counting_iterator<int32_t> iota(0);
+    size_t tb = 0;
+    e = rocprim::select(nullptr, tb, iota, d_flags, d_sel, d_count, n, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tb, 16));
+    if (e == hipSuccess) e = rocprim::select(d_tmp, tb, iota, d_flags, d_sel, d_count, n, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && count && out_idx) e = hipMemcpyAsync(out_idx, d_sel, 4 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream);
+  }
+  int rc = e == hipSuccess ? select_cloud_device(ctx, cloud, d_sel, count, out_cloud)
+                           : set_err(ctx, OPE_EHIP, std::string("ope_statistical_outlier_removal_cloud: ") + hipGetErrorString(e));
+  for (void *p : {(void *)d_flags, (void *)d_sel, (void *)d_count, d_tmp})
+    if (p) (void)hipFree(p);
+  if (rc == OPE_OK && n_out) *n_out = count;
+  return rc;
+}
+
+extern "C" int ope_statistical_outlier_removal(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double stddev_mul,
+                                               int32_t *out_idx, size_t *n_out, float *out_mean_dist) {
+  if (!ctx || !cloud || !out_idx || !n_out || mean_k < 1 || mean_k + 1 > kKnnMaxK)
+    return set_err(ctx, OPE_EINVAL, "ope_statistical_outlier_removal: bad argument (1 <= mean_k <= 31)");
+  return sor_core(ctx, cloud, mean_k, stddev_mul, out_idx, n_out, out_mean_dist, false, nullptr);
+}
+
+extern "C" int ope_statistical_outlier_removal_cloud(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double stddev_mul, ope_cloud **out,
+                                                     int32_t *out_idx, size_t *n_out) {
+  if (!ctx || !cloud || !out || mean_k < 1 || mean_k + 1 > kKnnMaxK)
+    return set_err(ctx, OPE_EINVAL, "ope_statistical_outlier_removal_cloud: bad argument (1 <= mean_k <= 31)");
+  return sor_core(ctx, cloud, mean_k, stddev_mul, out_idx, n_out, nullptr, true, out);
+}
+
+extern "C" int ope_pass_through_cloud(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], ope_cloud **out, int32_t *out_idx,
+                                      size_t *n_out) {
+  if (!ctx || !cloud || !lo || !hi || !out) return set_err(ctx, OPE_EINVAL, "ope_pass_through_cloud: bad argument");
+  return box_filter_cloud(ctx, cloud, lo, hi, out, out_idx, n_out, "ope_pass_through_cloud");
+}
+
+extern "C" int ope_remove_nan_cloud(ope_ctx *ctx, const ope_cloud *cloud, ope_cloud **out, int32_t *out_idx, size_t *n_out) {
+  if (!ctx || !cloud || !out) return set_err(ctx, OPE_EINVAL, "ope_remove_nan_cloud: bad argument");
+  const float lo[3] = {-INFINITY, -INFINITY, -INFINITY}, hi[3] = {INFINITY, INFINITY, INFINITY};
+  return box_filter_cloud(ctx, cloud, lo, hi, out, out_idx, n_out, "ope_remove_nan_cloud");
 }
 
 extern "C" int ope_reject_pairs(ope_ctx *ctx, int kind, const float *a, const float *b, size_t n, double threshold, unsigned char *keep) {

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "bvh_traverse.hpp"
+#include "lm_solve.hpp"
 
 namespace ope {
 
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
-    const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list) {
+    const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list,
+    float *__restrict__ knn_rk) {
   if (st->done) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   else if (threadIdx.x < 15) s_const[threadIdx.x] = (float)st->pivot[threadIdx.x - 12];
   else if (threadIdx.x == 15) s_const[15] = best0;
   __syncthreads();
+  if (MODE == 2 && knn_rk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) const_cast<IcpState *>(st)->knn_acc_flag = 1;
   const bool rej_sn = NRM && st->use_surface_normal_rej;
   const bool rej_so = NRM && st->use_self_occluded_rej;
   // the LM estimator (lm.hip) re-reads the matched target points: corr_match then holds their POSITION in the index
@@ -266,9 +269,39 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       // register list of KREG >= k entries: the k nearest are the first k of the KREG nearest
       constexpr int K = KREG;
       KnnRegVisitor<K> v;
-      v.init(active);
-      bvh_traverse(tgt, x, y, z, v, stk, BLOCK, active ? hint[i] : 0u);
-      if (active) hint[i] = v.leaf;
+      // Search bound from the previous launch: the K list entries of that launch lay within sqrt(rk) of the query as it
+      // was then, so they lie within sqrt(rk) + |displacement| of the query now, and so does this launch's K-th
+      // neighbour: only points inside that ball can enter the list.  Exact (the bound is inflated past every fp32
+      // rounding of the distances it is compared with); should a list still come back short, that lane searches again
+      // without a bound.  Insertions and box tests for everything beyond the ball fall away: normal shooting k = 20 on C3
+      // spends most of its time on list insertions of points that do not stay in the list.
+      float bound0 = INFINITY;
+      if (knn_rk != nullptr && active && st->have_prev) {
+        const float rk = knn_rk[i];
+        if (rk < 3.0e38f) {
+          const float ox = xform_row(st->Fprev + 0, s.x, s.y, s.z), oy = xform_row(st->Fprev + 4, s.x, s.y, s.z), oz = xform_row(st->Fprev + 8, s.x, s.y, s.z);
+          const float delta = sqrtf(sq_dist3(x - ox, y - oy, z - oz));
+          const float b = sqrtf(rk) * 1.00001f + delta * 1.00001f + 1e-6f * (fabsf(x) + fabsf(y) + fabsf(z)) + 1e-30f;
+          bound0 = b * b * 1.00001f;
+        }
+      }
+      const uint32_t h0 = active ? hint[i] : 0u;
+      bool todo = active;
+      for (;;) {
+        if (todo) {
+          v.init(true, bound0);
+          bvh_traverse(tgt, x, y, z, v, stk, BLOCK, h0);
+        }
+        const bool retry = todo && bound0 < 3.0e38f && v.count < K;   // (cannot happen while the bound holds; kept for exactness)
+        if (__ballot(retry) == 0ull) break;
+        todo = retry;
+        bound0 = INFINITY;
+      }
+      if (!active) v.init(false);
+      if (active) {
+        hint[i] = v.leaf;
+        if (knn_rk != nullptr) knn_rk[i] = v.count >= K ? v.d[K - 1] : INFINITY;
+      }
       // among the k nearest, the one with the smallest squared distance to the line (s, n)
       // (…normal_shooting_weighted.hpp:115-135; cross product in double)
       double min_dist = 1.79769313486231570815e308;
@@ -330,7 +363,12 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     }
     add_query_sums<NRM>(s_red[threadIdx.x >> 6], (lds_cfloat_ptr)s_const, lane_id, ok, p2p, x, y, z, tgt.pts[ok ? pos : 0],
                         (NRM && p2p) ? tgt.nrm[ok ? pos : 0] : make_float4(0.f, 0.f, 0.f, 0.f), d2);
-    if (lane_id == 0 && !oct) chunk_cost[chunk] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
+    // the chunk's cost for the next plan: its per-lane duration, or, walked by 8-lane groups, the duration of its first
+    // slot scaled to what the per-lane walk would take (so that no launch has to give up group walks just to measure)
+    if (lane_id == 0 && (!oct || sub == 0u)) {
+      const uint32_t dur = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
+      chunk_cost[chunk] = oct ? (uint32_t)((float)dur * (1.0f / kOctSlotShare)) : dur;
+    }
   }
 
   // wave slots -> block partial, fixed order
@@ -892,6 +930,11 @@ __device__ __forceinline__ void icp_update_lane(IcpState *st, const double *S, c
   float Tf[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { Tf[i] = (float)Tk[i]; st->Tk[i] = (double)Tf[i]; }
+  // k-NN runs: the transform the accumulate launch behind these sums searched with (see icp_accumulate_kernel, MODE 2)
+#pragma unroll
+  for (int i = 0; i < 12; ++i) st->Fprev[i] = st->Ff[i];
+  st->have_prev = st->knn_acc_flag;
+  st->knn_acc_flag = 0;
   // final_transformation_ = transformation_ * final_transformation_ (icp_mod.hpp:249), kept in fp64
   double Fn[16];
 #pragma unroll
@@ -1032,6 +1075,31 @@ __global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, double *S,
   if ((int)threadIdx.x < nsums) S[threadIdx.x] = 0.0;
 }
 
+// OPE_EST_POINT_TO_PLANE_LM: the Levenberg-Marquardt minimisation on the 91 sums of lm_stats_kernel (lm.hip, lm_solve.hpp)
+// and the update step in one launch, one lane: nothing comes back to the host between two iterations.  S: the 17 sums of the
+// accumulate launch (n and the MSE feed the convergence test); both sum buffers are left at zero.
+__global__ __launch_bounds__(64) void icp_lm_update_kernel(IcpState *st, double *S, double *stats) {
+  if (st->done) return;
+  __shared__ double s_S[kNumSumsMax];
+  __shared__ LmQuad s_q;
+  __shared__ IcpState s_st;
+  __shared__ float s_Tk[16];
+  state_to_lds(&s_st, st);
+  if ((int)threadIdx.x < kNumSumsMax) s_S[threadIdx.x] = (int)threadIdx.x < kNumSums ? S[threadIdx.x] : 0.0;
+  lm_load_stats(stats, s_q);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lm_minimize_lane(s_q, (long long)s_S[0], s_Tk);
+    icp_update_lane(&s_st, s_S, s_Tk);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < kNumSumsMax) s_st.S[threadIdx.x] = 0.0;   // S may be the state's own array
+  __syncthreads();
+  state_to_lds(st, &s_st);
+  if ((int)threadIdx.x < kNumSums) S[threadIdx.x] = 0.0;
+  for (int k = threadIdx.x; k < 91; k += blockDim.x) stats[k] = 0.0;
+}
+
 // ------------------------------------------------------------------------------------------
 // Peer-to-peer exchange of the sums and the update step in ONE launch (sharded runs on one node).
 // Thread w < 2 * nsums sends half w & 1 of sum w >> 1: an 8-byte word {32 data bits, sequence number} stored (relaxed,
@@ -1043,10 +1111,10 @@ __global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, double *S,
 // other parity, and it cannot be two ahead because it needs every peer's words of the exchange in between.
 // A peer that does not deliver within `timeout_ticks` (100 MHz ticks) ends the run with comm_error set: the kernel
 // always terminates.
-__global__ __launch_bounds__(128) void icp_p2p_update_kernel(IcpState *st, double *S, int nsums, P2pView pv, uint32_t seq,
+__global__ __launch_bounds__(256) void icp_p2p_update_kernel(IcpState *st, double *S, int nsums, P2pView pv, uint32_t seq,
                                                             unsigned long long timeout_ticks, int do_update, double *out_sums) {
-  if (do_update && st->done) return;
-  __shared__ double s_S[kNumSumsMax];
+  if (st != nullptr && st->done) return;   // (st == nullptr: the self-test at communicator set-up)
+  __shared__ double s_S[kP2pMaxSums];
   __shared__ IcpState s_st;
   __shared__ uint32_t s_half[kP2pMaxRanks][kP2pSlotWords];
   __shared__ int s_fail;
@@ -1076,7 +1144,7 @@ __global__ __launch_bounds__(128) void icp_p2p_update_kernel(IcpState *st, doubl
     }
   }
   __syncthreads();
-  if (t < kNumSumsMax) {
+  if (t < kP2pMaxSums) {
     double acc = 0.0;
     if (t < nsums)
       for (int r = 0; r < pv.nranks; ++r) acc += __hiloint2double((int)s_half[r][2 * t + 1], (int)s_half[r][2 * t]);
@@ -1084,8 +1152,9 @@ __global__ __launch_bounds__(128) void icp_p2p_update_kernel(IcpState *st, doubl
   }
   __syncthreads();
   const bool failed = s_fail != 0;
-  if (!do_update) {   // self-test at communicator set-up: hand the totals (or NaNs) back
+  if (!do_update) {   // the exchange alone (self-test at set-up; the LM estimator's sums): hand the totals (or NaNs) back
     if (t < nsums) out_sums[t] = failed ? __longlong_as_double(0x7ff8000000000000ll) : s_S[t];
+    if (failed && st != nullptr && t == 0) { st->comm_error = 1; st->done = 1; }
     return;
   }
   if (failed) {
@@ -1260,17 +1329,17 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
                            const BvhView &tgt, const BvhView &srcix, const IcpState *st, double *partials,
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
                            const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
-                           int k_normal_shooting, double *S_atomic, const uint32_t *slot_list) {
+                           int k_normal_shooting, double *S_atomic, const uint32_t *slot_list, float *knn_rk) {
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS)                                                                       \
   hipLaunchKernelGGL((icp_accumulate_kernel<M, N, R>), dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, \
-                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list)
+                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk)
   if (mode == 0 && !recip && packet) {
     if (nrm)
       hipLaunchKernelGGL((icp_accumulate_kernel<0, true, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list);
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk);
     else
       hipLaunchKernelGGL((icp_accumulate_kernel<0, false, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list);
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk);
     return;
   }
   if (mode == 0) {
@@ -1282,7 +1351,7 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
     // register list takes ~0.5 ms, and held the kernel at two waves per SIMD
 #define OPE_LAUNCH_NS(KR)                                                                                                          \
   hipLaunchKernelGGL((icp_accumulate_kernel<2, true, false, false, KR>), dim3(nblocks), dim3(kKnnBlock), 0, stream, src, tgt, srcix, st, \
-                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list)
+                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk)
     const int k = k_normal_shooting;
     if (k == 10) OPE_LAUNCH_NS(10);
     else if (k <= 4) OPE_LAUNCH_NS(4);
@@ -1333,7 +1402,11 @@ void launch_icp_reduce_update(hipStream_t stream, IcpState *st, const double *pa
 
 void launch_icp_p2p_update(hipStream_t stream, IcpState *st, double *S, int nsums, const P2pView &pv, uint32_t seq,
                            unsigned long long timeout_ticks, bool do_update, double *out_sums) {
-  hipLaunchKernelGGL(icp_p2p_update_kernel, dim3(1), dim3(128), 0, stream, st, S, nsums, pv, seq, timeout_ticks, do_update ? 1 : 0, out_sums);
+  hipLaunchKernelGGL(icp_p2p_update_kernel, dim3(1), dim3(256), 0, stream, st, S, nsums, pv, seq, timeout_ticks, do_update ? 1 : 0, out_sums);
+}
+
+void launch_icp_lm_update(hipStream_t stream, IcpState *st, double *S, double *stats) {
+  hipLaunchKernelGGL(icp_lm_update_kernel, dim3(1), dim3(64), 0, stream, st, S, stats);
 }
 
 void launch_icp_update(hipStream_t stream, IcpState *st, double *S, int nsums, const float *Tk_ext) {

@@ -81,12 +81,17 @@ struct IcpState {
   int iterations, converged, state, done;
   int corr_mode, k_normal_shooting, use_surface_normal_rej, use_self_occluded_rej, use_reciprocal, estimator;
   int comm_error, pad2_;   // set by the peer-to-peer exchange when a peer's sums did not arrive in time (run ends)
+  // k-NN runs (normal shooting): the transform the previous accumulate launch searched with, so that a query's k-th
+  // neighbour distance of that launch plus its own displacement since bounds this launch's search (icp_accumulate_kernel)
+  float Fprev[12];
+  int have_prev;       // Fprev and the stored k-th distances belong together (set by the update that follows an accumulate launch)
+  int knn_acc_flag;    // written by a k-NN accumulate launch: "the stored k-th distances are of the current transform"
 };
 
 // Peer-to-peer exchange of the sums (comm.cpp, icp_p2p_update_kernel): every rank owns one slot per parity in every
 // rank's buffer; a slot is 2 * kP2pMaxSums 8-byte words {low: 32 data bits, high: sequence number of the exchange}.
 constexpr int kP2pMaxRanks = 8;
-constexpr int kP2pMaxSums = 44;
+constexpr int kP2pMaxSums = 96;   // 17 / 44 sums of the SVD / LLS estimators, 91 of the LM estimator
 constexpr int kP2pSlotWords = 2 * kP2pMaxSums;
 constexpr size_t kP2pBufferBytes = sizeof(unsigned long long) * 2 * kP2pMaxRanks * kP2pSlotWords;
 struct P2pView {
@@ -94,6 +99,7 @@ struct P2pView {
   int nranks, rank;
 };
 
+constexpr float kOctSlotShare = 0.42f;   // one of a group-walked chunk's eight slots lasts about this share of the chunk's per-lane duration (tools/chain_probe.py: 0.39-0.53)
 constexpr int kNumSums = 17;
 constexpr int kNumSumsMax = 44;  // + 21 (upper triangle of AᵀA) + 6 (Aᵀb) for the point-to-plane estimator
 constexpr int kAccBlock = 512;       // threads per block of the accumulate kernel
@@ -127,6 +133,7 @@ struct ope_ctx {
   // ICP run state
   ope::IcpState *d_state = nullptr;
   double *d_partials = nullptr;   // [kNumSumsMax][kAccMaxBlocks]
+  double *d_lm_stats = nullptr;   // 96 doubles: the 91 sums of the LM estimator (lm.hip)
   uint32_t *d_work_counter = nullptr;  // small device scratch block: word 8 = number of chunks walked by 8-lane groups
   int32_t *d_corr_match = nullptr;  // per sorted query: ORIGINAL target index or -1
   float *d_corr_d2 = nullptr;
@@ -140,6 +147,8 @@ struct ope_ctx {
   int acc_launches = 0;
   int64_t kernel_launches[OPE_KERNEL_KINDS] = {0, 0, 0, 0};   // per search kernel, this run (ope_icp_kernel_launches)
   uint32_t *d_hint = nullptr;       // per sorted query: leaf (heap id) of the previous iteration's match, 0 = none
+  float *d_knn_rk = nullptr;        // k-NN runs: per sorted query the squared distance of the last list entry of the previous launch (+inf: none)
+  size_t knn_rk_cap = 0;
   // grid path of the 1-NN search (icp_accumulate_grid_kernel)
   uint32_t *d_ghint = nullptr;      // per sorted query: 1 + position of the previous match in the grid-sorted points, 0 = none
   uint32_t *d_qorder = nullptr;     // query order of the launch: [grid-class queries | tree-class queries]
@@ -289,6 +298,9 @@ struct HostBvh {
   std::vector<float> pts4;    // n*4 (x,y,z, original index bits)
   std::vector<float> nrm4;    // n*4 or empty
 };
+// sampling.hip: a new cloud from n_sel ORIGINAL indices (device array) of a device-resident cloud
+int select_cloud_device(ope_ctx *ctx, const ope_cloud *cloud, const int32_t *d_idx, size_t n_sel, ope_cloud **out);
+
 void build_bvh_host(const float *xyz, const int32_t *ids, const float *nrm, size_t n, int leaf_size, HostBvh &out);
 
 }  // namespace ope

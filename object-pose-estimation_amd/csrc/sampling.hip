@@ -98,7 +98,6 @@ __device__ __forceinline__ uint32_t count_costlier(const uint32_t *cost_sorted_d
 // plan_info[5] = n_alone, the next-costliest chunks that get a wave to themselves: those at or above the fair share L of
 //   the waves that are left, L = (work not yet given away) / (waves not yet given away), iterated to its fixed point.  A
 //   group-walked chunk counts as kOctWork x its per-lane cost (eight slots of about a third of the duration each).
-constexpr float kOctSlotShare = 0.42f;          // one of a group-walked chunk's eight slots lasts about this share of the chunk's per-lane duration (tools/chain_probe.py: 0.39-0.53)
 constexpr double kOctWork = 8.0 * kOctSlotShare;  // wave-time of a group-walked chunk relative to its per-lane walk
 bool g_plan_no_alone = false;   // developer A/B switch (OPE_NO_ALONE, set by api.hip in DEVELOPER builds)
 __device__ __forceinline__ double block_sum_range(const uint32_t *v, uint32_t a, uint32_t b, double *s_sum) {
@@ -460,11 +459,115 @@ hipError_t concat_device(hipStream_t stream, const CloudView &a, const float *d_
 
 }  // namespace ope
 
+// ---------------------------------------------------------------------------------------------------------------------
+// A new cloud from ORIGINAL indices of a device-resident one, without a trip through the host (what the filters either side
+// of the path hand on: PassThrough -> StatisticalOutlierRemoval -> UniformSampling, rosinterface.cpp:212-213,
+// poseestimator.cpp:141-145).  The new cloud's original order is the order of `idx`; its points are re-ordered along the
+// Morton curve of ITS bounding box like an uploaded cloud's.
+namespace ope {
+
+__global__ __launch_bounds__(256) void inverse_perm_kernel(CloudView c, uint32_t *__restrict__ inv) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p < c.n) inv[(uint32_t)__float_as_int(c.xyzw[p].w)] = p;
+}
+
+__global__ __launch_bounds__(256) void select_gather_kernel(CloudView c, const uint32_t *__restrict__ inv, const int32_t *__restrict__ idx, uint32_t n_sel,
+                                                            float *__restrict__ raw, uint32_t *__restrict__ mn, uint32_t *__restrict__ mx,
+                                                            uint32_t *__restrict__ n_finite) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  float v[3] = {0.f, 0.f, 0.f};
+  bool fin = false;
+  if (j < n_sel) {
+    const uint32_t p = inv[(uint32_t)idx[j]];
+    const float4 q = c.xyzw[p];
+    fin = p < c.n_valid;
+    v[0] = q.x; v[1] = q.y; v[2] = q.z;
+    raw[3 * (size_t)j] = q.x; raw[3 * (size_t)j + 1] = q.y; raw[3 * (size_t)j + 2] = q.z;
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const uint32_t u = (uint32_t)__float_as_int(v[d]);
+    const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    uint32_t lo = fin ? key : 0xffffffffu, hi = fin ? key : 0u;
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+      hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+    }
+    if ((threadIdx.x & 63u) == 0) { atomicMin(mn + d, lo); atomicMax(mx + d, hi); }
+  }
+  const unsigned long long m = __ballot(fin);
+  if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_finite, (uint32_t)__popcll(m));
+}
+
+// normals of the selected points, in the new cloud's sorted order
+__global__ __launch_bounds__(256) void select_normals_kernel(const float4 *__restrict__ nrm_old, const uint32_t *__restrict__ inv, const int32_t *__restrict__ idx,
+                                                             const int32_t *__restrict__ perm_new, uint32_t n_sel, float4 *__restrict__ nrm_new) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p < n_sel) nrm_new[p] = nrm_old[inv[(uint32_t)idx[perm_new[p]]]];
+}
+
+// d_idx: n_sel ORIGINAL indices of `cloud`, on the device.  Synchronises the stream (the bounding box comes back to the host).
+int select_cloud_device(ope_ctx *ctx, const ope_cloud *cloud, const int32_t *d_idx, size_t n_sel, ope_cloud **out) {
+  *out = nullptr;
+  ope_cloud *c = new ope_cloud();
+  c->ctx = ctx;
+  c->n = n_sel;
+  c->host_valid = false;
+  uint32_t *d_inv = nullptr, *d_mm = nullptr;
+  float *d_raw = nullptr;
+  int32_t *d_perm = nullptr;
+  const CloudView cv = cloud->view();
+  hipError_t e = hipMalloc((void **)&c->d_xyzw, sizeof(float4) * std::max<size_t>(n_sel, 1));
+  if (e == hipSuccess && n_sel) e = hipMalloc((void **)&d_inv, 4 * std::max<size_t>(cloud->n, 1));
+  if (e == hipSuccess && n_sel) e = hipMalloc((void **)&d_raw, 12 * n_sel);
+  if (e == hipSuccess && n_sel) e = hipMalloc((void **)&d_perm, 4 * n_sel);
+  if (e == hipSuccess && n_sel) e = hipMalloc((void **)&d_mm, 48);
+  uint32_t res[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0u, 0u, 0u, 0, 0u, 0, 0, 0};
+  if (e == hipSuccess && n_sel) {
+    e = hipMemcpyAsync(d_mm, res, sizeof res, hipMemcpyHostToDevice, ctx->stream);
+    hipLaunchKernelGGL(inverse_perm_kernel, dim3((unsigned)((cloud->n + 255) / 256)), dim3(256), 0, ctx->stream, cv, d_inv);
+    hipLaunchKernelGGL(select_gather_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, ctx->stream, cv, d_inv, d_idx, (uint32_t)n_sel, d_raw,
+                       d_mm, d_mm + 4, d_mm + 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(res, d_mm, sizeof res, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  if (e == hipSuccess && n_sel) {
+    auto unkey = [](uint32_t k) { const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; std::memcpy(&f, &u, 4); return f; };
+    c->n_valid = res[8];
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, inv3[3];
+    if (c->n_valid > 0)
+      for (int d = 0; d < 3; ++d) { lo[d] = unkey(res[d]); hi[d] = unkey(res[4 + d]); }
+    std::memcpy(c->bb_lo, lo, sizeof lo);
+    std::memcpy(c->bb_hi, hi, sizeof hi);
+    for (int d = 0; d < 3; ++d) inv3[d] = (hi[d] > lo[d]) ? 1023.999f / (hi[d] - lo[d]) : 0.f;
+    e = morton_order_device(ctx->stream, d_raw, n_sel, lo, inv3, c->d_xyzw, d_perm);
+    if (e == hipSuccess && cloud->d_nrm) {
+      e = hipMalloc((void **)&c->d_nrm, sizeof(float4) * n_sel);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(select_normals_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, ctx->stream, cloud->d_nrm, d_inv, d_idx, d_perm,
+                           (uint32_t)n_sel, c->d_nrm);
+        e = hipStreamSynchronize(ctx->stream);
+      }
+    }
+  }
+  for (void *p : {(void *)d_inv, (void *)d_raw, (void *)d_perm, (void *)d_mm})
+    if (p) (void)hipFree(p);
+  if (e != hipSuccess) {
+    ope_cloud_free(c);
+    return set_err(ctx, OPE_EHIP, std::string("cloud selection: ") + hipGetErrorString(e));
+  }
+  *out = c;
+  return OPE_OK;
+}
+
+}  // namespace ope
+
 using namespace ope;
 
-extern "C" int ope_uniform_sampling(ope_ctx *ctx, const ope_cloud *cloud, float leaf, int32_t *out_idx, size_t *n_out) {
-  if (!ctx || !cloud || !out_idx || !n_out || !(leaf > 0)) return set_err(ctx, OPE_EINVAL, "ope_uniform_sampling: bad argument");
-  *n_out = 0;
+// the survivors' ORIGINAL indices, ascending voxel key, left on the device (*d_out_ret, caller frees); count on the host
+static int uniform_sampling_dev(ope_ctx *ctx, const ope_cloud *cloud, float leaf, int32_t **d_out_ret, unsigned int *count_ret) {
+  *d_out_ret = nullptr;
+  *count_ret = 0;
   const size_t n = cloud->n;
   if (n == 0 || cloud->n_valid == 0) return OPE_OK;
   OPE_HIP(ctx, hipSetDevice(ctx->device));
@@ -512,12 +615,62 @@ extern "C" int ope_uniform_sampling(ope_ctx *ctx, const ope_cloud *cloud, float 
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess && count) e = hipMemcpy(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost);
   }
-  for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_vals, (void *)d_vals2, (void *)d_win, (void *)d_out,
-                  (void *)d_flags, (void *)d_count, d_tmp})
+  for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_vals, (void *)d_vals2, (void *)d_win, (void *)d_flags, (void *)d_count, d_tmp})
     if (p) (void)hipFree(p);
+  if (e != hipSuccess) {
+    if (d_out) (void)hipFree(d_out);
+    return set_err(ctx, OPE_EHIP, std::string("ope_uniform_sampling: ") + hipGetErrorString(e));
+  }
+  *d_out_ret = d_out;
+  *count_ret = count;
+  return OPE_OK;
+}
+
+extern "C" int ope_uniform_sampling(ope_ctx *ctx, const ope_cloud *cloud, float leaf, int32_t *out_idx, size_t *n_out) {
+  if (!ctx || !cloud || !out_idx || !n_out || !(leaf > 0)) return set_err(ctx, OPE_EINVAL, "ope_uniform_sampling: bad argument");
+  *n_out = 0;
+  int32_t *d_out = nullptr;
+  unsigned int count = 0;
+  const int rc = uniform_sampling_dev(ctx, cloud, leaf, &d_out, &count);
+  if (rc != OPE_OK) return rc;
+  hipError_t e = hipSuccess;
+  if (count) e = hipMemcpy(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost);
+  if (d_out) (void)hipFree(d_out);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_uniform_sampling: ") + hipGetErrorString(e));
   *n_out = count;
   return OPE_OK;
+}
+
+extern "C" int ope_uniform_sampling_cloud(ope_ctx *ctx, const ope_cloud *cloud, float leaf, ope_cloud **out, int32_t *out_idx, size_t *n_out) {
+  if (!ctx || !cloud || !out || !(leaf > 0)) return set_err(ctx, OPE_EINVAL, "ope_uniform_sampling_cloud: bad argument");
+  *out = nullptr;
+  if (n_out) *n_out = 0;
+  int32_t *d_out = nullptr;
+  unsigned int count = 0;
+  int rc = uniform_sampling_dev(ctx, cloud, leaf, &d_out, &count);
+  if (rc != OPE_OK) return rc;
+  hipError_t e = hipSuccess;
+  if (count && out_idx) e = hipMemcpyAsync(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream);
+  rc = e == hipSuccess ? select_cloud_device(ctx, cloud, d_out, count, out) : set_err(ctx, OPE_EHIP, std::string("ope_uniform_sampling_cloud: ") + hipGetErrorString(e));
+  if (d_out) (void)hipFree(d_out);
+  if (rc == OPE_OK && n_out) *n_out = count;
+  return rc;
+}
+
+extern "C" int ope_cloud_select(ope_ctx *ctx, const ope_cloud *cloud, const int32_t *idx, size_t n, ope_cloud **out) {
+  if (!ctx || !cloud || !out || (n && !idx) || n > (size_t)0x7fffffff) return set_err(ctx, OPE_EINVAL, "ope_cloud_select: bad argument");
+  *out = nullptr;
+  for (size_t j = 0; j < n; ++j)
+    if (idx[j] < 0 || (size_t)idx[j] >= cloud->n) return set_err(ctx, OPE_EINVAL, "ope_cloud_select: index out of range");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  int32_t *d_idx = nullptr;
+  if (n) {
+    OPE_HIP(ctx, hipMalloc((void **)&d_idx, 4 * n));
+    const hipError_t e = hipMemcpyAsync(d_idx, idx, 4 * n, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d_idx); return set_err(ctx, OPE_EHIP, std::string("ope_cloud_select: ") + hipGetErrorString(e)); }
+  }
+  const int rc = select_cloud_device(ctx, cloud, d_idx, n, out);
+  if (d_idx) (void)hipFree(d_idx);
+  return rc;
 }

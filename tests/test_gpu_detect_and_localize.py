@@ -23,11 +23,11 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 EXE = os.path.join(ROOT, "object-pose-estimation_amd", "build", "detect_and_localize")
 
 
-def _run(model_path, scene_paths, seed):
+def _run(model_path, scene_paths, seed, extra=()):
     if not os.path.exists(EXE):
         import __graft_entry__ as g
         g.build()
-    r = subprocess.run([EXE, model_path, *scene_paths, "--seed", str(seed)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([EXE, model_path, *scene_paths, "--seed", str(seed), *extra], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     frames = []
     for line in r.stdout.splitlines():
@@ -66,16 +66,17 @@ def _fine_inputs_on_gpu(ctx, cloud):
     return keys[ok], nrm[ok]
 
 
-def _oracle_fine(sk, sn, tk, tn):
+def _oracle_fine(sk, sn, tk, tn, self_occluded=False):
     import oracle
     p = oracle.default_icp_params()
     p.max_iterations = 100; p.transformation_epsilon = 1e-8; p.euclidean_fitness_epsilon = 1e-8
     p.corr_mode = 1; p.k_normal_shooting = 20; p.use_surface_normal_rej = 1; p.surface_normal_thr = 0.7
+    p.use_self_occluded_rej = int(self_occluded); p.self_occluded_thr = 0.6      # poseestimator.cpp:289-292,335-337
     p.estimator = 0; p.acc_mode = 1; p.transform_mode = 1
     return oracle.icp(sk, tk, p, src_nrm=sn, tgt_nrm=tn)
 
 
-def _check(frames, model, scenes, seed, tol_coarse=2e-5, tol=1e-4, band=3e-2):
+def _check(frames, model, scenes, seed, tol_coarse=2e-5, tol=1e-4, band=3e-2, self_occluded=False):
     """Stage by stage, then end to end.
 
     The fine stage is a discrete dynamical system: normal shooting picks one of 20 candidates per point and the 8 mm
@@ -87,7 +88,7 @@ def _check(frames, model, scenes, seed, tol_coarse=2e-5, tol=1e-4, band=3e-2):
     import oracle
     ope = importlib.import_module("object-pose-estimation_amd")
     ctx = ope.Context(0)
-    pe = oracle.PoseEstimator(sacia_seed=seed)
+    pe = oracle.PoseEstimator(sacia_seed=seed, use_self_occluded=self_occluded)
     src = model.copy()          # the oracle's chain
     src_dev = model.copy()      # the façade's chain, replayed from its printed transforms
     aligned_dev = None
@@ -103,7 +104,7 @@ def _check(frames, model, scenes, seed, tol_coarse=2e-5, tol=1e-4, band=3e-2):
         # ---- fine stage on identical inputs
         sk, sn = _fine_inputs_on_gpu(ctx, aligned_dev)
         tk, tn = _fine_inputs_on_gpu(ctx, scene)
-        ref = _oracle_fine(sk, sn, tk, tn)
+        ref = _oracle_fine(sk, sn, tk, tn, self_occluded)
         assert _frob(fr["fine"], ref.T) < tol, (k, _frob(fr["fine"], ref.T), fr["icp_iterations"], ref.iterations)
         assert fr["icp_iterations"] == ref.iterations
         assert fr["fitness"] == pytest.approx(ref.fitness, rel=2e-3)
@@ -145,6 +146,23 @@ def test_c1_drill_model_two_frames_match_the_oracle_composite(tmp_path):
     axyz, argb = pcd.read_pcd(aligned_path)
     assert axyz.shape == model.shape and np.abs(axyz - src).max() < 1e-6     # the façade's own chain, replayed
     np.testing.assert_array_equal(argb, rgb)
+
+
+def test_c1_with_the_self_occluded_rejector_as_the_reference_adds_it(tmp_path):
+    """The reference adds CorrespondenceRejectorSelfOccludedNormal (threshold 0.6) to the fine ICP whenever PCL >= 1.7.2
+    (poseestimator.cpp:289-292,335-337); the facade class makes it a switch.  With the switch ON, through the
+    C++ facade, against the oracle composite with the same rejector: the scene fixture is the part of the drill that is
+    visible from the sensor origin, so the model's far side really is rejected (fewer correspondences than without)."""
+    model, rgb = pcd.read_pcd(os.path.join(GOLD, "drill_model_decimated.pcd"))
+    scene = np.load(os.path.join(GOLD, "drill_scene_c1.npz"))["scene"]
+    path = str(tmp_path / "scene1.pcd")
+    pcd.write_pcd(path, scene)
+    frames_on, _ = _run(os.path.join(GOLD, "drill_model_decimated.pcd"), [path], seed=1, extra=("--self-occluded",))
+    frames_off, _ = _run(os.path.join(GOLD, "drill_model_decimated.pcd"), [path], seed=1)
+    assert len(frames_on) == 1
+    _check(frames_on, model, [scene], seed=1, self_occluded=True)
+    assert _frob(frames_on[0]["coarse"], frames_off[0]["coarse"]) == 0.0          # the coarse stage does not know the switch
+    assert frames_on[0]["strength"] < frames_off[0]["strength"]                   # the rejector removed correspondences
 
 
 def test_dense_model_second_frame_skips_the_coarse_stage(tmp_path):

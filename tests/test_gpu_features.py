@@ -268,6 +268,52 @@ def test_voxel_grid_with_colours_equals_oracle(ctx, n, leaf):
     assert (got_rgb >> 24 == 0).all()
 
 
+def test_device_resident_filters_hand_on_the_same_points_as_the_host_forms(ctx):
+    """crop -> outlier removal -> key points as device-resident clouds (ope_*_cloud): at every stage the cloud that stays on
+    the GPU holds exactly the points the host form's indices select, in the same (original) order, with the same
+    bounding box and finite count — bit for bit — and the normals of a selected cloud are the selected normals."""
+    ope = load_pkg()
+    x = _cloud_with_holes(60_000, 5)
+    x[:40_000] = synth.scene_cloud(40_000)
+    c = ctx.upload(x)
+    # NaN removal
+    c1, i1 = ctx.remove_nan_cloud(c, want_idx=True)
+    np.testing.assert_array_equal(i1, oracle.remove_nan(x))
+    np.testing.assert_array_equal(ctx.download(c1), x[i1])
+    # pass-through on the result
+    lo, hi = [-0.1, -0.15, -0.1], [0.2, 0.1, 0.3]
+    c2, i2 = ctx.pass_through_cloud(c1, lo, hi, want_idx=True)
+    x1 = x[i1]
+    np.testing.assert_array_equal(i2, oracle.pass_through(x1, lo, hi))
+    np.testing.assert_array_equal(ctx.download(c2), x1[i2])
+    # statistical outlier removal
+    x2 = x1[i2]
+    c3, i3 = ctx.statistical_outlier_removal_cloud(c2, 30, 1.0, want_idx=True)
+    np.testing.assert_array_equal(i3, oracle.statistical_outlier_removal(x2, 30, 1.0))
+    np.testing.assert_array_equal(i3, ctx.statistical_outlier_removal(ctx.upload(x2), 30, 1.0))
+    np.testing.assert_array_equal(ctx.download(c3), x2[i3])
+    # uniform sampling
+    x3 = x2[i3]
+    c4, i4 = ctx.uniform_sampling_cloud(c3, 0.01, want_idx=True)
+    np.testing.assert_array_equal(i4, oracle.uniform_sampling(x3, 0.01))
+    np.testing.assert_array_equal(ctx.download(c4), x3[i4])
+    # everything downstream sees the same cloud as an upload of the same points would give
+    n_dev = ctx.normals(c4, 30)
+    n_up = ctx.normals(ctx.upload(x3[i4]), 30)
+    np.testing.assert_array_equal(n_dev[0], n_up[0])
+    # select: arbitrary order, repeats, normals carried
+    idx = np.array([5, 1, 1, 300, 7, len(x3[i4]) - 1], np.int32)
+    cs = ctx.select(c4, idx)
+    np.testing.assert_array_equal(ctx.download(cs), x3[i4][idx])
+    f_dev = ctx.fpfh(cs, 0.03)
+    cu = ctx.upload(x3[i4][idx], n_up[0][idx])
+    np.testing.assert_array_equal(f_dev, ctx.fpfh(cu, 0.03))
+    with pytest.raises(ope.OpeError):
+        ctx.select(c4, [len(x3[i4])])
+    empty, ie = ctx.pass_through_cloud(c4, [1, 1, 1], [0, 0, 0], want_idx=True)
+    assert empty.n == 0 and len(ie) == 0
+
+
 def test_voxel_grid_on_model_surface_and_refused_leaf(ctx):
     ope = load_pkg()
     m = synth.model_surface(100_000, 1)
