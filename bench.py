@@ -168,35 +168,46 @@ def main() -> int:
     cluster = None
     gt_inv = np.linalg.inv(synth.ground_truth_pose())
     if not args.no_coarse:
+        def front_end():
+            """One frame through the reference's steps in front of the ICP; every stage hands its survivors on as a
+            device-resident cloud (ope_*_cloud): no host round trip between the stages."""
+            lo_w, hi_w = synth.workspace_limits(0.01)
+            ctx.sync()
+            t_c = time.perf_counter()
+            stage = {}
+            frame = ctx.upload(scene)
+            t1 = time.perf_counter(); crop_c, _ = ctx.pass_through_cloud(frame, lo_w, hi_w)
+            t2 = time.perf_counter(); clus, _ = ctx.statistical_outlier_removal_cloud(crop_c, 30, 1.0)
+            t3 = time.perf_counter()
+            stage["frame"] = {"points": int(len(scene)), "upload_ms": (t1 - t_c) * 1e3, "pass_through_kept": int(crop_c.n), "pass_through_ms": (t2 - t1) * 1e3,
+                              "outlier_removal_kept": int(clus.n), "outlier_removal_ms": (t3 - t2) * 1e3}
+            feats, kclouds = [], []
+            for name, full in (("cluster", clus), ("model", ix.cloud)):
+                t1 = time.perf_counter(); kc, _ = ctx.uniform_sampling_cloud(full, 0.01)
+                t2 = time.perf_counter(); ctx.normals(kc, 30, fetch=False)
+                t3 = time.perf_counter(); feats.append(ctx.fpfh(kc, 0.03))
+                t4 = time.perf_counter()
+                stage[name] = {"points": int(full.n), "keypoints": int(kc.n), "uniform_sampling_ms": (t2 - t1) * 1e3,
+                               "normals_ms": (t3 - t2) * 1e3, "fpfh_ms": (t4 - t3) * 1e3}
+                kclouds.append(kc)
+            t5 = time.perf_counter()
+            # SAC-IA in the reference's direction: source = the model, target = the scene cluster (rosinterface.cpp:250 hands
+            # estimateFinalPose the loaded model as source); the ICP below runs scene -> model, so it starts from the inverse
+            kix = ctx.build_index(kclouds[0])
+            m2s, sac_err, sac_it = ctx.sacia(kclouds[1], feats[1], kclouds[0], kix, feats[0], ope.default_sacia_params(seed=1))
+            t6 = time.perf_counter()
+            return dict(stage=stage, total_ms=(t6 - t_c) * 1e3, sacia_ms=(t6 - t5) * 1e3, m2s=m2s, sac_err=sac_err, sac_it=sac_it, cluster=clus)
+
+        # the first frame pays for the lazy loading of every kernel it touches (~35 ms of the first upload alone); the reference's
+        # loop sees one frame after another, so the frame that is reported is the second one, the first one's total beside it
+        first = front_end()
         ctx.profile_kernels(True)
-        t_c = time.perf_counter()
-        stage = {}
-        # every stage hands its survivors on as a device-resident cloud (ope_*_cloud): no host round trip between the stages
-        frame = ctx.upload(scene)
-        lo_w, hi_w = synth.workspace_limits(0.01)
-        t1 = time.perf_counter(); crop_c, _ = ctx.pass_through_cloud(frame, lo_w, hi_w)
-        t2 = time.perf_counter(); cluster, _ = ctx.statistical_outlier_removal_cloud(crop_c, 30, 1.0)
-        t3 = time.perf_counter()
-        stage["frame"] = {"points": int(len(scene)), "upload_ms": (t1 - t_c) * 1e3, "pass_through_kept": int(crop_c.n), "pass_through_ms": (t2 - t1) * 1e3,
-                          "outlier_removal_kept": int(cluster.n), "outlier_removal_ms": (t3 - t2) * 1e3}
-        feats, kclouds = [], []
-        for name, full in (("cluster", cluster), ("model", ix.cloud)):
-            t1 = time.perf_counter(); kc, _ = ctx.uniform_sampling_cloud(full, 0.01)
-            t2 = time.perf_counter(); ctx.normals(kc, 30, fetch=False)
-            t3 = time.perf_counter(); feats.append(ctx.fpfh(kc, 0.03))
-            t4 = time.perf_counter()
-            stage[name] = {"points": int(full.n), "keypoints": int(kc.n), "uniform_sampling_ms": (t2 - t1) * 1e3,
-                           "normals_ms": (t3 - t2) * 1e3, "fpfh_ms": (t4 - t3) * 1e3}
-            kclouds.append(kc)
-        t5 = time.perf_counter()
-        # SAC-IA in the reference's direction: source = the model, target = the scene cluster (rosinterface.cpp:250 hands
-        # estimateFinalPose the loaded model as source); the ICP below runs scene -> model, so it starts from the inverse
-        kix = ctx.build_index(kclouds[0])
-        m2s, sac_err, sac_it = ctx.sacia(kclouds[1], feats[1], kclouds[0], kix, feats[0], ope.default_sacia_params(seed=1))
-        guess = np.linalg.inv(np.asarray(m2s, np.float64)).astype(np.float32)
-        t6 = time.perf_counter()
+        fe = front_end()
         ktimes = ctx.profile_kernels_read()
         ctx.profile_kernels(False)
+        assert np.array_equal(np.asarray(first["m2s"]), np.asarray(fe["m2s"]))      # same frame, same pose
+        stage, cluster, sac_err, sac_it = fe["stage"], fe["cluster"], fe["sac_err"], fe["sac_it"]
+        guess = np.linalg.inv(np.asarray(fe["m2s"], np.float64)).astype(np.float32)
         kroof = {}
         for kname, rec in sorted(ktimes.items()):
             gbs = rec["algorithmic_bytes"] / (rec["ms"] * 1e-3) / 1e9 if rec["ms"] > 0 else 0.0
@@ -206,14 +217,16 @@ def main() -> int:
         n_kp = stage["cluster"]["keypoints"] + stage["model"]["keypoints"]
         fp_ms = ktimes.get("spfh_kernel", {}).get("ms", 0.0) + ktimes.get("fpfh_kernel", {}).get("ms", 0.0)
         sa_ms = ktimes.get("sacia_error_kernel", {}).get("ms", 0.0)
-        coarse = {"total_ms": (t6 - t_c) * 1e3, "sacia_ms": (t6 - t5) * 1e3, "sacia_hypotheses": 400,
+        coarse = {"total_ms": fe["total_ms"], "first_frame_total_ms": first["total_ms"], "sacia_ms": fe["sacia_ms"], "sacia_hypotheses": 400,
                   "sacia_best_iteration": int(sac_it), "sacia_error": float(sac_err),
                   "pose_error_vs_ground_truth_frobenius": float(np.linalg.norm(guess.astype(np.float64) - gt_inv)),
                   "fpfh_points_per_s": n_kp / (fp_ms * 1e-3) if fp_ms > 0 else None,
                   "sacia_hypotheses_per_s": 400 / (sa_ms * 1e-3) if sa_ms > 0 else None,
                   "stages": stage, "kernels": kroof,
-                  "note": "stage times are host wall-clock incl. uploads, device index builds and read-backs; `kernels` are "
-                          "HIP-event times of the launches with the algorithmic bytes of SURVEY 8d; none of it is part of value"}
+                  "note": "total_ms: the second pass over the same frame (device-resident hand-over between the stages; host wall-clock incl. "
+                          "the frame's upload, device index builds and the read-backs that are left: sizes, outlier-removal distances, 33 x "
+                          "key points descriptors); first_frame_total_ms: the first pass, which also loads every kernel it touches; `kernels` "
+                          "are HIP-event times of the launches with the algorithmic bytes of SURVEY 8d; none of it is part of value"}
 
     if launched and guess is not None:
         # one initial pose for the whole job: every rank computed it from the same inputs, but the ranks must not
@@ -260,12 +273,15 @@ def main() -> int:
         dt = time.perf_counter() - t0
         km, kn = ctx.icp_profile_read() if profile else (0.0, 0)
         if profile:
+            timed.last_launch_ms = [round(float(v), 4) for v in ctx.icp_profile_launches()]
             ctx.icp_profile(0)
         return dt, (km / max(kn, 1)), kn
 
     for _ in range(W):
         step()
     elapsed, kern_avg_ms, kern_n = timed(K, True)
+    launch_ms = getattr(timed, "last_launch_ms", None)
+    kernels_timed = ctx.icp_kernel_launches()
     T_timed = ctx.icp_current_transform()
     steady = None
     if S > 0:
@@ -376,6 +392,8 @@ def main() -> int:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "icp_accumulate_kernel", "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
+                         "kernel_ms_per_launch": launch_ms if (launch_ms and len(launch_ms) <= 128) else None,
+                         "kernel_launches_so_far": kernels_timed,
                          "algorithmic_bytes_per_launch": algo_bytes},
             "phases": {"from_coarse_pose": {"steps": K, "after_warmup": W, "ms_per_step": elapsed / K * 1e3, "kernel_ms": kern_avg_ms},
                        "steady_state": steady},

@@ -152,8 +152,10 @@ enum { OPE_CORR_NEAREST = 0, OPE_CORR_NORMAL_SHOOTING = 1 };
  * estimator that IterativeClosestPointWithNormals defaults to (icp_mod.h:352-357; needs TARGET normals).
  * OPE_EST_POINT_TO_PLANE_LM: pcl::registration::TransformationEstimationPointToPlane, the Levenberg-Marquardt estimator
  * BuildModel installs (regmeshpcd.cpp:162,193): same cost, minimised over (t, quaternion) with Eigen's LM logic on a
- * forward-difference Jacobian and float tolerances; one device reduction per functor evaluation, the host is
- * synchronised every iteration (ope_icp_run / ope_icp_iterate only; needs TARGET normals). */
+ * forward-difference Jacobian and float tolerances.  The residual is linear in the warp matrix, so one device pass per ICP
+ * iteration reduces the 91 sums every functor evaluation is a quadratic form of, and the minimisation runs in the launch
+ * that also updates the transform: nothing synchronises the host (ope_icp_run / ope_icp_iterate only — the step-wise
+ * accumulate / update pair exchanges 17 or 44 sums, not these; needs TARGET normals). */
 enum { OPE_EST_SVD = 0, OPE_EST_POINT_TO_PLANE_LLS = 1, OPE_EST_POINT_TO_PLANE_LM = 2 };
 #define OPE_NUM_SUMS 17     /* {n, Σs, Σt, Σ t sᵀ, Σd²} */
 #define OPE_NUM_SUMS_MAX 44 /* + upper triangle of AᵀA (21) and Aᵀb (6) for point-to-plane */
@@ -307,8 +309,10 @@ int ope_comm_transport(const ope_ctx *ctx);
  * (torch.distributed with any backend, MPI, a file): every rank calls ope_comm_p2p_open and publishes the handle it gets;
  * every rank then calls ope_comm_p2p_connect with all handles in rank order.  connect is collective: it maps the peers'
  * buffers and runs the test exchange (up to 10 s); OPE_ECOMM on any rank means no rank may use the communicator — agree
- * on the return codes before iterating.  Such a communicator carries the SVD and LLS estimators (17 / 44 sums per
- * iteration); the LM estimator's repeated reductions need ope_comm_init_rank. */
+ * on the return codes before iterating.  Such a communicator carries every estimator (17 / 44 sums per iteration, the LM
+ * estimator's 17 + 91).  After an exchange has timed out (OPE_ECOMM from ope_icp_poll / ope_icp_end) the ranks' sequence
+ * numbers no longer agree: ope_icp_begin refuses further runs until the communicator has been re-created
+ * (ope_comm_destroy, then ope_comm_p2p_open / connect or ope_comm_init_rank again, on every rank). */
 #define OPE_P2P_HANDLE_BYTES 64
 int ope_comm_p2p_open(ope_ctx *ctx, char handle[OPE_P2P_HANDLE_BYTES]);
 int ope_comm_p2p_connect(ope_ctx *ctx, const char *handles /* nranks * OPE_P2P_HANDLE_BYTES */, int nranks, int rank);

@@ -15,7 +15,7 @@ namespace ope {
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
-                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *);
+                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *, const uint32_t *);
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
 void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
@@ -33,6 +33,8 @@ int grid_plan(hipStream_t, bool, const unsigned char *, uint32_t, uint32_t *, ui
               uint32_t *, uint32_t, uint32_t, float, float, void *, size_t);
 size_t grid_plan_tmp_bytes(uint32_t, uint32_t);
 void grid_count_far(hipStream_t, const float *, uint32_t, float, uint32_t *);
+void grid_count_outside(hipStream_t, const CloudView &, const float[12], const float[3], const float[3], float, uint32_t *);
+void grid_hints_to_leaves(hipStream_t, const uint32_t *, const uint32_t *, uint32_t, uint32_t, int, uint32_t *, uint32_t *);
 hipError_t build_grid_device(hipStream_t, const float4 *, const float4 *, size_t, const float[3], const float[3], double, uint32_t, GridView *,
                              float4 **, float4 **, uint32_t **, uint32_t **);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
@@ -120,7 +122,10 @@ static bool atomic_sums(const ope_ctx *ctx) { return ctx->run_params.determinist
 // kernel below kGridMinTreeShare.  Either kernel is exact: the choice only moves time.
 static int grid_probe_issue(ope_ctx *ctx) {
   if (ctx->grid_probe_pending || !ctx->grid_probe_event || !ctx->grid_auto) return OPE_OK;
-  const float cell = 1.0f / ctx->run_tgt->grid.inv;
+  // "far": further than eight cells from the target — clutter, whose ball no 27-cell scan will ever cover; a source that is
+  // merely a few cells off at the start of a run is not counted (round 2 counted beyond ONE cell and therefore had to wait
+  // for the loop to settle before it could trust the count)
+  const float cell = 8.0f / ctx->run_tgt->grid.inv;
   grid_count_far(ctx->stream, ctx->d_corr_d2, (uint32_t)ctx->run_src->n_valid, cell * cell, ctx->d_work_counter + 8);
   OPE_HIP(ctx, hipMemcpyAsync(ctx->h_grid_probe, ctx->d_work_counter + 10, 4, hipMemcpyDeviceToHost, ctx->stream));
   OPE_HIP(ctx, hipEventRecord(ctx->grid_probe_event, ctx->stream));
@@ -135,7 +140,12 @@ static float heavy_load_factor() {
 }
 // returns +1: switch to the grid kernel, -1: switch to the tree kernel, 0: stay
 static int grid_probe_poll(ope_ctx *ctx, int it_done) {
-  if (!ctx->grid_probe_pending || hipEventQuery(ctx->grid_probe_event) != hipSuccess) return 0;
+  if (!ctx->grid_probe_pending) return 0;
+  // The first count of a run (taken after launch 0) is WAITED for before launch 2 is enqueued: one short wait per run, and
+  // which kernel serves which launch no longer depends on how far the host runs ahead of the GPU.  Later counts (every
+  // plan step from launch 8 on, both directions) are polled without waiting.
+  if (it_done == 2) { if (hipEventSynchronize(ctx->grid_probe_event) != hipSuccess) return 0; }
+  else if (hipEventQuery(ctx->grid_probe_event) != hipSuccess) return 0;
   ctx->grid_probe_pending = false;
   const uint32_t n_far = *ctx->h_grid_probe;
   const double share = (double)n_far / (double)std::max<size_t>(ctx->run_src->n_valid, 1);
@@ -149,6 +159,7 @@ static int grid_probe_poll(ope_ctx *ctx, int it_done) {
 static int switch_kernel(ope_ctx *ctx, bool to_grid, int it_done, uint32_t nch) {
   ctx->use_grid = to_grid;
   ctx->plan_valid = false;   // chunk ids mean something else to the other kernel
+  if (ctx->plan_pending) { OPE_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_plan_done, 0)); ctx->plan_pending = false; }
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * (size_t)(nch + 1), ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 8, 0, 8, ctx->stream));
   if (to_grid) {
@@ -157,7 +168,15 @@ static int switch_kernel(ope_ctx *ctx, bool to_grid, int it_done, uint32_t nch) 
     fill_iota(ctx->stream, ctx->d_qorder, (uint32_t)std::max<size_t>(ctx->run_src->n, 1));
     OPE_HIP(ctx, hipMemsetAsync(ctx->d_qclass, 0, std::max<size_t>(ctx->run_src->n, 1), ctx->stream));
   }
-  ctx->force_plan_at = it_done + 2;   // as soon as two launches have measured their chunks
+  if (!to_grid && ctx->run_tgt->has_grid && ctx->d_ghint) {
+    // the previous matches the grid kernel kept become the tree kernel's start leaves (grid_build.hip)
+    const int rcs = ensure_scratch(ctx, std::max<size_t>(4 * ctx->run_tgt->n + 4096, (size_t)1 << 16));
+    if (rcs != OPE_OK) return rcs;
+    grid_hints_to_leaves(ctx->stream, ctx->d_ghint, ctx->run_tgt->d_gpos, (uint32_t)ctx->run_src->n_valid, (uint32_t)ctx->run_tgt->n, ctx->run_tgt->depth,
+                         ctx->d_hint, reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(ctx->d_scratch) + 4096));
+  }
+  // the kernel taken over plans as soon as its first launch has measured its chunks (an unplanned launch measures them all)
+  ctx->force_plan_at = it_done + 1;
   return OPE_OK;
 }
 
@@ -172,11 +191,10 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     // the launch before a plan step measures: no 8-lane group walks (their chunks would keep the cost of the last
     // per-lane walk they had, however old), flagged to the kernels through plan_info[4]
     const int nx = it_done + 1;
-    // (round 3: a group-walked chunk reports an estimate of its per-lane cost, icp_accumulate_kernel, so the tree kernel no
-    // longer needs measuring launches; the grid kernel's tree part still takes them.  OPE_MEASURING=1: developer A/B)
-    static const bool measuring_env = dev_env("OPE_MEASURING") != nullptr;
-    const bool measuring = (ctx->use_grid || measuring_env) && !no_plan && nch > 1 &&
-                           ((((nx & (nx - 1)) == 0 && nx <= plan_every) || nx % plan_every == 0 || nx == ctx->force_plan_at));
+    // (round 3: letting a group-walked chunk report an estimate of its per-lane cost instead — the duration of one of its
+    // slots over kOctSlotShare — did away with these launches and with a good schedule: steady state 172-186 us against
+    // 152-157; a slot lasts 51-60 us whatever its chunk costs per lane.  Measured, not kept.)
+    const bool measuring = !no_plan && nch > 1 && ((((nx & (nx - 1)) == 0 && nx <= plan_every) || nx % plan_every == 0 || nx == ctx->force_plan_at));
     if (measuring != ctx->measuring_flag) {
       OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 12, measuring ? 0x01 : 0x00, 4, ctx->stream));
       ctx->measuring_flag = measuring;
@@ -203,7 +221,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
                     (uint32_t)ctx->acc_blocks * (kAccBlock / 64), heavy_env, heavy_load_factor(), ctx->d_part_tmp, ctx->part_tmp_bytes) != 0)
         return set_err(ctx, OPE_EHIP, "grid plan step failed");
       ctx->plan_valid = true;
-      if (it_done >= 2) {
+      if (it_done == 1 || it_done >= 8) {   // after launch 0 (decided before launch 2, see grid_probe_poll), then with the later plans
         const int rcp = grid_probe_issue(ctx);
         if (rcp != OPE_OK) return rcp;
       }
@@ -227,8 +245,23 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     --ctx->acc_launches;
     return enqueue_accumulate(ctx, atomic_sums);
   }
-  if (!no_plan && nch > 1 && it_done >= 1 &&
-      (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0 || it_done == ctx->force_plan_at)) {
+  // ---- the tree kernel's plan.  It is made on a side stream from a copy of the costs the launches before this one measured,
+  // while THIS launch still runs with the plan before it; the next launch waits for it (an event, no host synchronisation)
+  // and switches over.  Round 2 sorted between two launches: ~40 us on the critical path per plan step, twice inside the
+  // driver's twenty-step window.
+  if (ctx->plan_pending) {
+    OPE_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_plan_done, 0));
+    ctx->plan_cur ^= 1;
+    ctx->plan_cur_slots = ctx->plan_pending_slots;
+    ctx->plan_valid = true;
+    ctx->plan_pending = false;
+  }
+  static const bool plan_sync_env = dev_env("OPE_PLAN_SYNC") != nullptr;     // developer A/B: the plan between two launches, as in round 2
+  // plan steps: after launches 1, 2, 4, ..., 32 and then every 32 (each follows a measuring launch, which runs without group
+  // walks and is ~40 us slower: more frequent plans cost more than they gain)
+  const bool plan_step = !no_plan && nch > 1 && it_done >= 1 &&
+                         (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0 || it_done == ctx->force_plan_at);
+  if (plan_step) {
     if (ctx->grid_auto && it_done >= 8) {
       const int rcp = grid_probe_issue(ctx);
       if (rcp != OPE_OK) return rcp;
@@ -246,18 +279,35 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     const float load_factor = (heavy_env < 0.f && chunks_per_wave > kHeavyMaxChunksPerWave) ? heavy_load_factor() : 0.0f;
     // (a one-launch plan — costs bucketed at 16 per octave, counting sort, same rules on the buckets — took 2.5 us per
     // iteration off the driver's twenty-step window and put 5-9 us on its search kernel: the coarser order is the worse
-    // schedule while the costs still move; measured, not kept)
-    // (rocPRIM sorts these few keys with a block sort and four or five merge launches, ~40 us; a one-block
-    // rocprim::block_radix_sort of the 15 625 keys took 63 us on its single CU: measured, not kept)
+    // schedule while the costs still move; a one-block rocprim::block_radix_sort of the 15 625 keys took 63 us on its single
+    // CU: both measured in round 2, not kept)
+    const bool async = !plan_sync_env;
+    hipStream_t ps = async ? ctx->plan_stream : ctx->stream;
+    const int nxt = ctx->plan_cur ^ 1;
+    const uint32_t *costs = ctx->d_chunk_cost;
+    if (async) {
+      OPE_HIP(ctx, hipEventRecord(ctx->ev_acc_done, ctx->stream));       // every launch before this one has finished ...
+      OPE_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_acc_done, 0));         // ... before the costs are copied (this launch overwrites them)
+      OPE_HIP(ctx, hipMemcpyAsync(ctx->d_cost_snap, ctx->d_chunk_cost, 4 * (size_t)nch, hipMemcpyDeviceToDevice, ps));
+      costs = ctx->d_cost_snap;
+    }
     size_t tb = ctx->plan_tmp_bytes;
-    if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch, ctx->d_plan_tmp, tb) != 0)
+    if (chunk_plan(ps, costs, ctx->d_plan_sorted[nxt], ctx->d_chunk_ids, ctx->d_plan_order[nxt], nch, ctx->d_plan_tmp, tb) != 0)
       return set_err(ctx, OPE_EHIP, "chunk plan sort failed");
-    plan_heavy(ctx->stream, ctx->d_chunk_cost_sorted, nch, heavy_factor, load_factor, (uint32_t)ctx->acc_blocks * (kAccBlock / 64),
-               ctx->d_work_counter + 8);
+    uint32_t *out = ctx->d_plan_out + 8 * nxt;
+    plan_heavy(ps, ctx->d_plan_sorted[nxt], nch, heavy_factor, load_factor, (uint32_t)ctx->acc_blocks * (kAccBlock / 64), out);
     static const bool no_slot_list = dev_env("OPE_NO_SLOT_LIST") != nullptr;  // developer A/B switch
-    ctx->slot_list_valid = !no_slot_list && ctx->run_params.corr_mode == OPE_CORR_NEAREST && !ctx->run_params.use_reciprocal;
-    if (ctx->slot_list_valid) plan_slots(ctx->stream, ctx->d_chunk_cost_sorted, nch, ctx->d_work_counter + 8, ctx->d_slot_list);
-    ctx->plan_valid = true;
+    const bool slots = !no_slot_list && ctx->run_params.corr_mode == OPE_CORR_NEAREST && !ctx->run_params.use_reciprocal;
+    if (slots) plan_slots(ps, ctx->d_plan_sorted[nxt], nch, out, ctx->d_plan_slots[nxt]);
+    if (async) {
+      OPE_HIP(ctx, hipEventRecord(ctx->ev_plan_done, ps));
+      ctx->plan_pending = true;
+      ctx->plan_pending_slots = slots;
+    } else {
+      ctx->plan_cur = nxt;
+      ctx->plan_cur_slots = slots;
+      ctx->plan_valid = true;
+    }
   }
   const ope_icp_params &p = ctx->run_params;
   const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej ||
@@ -275,9 +325,9 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   ++ctx->kernel_launches[p.corr_mode != OPE_CORR_NEAREST ? OPE_KERNEL_KNN : (packet && !recip) ? OPE_KERNEL_TREE_PACKET : OPE_KERNEL_TREE_LANE];
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
                         recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
-                        ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr,
-                        (ctx->plan_valid && ctx->slot_list_valid) ? ctx->d_slot_list : nullptr,
-                        p.corr_mode == OPE_CORR_NORMAL_SHOOTING ? ctx->d_knn_rk : nullptr);
+                        ctx->plan_valid ? ctx->d_plan_order[ctx->plan_cur] : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr,
+                        (ctx->plan_valid && ctx->plan_cur_slots) ? ctx->d_plan_slots[ctx->plan_cur] : nullptr,
+                        (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && !dev_env("OPE_NO_KNN_BOUND")) ? ctx->d_knn_rk : nullptr, ctx->d_plan_out + 8 * ctx->plan_cur);
   if (timed) {
     OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
     ++ctx->prof_used;
@@ -317,10 +367,21 @@ int ope_ctx_create(ope_ctx **out, int device_ordinal) {
     return set_err(nullptr, OPE_EHIP, "hipSetDevice/hipStreamCreate failed");
   }
   ctx->stream = ctx->own_stream;
+  {
+    // temporaries come from the device's default memory pool (tmp_malloc): let it keep what it has been given
+    hipMemPool_t pool = nullptr;
+    uint64_t keep = UINT64_MAX;
+    if (hipDeviceGetDefaultMemPool(&pool, device_ordinal) == hipSuccess && pool) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    (void)hipGetLastError();
+  }
   if (hipMalloc(&ctx->d_state, sizeof(IcpState)) != hipSuccess ||
       hipMalloc(&ctx->d_partials, sizeof(double) * kNumSumsMax * kAccMaxBlocks) != hipSuccess ||
       hipMalloc((void **)&ctx->d_work_counter, 256) != hipSuccess ||
       hipMalloc((void **)&ctx->d_lm_stats, sizeof(double) * 96) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_plan_out, 64) != hipSuccess || hipMemset(ctx->d_plan_out, 0, 64) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->plan_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_acc_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_plan_done, hipEventDisableTiming) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState)) != hipSuccess) {
     ope_ctx_destroy(ctx);
     return set_err(nullptr, OPE_ENOMEM, "context allocation failed");
@@ -341,6 +402,12 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
   if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
   if (ctx->d_lm_stats) (void)hipFree(ctx->d_lm_stats);
+  if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
+  if (ctx->ev_acc_done) (void)hipEventDestroy(ctx->ev_acc_done);
+  if (ctx->ev_plan_done) (void)hipEventDestroy(ctx->ev_plan_done);
+  for (void *q : {(void *)ctx->d_plan_out, (void *)ctx->d_cost_snap, (void *)ctx->d_plan_sorted[0], (void *)ctx->d_plan_sorted[1], (void *)ctx->d_plan_order[0],
+                  (void *)ctx->d_plan_order[1], (void *)ctx->d_plan_slots[0], (void *)ctx->d_plan_slots[1]})
+    if (q) (void)hipFree(q);
   if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
   if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
   if (ctx->d_hint) (void)hipFree(ctx->d_hint);
@@ -427,13 +494,13 @@ int ope_cloud_upload(ope_ctx *ctx, const void *base, size_t n, size_t stride_byt
   float *d_raw = nullptr;
   int32_t *d_perm = nullptr;
   hipError_t e = hipMalloc((void **)&c->d_xyzw, sizeof(float4) * std::max<size_t>(n, 1));
-  if (e == hipSuccess && n) e = hipMalloc((void **)&d_raw, 12 * n);
-  if (e == hipSuccess && n) e = hipMalloc((void **)&d_perm, 4 * n);
+  if (e == hipSuccess && n) e = tmp_malloc(ctx->stream, (void **)&d_raw, 12 * n);
+  if (e == hipSuccess && n) e = tmp_malloc(ctx->stream, (void **)&d_perm, 4 * n);
   if (e == hipSuccess && n) e = hipMemcpyAsync(d_raw, c->h_xyz.data(), 12 * n, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && n) e = morton_order_device(ctx->stream, d_raw, n, lo, inv, c->d_xyzw, d_perm);
   if (e == hipSuccess && n) e = hipMemcpy(c->perm.data(), d_perm, 4 * n, hipMemcpyDeviceToHost);
-  if (d_raw) (void)hipFree(d_raw);
-  if (d_perm) (void)hipFree(d_perm);
+  tmp_free(ctx->stream, d_raw);
+  tmp_free(ctx->stream, d_perm);
   if (e != hipSuccess) {
     ope_cloud_free(c);
     return set_err(ctx, OPE_EHIP, std::string("ope_cloud_upload: ") + hipGetErrorString(e));
@@ -818,6 +885,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   if (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && (p.k_normal_shooting < 1 || p.k_normal_shooting > 32))
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: 1 <= k_normal_shooting <= 32");
   OPE_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->plan_pending) OPE_HIP(ctx, hipStreamSynchronize(ctx->plan_stream));   // a plan of the previous run still in the making reads the buffers below
   // From here on the context's run state is being rebuilt: any failure leaves NO run behind (not the previous one
   // with new buffers, and not stale align-strength sizes).
   const int64_t keep_ns = ctx->n_src_total, keep_nt = ctx->n_tgt_total;
@@ -849,7 +917,19 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     ctx->use_grid = tgt->has_grid;
   }
   ctx->grid_auto = ctx->use_grid && tgt->grid_mode == 1;
-  if (ctx->use_grid) {
+  if (ctx->grid_auto) {
+    // a lower bound on the clutter share before anything is searched: source points, under the guess, more than eight cells
+    // outside the target's bounding box (grid_build.hip); above the threshold the run starts on the tree kernel
+    static const float I4g[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    float rows[12];
+    colmajor_to_rows(guess ? guess : I4g, rows);
+    uint32_t n_out = 0;
+    grid_count_outside(ctx->stream, src->view(), rows, tgt->bb_lo, tgt->bb_hi, 8.0f / tgt->grid.inv, ctx->d_work_counter + 20);
+    OPE_HIP(ctx, hipMemcpyAsync(&n_out, ctx->d_work_counter + 20, 4, hipMemcpyDeviceToHost, ctx->stream));
+    OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((double)n_out > kGridMaxTreeShare * (double)src->n_valid) ctx->use_grid = false;
+  }
+  if (ctx->use_grid || ctx->grid_auto) {   // (a run that starts on the tree kernel may still move to the grid kernel later)
     const size_t cap = std::max<size_t>(src->n, 1);
     if (ctx->grid_cap < cap) {
       for (void *q : {(void *)ctx->d_ghint, (void *)ctx->d_qorder, (void *)ctx->d_qclass, ctx->d_part_tmp})
@@ -892,6 +972,17 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
       if (ctx->d_slot_list) (void)hipFree(ctx->d_slot_list);
       ctx->d_slot_list = nullptr;
       OPE_HIP(ctx, hipMalloc((void **)&ctx->d_slot_list, 4 * (nch + 7 * (nch / 4 + 1))));   // n chunks + 7 per group-walked chunk (at most n / 4)
+      for (void *q : {(void *)ctx->d_cost_snap, (void *)ctx->d_plan_sorted[0], (void *)ctx->d_plan_sorted[1], (void *)ctx->d_plan_order[0],
+                      (void *)ctx->d_plan_order[1], (void *)ctx->d_plan_slots[0], (void *)ctx->d_plan_slots[1]})
+        if (q) (void)hipFree(q);
+      ctx->d_cost_snap = nullptr;
+      for (int k = 0; k < 2; ++k) ctx->d_plan_sorted[k] = ctx->d_plan_order[k] = ctx->d_plan_slots[k] = nullptr;
+      OPE_HIP(ctx, hipMalloc((void **)&ctx->d_cost_snap, 4 * nch));
+      for (int k = 0; k < 2; ++k) {
+        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_plan_sorted[k], 4 * nch));
+        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_plan_order[k], 4 * nch));
+        OPE_HIP(ctx, hipMalloc((void **)&ctx->d_plan_slots[k], 4 * (nch + 7 * (nch / 4 + 1))));
+      }
       size_t tb = 0;
       if (chunk_plan(ctx->stream, ctx->d_chunk_cost, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order,
                      (uint32_t)nch, nullptr, tb) != 0)
@@ -902,6 +993,9 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     }
     fill_iota(ctx->stream, ctx->d_chunk_ids, (uint32_t)nch);
     OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * nch, ctx->stream));
+    ctx->plan_pending = false;
+    ctx->plan_cur = 0;
+    ctx->plan_cur_slots = false;
     ctx->plan_valid = false;
     ctx->slot_list_valid = false;
     ctx->acc_launches = 0;
@@ -1127,8 +1221,8 @@ int ope_debug_chunk_costs(ope_ctx *ctx, uint32_t *cost, uint32_t *order, uint32_
   if (!ctx || !ctx->run_active) return OPE_ESTATE;
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   OPE_HIP(ctx, hipMemcpy(cost, ctx->d_chunk_cost, 4 * (size_t)n, hipMemcpyDeviceToHost));
-  OPE_HIP(ctx, hipMemcpy(order, ctx->d_chunk_order, 4 * (size_t)n, hipMemcpyDeviceToHost));
-  OPE_HIP(ctx, hipMemcpy(plan_info4, ctx->d_work_counter + 8, 16, hipMemcpyDeviceToHost));
+  OPE_HIP(ctx, hipMemcpy(order, ctx->use_grid ? ctx->d_chunk_order : ctx->d_plan_order[ctx->plan_cur], 4 * (size_t)n, hipMemcpyDeviceToHost));
+  OPE_HIP(ctx, hipMemcpy(plan_info4, ctx->use_grid ? ctx->d_work_counter + 8 : ctx->d_plan_out + 8 * ctx->plan_cur, 16, hipMemcpyDeviceToHost));
   return OPE_OK;
 }
 #endif

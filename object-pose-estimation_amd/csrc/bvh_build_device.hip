@@ -525,15 +525,15 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
   if (e == hipSuccess) e = hipMalloc((void **)d_pts, sizeof(float4) * (n + kPtsPad));
   if (e == hipSuccess) e = hipMemsetAsync(*d_pts + n, 0, sizeof(float4) * kPtsPad, stream);
   if (e == hipSuccess && d_src_nrm) e = hipMalloc((void **)d_nrm, sizeof(float4) * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_keys, 8 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_keys2, 8 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_order, 4 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_order2, 4 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_mn, 12 * ((size_t)1 << D));
-  if (e == hipSuccess) e = hipMalloc((void **)&d_mx, 12 * ((size_t)1 << D));
+  if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_keys, 8 * n);
+  if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_keys2, 8 * n);
+  if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_order, 4 * n);
+  if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_order2, 4 * n);
+  if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_mn, 12 * ((size_t)1 << D));
+  if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_mx, 12 * ((size_t)1 << D));
   size_t tmp_bytes = 0;
   if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_order, d_order2, n, 0, 64, stream);
-  if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16));
+  if (e == hipSuccess) e = tmp_malloc(stream, &d_tmp, tmp_bytes);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(iota_u32_kernel, dim3(nb), dim3(256), 0, stream, d_order, nn);
     for (int level = 0; level < D && e == hipSuccess; ++level) {
@@ -552,7 +552,7 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
                        d_src_nrm ? *d_nrm : nullptr);
     int first_level = 0;
     if (n >= kTopMinPoints && D > kTopLevels) {   // first levels from 2^kTopLevels slices (see TopWork)
-      e = hipMalloc((void **)&d_top, sizeof(TopWork));
+      e = tmp_malloc(stream, (void **)&d_top, sizeof(TopWork));
       if (e == hipSuccess) e = hipMemsetAsync(d_top, 0, sizeof(TopWork), stream);
       if (e == hipSuccess) e = hipMemsetAsync(d_top->lo, 0xff, sizeof d_top->lo, stream);
       if (e == hipSuccess) {
@@ -584,7 +584,7 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
   }
   for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_order, (void *)d_order2, (void *)d_mn, (void *)d_mx, d_tmp, (void *)d_top})
-    if (p) (void)hipFree(p);
+    tmp_free(stream, p);
   return e;
 }
 

@@ -170,24 +170,23 @@ static int box_filter_dev(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3
   unsigned int *d_count = nullptr;
   void *d_tmp = nullptr;
   unsigned int count = 0;
-  hipError_t e = hipMalloc((void **)&d_flags, n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_out, 4 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_count, 4);
+  hipError_t e = tmp_malloc(ctx->stream, (void **)&d_flags, n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_out, 4 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_count, 4);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(box_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cloud->view(), lo[0], lo[1],
                        lo[2], hi[0], hi[1], hi[2], d_flags);
     rocprim::counting_iterator<int32_t> iota(0);
     size_t tb = 0;
     e = rocprim::select(nullptr, tb, iota, d_flags, d_out, d_count, n, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tb, 16));
+    if (e == hipSuccess) e = tmp_malloc(ctx->stream, &d_tmp, tb);
     if (e == hipSuccess) e = rocprim::select(d_tmp, tb, iota, d_flags, d_out, d_count, n, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
-  for (void *p : {(void *)d_flags, (void *)d_count, d_tmp})
-    if (p) (void)hipFree(p);
+  for (void *p : {(void *)d_flags, (void *)d_count, d_tmp}) tmp_free(ctx->stream, p);
   if (e != hipSuccess) {
-    if (d_out) (void)hipFree(d_out);
+    tmp_free(ctx->stream, d_out);
     return set_err(ctx, OPE_EHIP, std::string(who) + ": " + hipGetErrorString(e));
   }
   *d_out_ret = d_out;
@@ -204,27 +203,39 @@ static int box_filter(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], c
   if (rc != OPE_OK) return rc;
   hipError_t e = hipSuccess;
   if (count) e = hipMemcpy(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost);
-  if (d_out) (void)hipFree(d_out);
+  tmp_free(ctx->stream, d_out);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string(who) + ": " + hipGetErrorString(e));
   *n_out = count;
   return OPE_OK;
 }
 
-// the same with the survivors handed on as a device-resident cloud (and, optionally, their indices to the host)
+// the same with the survivors handed on as a device-resident cloud (and, optionally, their indices to the host): the flags
+// by original index go straight into the order-preserving compaction (sampling.hip), nothing is sorted again
 static int box_filter_cloud(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], const float hi[3], ope_cloud **out, int32_t *out_idx,
                             size_t *n_out, const char *who) {
   *out = nullptr;
   if (n_out) *n_out = 0;
-  int32_t *d_out = nullptr;
-  unsigned int count = 0;
-  int rc = box_filter_dev(ctx, cloud, lo, hi, &d_out, &count, who);
+  const size_t n = cloud->n;
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned char *d_flags = nullptr;
+  int32_t *d_idx = nullptr;
+  hipError_t e = tmp_malloc(ctx->stream, (void **)&d_flags, std::max<size_t>(n, 1));
+  if (e == hipSuccess && out_idx) e = tmp_malloc(ctx->stream, (void **)&d_idx, 4 * std::max<size_t>(n, 1));
+  int rc = OPE_OK;
+  size_t count = 0;
+  if (e == hipSuccess) {
+    if (n)
+      hipLaunchKernelGGL(box_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cloud->view(), lo[0], lo[1], lo[2], hi[0], hi[1],
+                         hi[2], d_flags);
+    rc = compact_cloud_device(ctx, cloud, d_flags, out, d_idx, &count);
+    if (rc == OPE_OK && out_idx && count) e = hipMemcpy(out_idx, d_idx, 4 * count, hipMemcpyDeviceToHost);
+  }
+  tmp_free(ctx->stream, d_flags);
+  tmp_free(ctx->stream, d_idx);
   if (rc != OPE_OK) return rc;
-  hipError_t e = hipSuccess;
-  if (count && out_idx) e = hipMemcpyAsync(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream);
-  rc = e == hipSuccess ? select_cloud_device(ctx, cloud, d_out, count, out) : set_err(ctx, OPE_EHIP, std::string(who) + ": " + hipGetErrorString(e));
-  if (d_out) (void)hipFree(d_out);
-  if (rc == OPE_OK && n_out) *n_out = count;
-  return rc;
+  if (e != hipSuccess) { ope_cloud_free(*out); *out = nullptr; return set_err(ctx, OPE_EHIP, std::string(who) + ": " + hipGetErrorString(e)); }
+  if (n_out) *n_out = count;
+  return OPE_OK;
 }
 
 // keep[i] = !(dist[i] > thr), by ORIGINAL index (non-finite points carry distance 0 and pass: PCL quirk)
@@ -333,8 +344,8 @@ static int sor_core(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double std
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<float> dist(n, 0.0f);
   float *d_dist = nullptr;
-  OPE_HIP(ctx, hipMalloc((void **)&d_dist, 4 * n));
-  struct FreeDist { float *p; ~FreeDist() { if (p) (void)hipFree(p); } } free_dist{d_dist};
+  OPE_HIP(ctx, tmp_malloc(ctx->stream, (void **)&d_dist, 4 * n));
+  struct FreeDist { hipStream_t s; float *p; ~FreeDist() { tmp_free(s, p); } } free_dist{ctx->stream, d_dist};
   if (cloud->n_valid > 0) {
     TraceRange r(ctx, "sor");
     ope_index *ix = nullptr;
@@ -378,32 +389,24 @@ static int sor_core(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double std
     *n_out = m;
     return OPE_OK;
   }
-  // the inliers stay on the device: flags from the same comparison, compacted in input order
+  // the inliers stay on the device: flags from the same comparison, compacted in input order (no re-sort)
   unsigned char *d_flags = nullptr;
   int32_t *d_sel = nullptr;
-  unsigned int *d_count = nullptr;
-  void *d_tmp = nullptr;
-  unsigned int count = 0;
-  hipError_t e = hipMalloc((void **)&d_flags, n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_sel, 4 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_count, 4);
+  hipError_t e = tmp_malloc(ctx->stream, (void **)&d_flags, n);
+  if (e == hipSuccess && out_idx) e = tmp_malloc(ctx->stream, (void **)&d_sel, 4 * n);
+  int rc = OPE_OK;
+  size_t count = 0;
   if (e == hipSuccess) {
     hipLaunchKernelGGL(sor_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_dist, (uint32_t)n, thr, d_flags);
-    rocprim::counting_iterator<int32_t> iota(0);
-    size_t tb = 0;
-    e = rocprim::select(nullptr, tb, iota, d_flags, d_sel, d_count, n, ctx->stream);
-    if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tb, 16));
-    if (e == hipSuccess) e = rocprim::select(d_tmp, tb, iota, d_flags, d_sel, d_count, n, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess && count && out_idx) e = hipMemcpyAsync(out_idx, d_sel, 4 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream);
+    rc = compact_cloud_device(ctx, cloud, d_flags, out_cloud, d_sel, &count);
+    if (rc == OPE_OK && out_idx && count) e = hipMemcpy(out_idx, d_sel, 4 * count, hipMemcpyDeviceToHost);
   }
-  int rc = e == hipSuccess ? select_cloud_device(ctx, cloud, d_sel, count, out_cloud)
-                           : set_err(ctx, OPE_EHIP, std::string("ope_statistical_outlier_removal_cloud: ") + hipGetErrorString(e));
-  for (void *p : {(void *)d_flags, (void *)d_sel, (void *)d_count, d_tmp})
-    if (p) (void)hipFree(p);
-  if (rc == OPE_OK && n_out) *n_out = count;
-  return rc;
+  tmp_free(ctx->stream, d_flags);
+  tmp_free(ctx->stream, d_sel);
+  if (rc != OPE_OK) return rc;
+  if (e != hipSuccess) { ope_cloud_free(*out_cloud); *out_cloud = nullptr; return set_err(ctx, OPE_EHIP, std::string("ope_statistical_outlier_removal_cloud: ") + hipGetErrorString(e)); }
+  if (n_out) *n_out = count;
+  return OPE_OK;
 }
 
 extern "C" int ope_statistical_outlier_removal(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double stddev_mul,

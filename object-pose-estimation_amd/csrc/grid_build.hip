@@ -169,4 +169,60 @@ hipError_t build_grid_device(hipStream_t stream, const float4 *d_pts, const floa
   return hipSuccess;
 }
 
+// ---- when a run moves from the grid kernel to the tree kernel: the previous matches the grid kernel kept as positions in
+// the cell-sorted points become the tree kernel's start leaves, so that its first launch starts from every query's previous
+// match instead of the root (round 2 left the hints of grid-answered queries untouched: three launches of 250 us followed
+// every switch, the driver's window began with them).
+__global__ __launch_bounds__(256) void invert_gpos_kernel(const uint32_t *__restrict__ gpos_of_bvhpos, uint32_t n, uint32_t *__restrict__ bvhpos_of_gpos) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b < n) bvhpos_of_gpos[gpos_of_bvhpos[b]] = b;
+}
+__global__ __launch_bounds__(256) void ghint_to_leaf_kernel(const uint32_t *__restrict__ ghint, const uint32_t *__restrict__ bvhpos_of_gpos, uint32_t nq,
+                                                            uint32_t n_t, int depth, uint32_t *__restrict__ hint) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nq) return;
+  const uint32_t g = ghint[i];
+  if (g == 0u || g > n_t) return;
+  const unsigned long long b = bvhpos_of_gpos[g - 1u];
+  // leaf j owns the positions [j n >> D, (j + 1) n >> D)
+  unsigned long long j = (b << depth) / n_t;
+  while ((((j + 1ull) * n_t) >> depth) <= b) ++j;
+  while (j > 0ull && ((j * n_t) >> depth) > b) --j;
+  hint[i] = (1u << depth) + (uint32_t)j;
+}
+// d_inv: scratch of n_t words
+void grid_hints_to_leaves(hipStream_t stream, const uint32_t *ghint, const uint32_t *gpos_of_bvhpos, uint32_t nq, uint32_t n_t, int depth, uint32_t *hint,
+                          uint32_t *d_inv) {
+  if (nq == 0 || n_t == 0) return;
+  hipLaunchKernelGGL(invert_gpos_kernel, dim3((n_t + 255) / 256), dim3(256), 0, stream, gpos_of_bvhpos, n_t, d_inv);
+  hipLaunchKernelGGL(ghint_to_leaf_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, ghint, d_inv, nq, n_t, depth, hint);
+}
+
+// ---- before the first launch of a run: how many source points, under the initial guess, lie further than `margin` outside
+// the target's bounding box?  A lower bound on the number of queries the 27-cell scan can never answer (clutter), taken
+// before anything has been searched: a run over a cluttered frame starts on the tree kernel instead of moving there a few
+// launches later (every move costs the kernel taken over a few launches with cold plans: round 3 measured ~30 us on each of
+// the four launches that followed it).
+struct Rows12 { float r[12]; };
+__global__ __launch_bounds__(256) void count_outside_kernel(CloudView src, Rows12 F, float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                                            uint32_t *__restrict__ count) {
+  uint32_t c = 0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < src.n_valid; i += gridDim.x * 256) {
+    const float4 s = src.xyzw[i];
+    const float x = F.r[0] * s.x + F.r[1] * s.y + F.r[2] * s.z + F.r[3];
+    const float y = F.r[4] * s.x + F.r[5] * s.y + F.r[6] * s.z + F.r[7];
+    const float z = F.r[8] * s.x + F.r[9] * s.y + F.r[10] * s.z + F.r[11];
+    c += (x < lox || x > hix || y < loy || y > hiy || z < loz || z > hiz) ? 1u : 0u;
+  }
+  for (int off = 32; off >= 1; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off, 64);
+  if ((threadIdx.x & 63u) == 0 && c) atomicAdd(count, c);
+}
+void grid_count_outside(hipStream_t stream, const CloudView &src, const float rows[12], const float lo[3], const float hi[3], float margin, uint32_t *d_count) {
+  Rows12 F;
+  for (int k = 0; k < 12; ++k) F.r[k] = rows[k];
+  (void)hipMemsetAsync(d_count, 0, 4, stream);
+  hipLaunchKernelGGL(count_outside_kernel, dim3(std::min<uint32_t>((src.n_valid + 255) / 256, 1024)), dim3(256), 0, stream, src, F, lo[0] - margin, lo[1] - margin,
+                     lo[2] - margin, hi[0] + margin, hi[1] + margin, hi[2] + margin, d_count);
+}
+
 }  // namespace ope

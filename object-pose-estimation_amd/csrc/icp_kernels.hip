@@ -101,7 +101,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
     const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list,
-    float *__restrict__ knn_rk) {
+    float *__restrict__ knn_rk, const uint32_t *__restrict__ plan_out) {
   if (st->done) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
@@ -156,7 +156,9 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   // plan_info[4] != 0: a measuring launch (the one before a plan step) — every chunk takes the per-lane walk, so that the
   // costs the plan sorts are all of one kind and none is older than one launch
   const bool measuring = chunk_order && plan_info[4] != 0u;
-  const uint32_t n_heavy = (OCT_OK && chunk_order && !measuring) ? min(plan_info[0], n_chunks) : 0u;
+  // plan_out: what the plan step computed for this chunk order ([0] chunks walked by groups, [5] / [7] chunks with a wave to
+  // themselves); plan_info: the launch's flags
+  const uint32_t n_heavy = (OCT_OK && chunk_order && !measuring) ? min(plan_out[0], n_chunks) : 0u;
   // The plan's costliest per-lane chunks each outlast the share of work a wave has in a balanced launch (plan_info[5] of
   // them, ranks n_heavy .. n_heavy + n_alone - 1): each gets a wave to itself (waves 0 .. n_alone - 1) and that wave
   // takes nothing else; all other slots are dealt to the remaining waves in snake order.
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   // plan_info[7] entries being the ones that get a wave to themselves.
   const bool listed = OCT_OK && slot_list != nullptr && chunk_order != nullptr && !measuring && n_heavy > 0u;
   const uint32_t n_alone = !chunk_order ? 0u
-                           : listed   ? min(plan_info[7], n_waves / 2u)
-                                      : min(min(plan_info[5] + (measuring ? min(plan_info[0], n_chunks) : 0u), n_chunks - n_heavy), n_waves / 2u);
+                           : listed   ? min(plan_out[7], n_waves / 2u)
+                                      : min(min(plan_out[5] + (measuring ? min(plan_out[0], n_chunks) : 0u), n_chunks - n_heavy), n_waves / 2u);
   const uint32_t n_snake = listed ? (n_chunks + 7u * n_heavy - n_alone) : (8u * n_heavy + (n_chunks - n_heavy - n_alone));
   const uint32_t snake_waves = n_waves - n_alone;
   for (uint32_t round = 0;; ++round) {
@@ -363,12 +365,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     }
     add_query_sums<NRM>(s_red[threadIdx.x >> 6], (lds_cfloat_ptr)s_const, lane_id, ok, p2p, x, y, z, tgt.pts[ok ? pos : 0],
                         (NRM && p2p) ? tgt.nrm[ok ? pos : 0] : make_float4(0.f, 0.f, 0.f, 0.f), d2);
-    // the chunk's cost for the next plan: its per-lane duration, or, walked by 8-lane groups, the duration of its first
-    // slot scaled to what the per-lane walk would take (so that no launch has to give up group walks just to measure)
-    if (lane_id == 0 && (!oct || sub == 0u)) {
-      const uint32_t dur = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
-      chunk_cost[chunk] = oct ? (uint32_t)((float)dur * (1.0f / kOctSlotShare)) : dur;
-    }
+    if (lane_id == 0 && !oct) chunk_cost[chunk] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
   }
 
   // wave slots -> block partial, fixed order
@@ -1329,17 +1326,17 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
                            const BvhView &tgt, const BvhView &srcix, const IcpState *st, double *partials,
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
                            const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
-                           int k_normal_shooting, double *S_atomic, const uint32_t *slot_list, float *knn_rk) {
+                           int k_normal_shooting, double *S_atomic, const uint32_t *slot_list, float *knn_rk, const uint32_t *plan_out) {
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS)                                                                       \
   hipLaunchKernelGGL((icp_accumulate_kernel<M, N, R>), dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, \
-                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk)
+                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out)
   if (mode == 0 && !recip && packet) {
     if (nrm)
       hipLaunchKernelGGL((icp_accumulate_kernel<0, true, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk);
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out);
     else
       hipLaunchKernelGGL((icp_accumulate_kernel<0, false, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk);
+                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out);
     return;
   }
   if (mode == 0) {
@@ -1351,7 +1348,7 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
     // register list takes ~0.5 ms, and held the kernel at two waves per SIMD
 #define OPE_LAUNCH_NS(KR)                                                                                                          \
   hipLaunchKernelGGL((icp_accumulate_kernel<2, true, false, false, KR>), dim3(nblocks), dim3(kKnnBlock), 0, stream, src, tgt, srcix, st, \
-                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk)
+                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out)
     const int k = k_normal_shooting;
     if (k == 10) OPE_LAUNCH_NS(10);
     else if (k <= 4) OPE_LAUNCH_NS(4);

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <memory>
 #include <mutex>
@@ -144,6 +145,15 @@ struct ope_ctx {
   void *d_plan_tmp = nullptr;
   size_t plan_tmp_bytes = 0, chunk_cap = 0;
   bool plan_valid = false;
+  // The tree kernel's plan is made on a side stream while the next launch runs with the plan before it (api.hip,
+  // enqueue_accumulate): two sets of plan outputs, `plan_cur` the one launches read.
+  hipStream_t plan_stream = nullptr;
+  hipEvent_t ev_acc_done = nullptr, ev_plan_done = nullptr;
+  uint32_t *d_cost_snap = nullptr;                          // the costs a plan is made from (copied when the plan starts)
+  uint32_t *d_plan_sorted[2] = {nullptr, nullptr}, *d_plan_order[2] = {nullptr, nullptr}, *d_plan_slots[2] = {nullptr, nullptr};
+  uint32_t *d_plan_out = nullptr;                           // 2 x 8 words
+  int plan_cur = 0;
+  bool plan_pending = false, plan_pending_slots = false, plan_cur_slots = false;
   int acc_launches = 0;
   int64_t kernel_launches[OPE_KERNEL_KINDS] = {0, 0, 0, 0};   // per search kernel, this run (ope_icp_kernel_launches)
   uint32_t *d_hint = nullptr;       // per sorted query: leaf (heap id) of the previous iteration's match, 0 = none
@@ -251,6 +261,24 @@ struct ope_index {
 
 namespace ope {
 
+// Temporaries of one entry point: stream-ordered allocations from the device's default memory pool, whose release threshold
+// ope_ctx_create raises so that the pool keeps what it has been given (a hipMalloc / hipFree pair of a few MB costs ~0.5 ms and
+// the free synchronises the device: the front-end stages were made of them).  Buffers that outlive the call (clouds, indexes)
+// stay plain hipMalloc.
+#ifdef OPE_NO_POOL   // (A/B build)
+inline hipError_t tmp_malloc(hipStream_t, void **p, size_t bytes) { return hipMalloc(p, std::max<size_t>(bytes, 16)); }
+inline void tmp_free(hipStream_t, void *p) { if (p) (void)hipFree(p); }
+#elif defined(OPE_POISON_TMP)   // (A/B build: every temporary starts out as 0xA5 bytes — a read of memory nobody wrote changes results)
+inline hipError_t tmp_malloc(hipStream_t s, void **p, size_t bytes) {
+  const hipError_t e = hipMallocAsync(p, std::max<size_t>(bytes, 16), s);
+  return e != hipSuccess ? e : hipMemsetAsync(*p, 0xA5, std::max<size_t>(bytes, 16), s);
+}
+inline void tmp_free(hipStream_t s, void *p) { if (p) (void)hipFreeAsync(p, s); }
+#else
+inline hipError_t tmp_malloc(hipStream_t s, void **p, size_t bytes) { return hipMallocAsync(p, std::max<size_t>(bytes, 16), s); }
+inline void tmp_free(hipStream_t s, void *p) { if (p) (void)hipFreeAsync(p, s); }
+#endif
+
 int set_err(ope_ctx *ctx, int code, const std::string &msg);
 
 // RAII HIP-event bracket around ONE kernel launch on the context stream, recorded under `name` together with the
@@ -300,6 +328,8 @@ struct HostBvh {
 };
 // sampling.hip: a new cloud from n_sel ORIGINAL indices (device array) of a device-resident cloud
 int select_cloud_device(ope_ctx *ctx, const ope_cloud *cloud, const int32_t *d_idx, size_t n_sel, ope_cloud **out);
+// the same for order-preserving filters: keep = one byte per ORIGINAL index (device); no re-sort (sampling.hip)
+int compact_cloud_device(ope_ctx *ctx, const ope_cloud *cloud, const unsigned char *d_keep, ope_cloud **out, int32_t *d_idx_out, size_t *n_out);
 
 void build_bvh_host(const float *xyz, const int32_t *ids, const float *nrm, size_t n, int leaf_size, HostBvh &out);
 

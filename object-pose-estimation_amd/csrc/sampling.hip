@@ -345,53 +345,57 @@ __device__ __forceinline__ uint32_t expand_bits10_dev(uint32_t v) {
 }
 
 __global__ __launch_bounds__(256) void morton_key_kernel(const float *__restrict__ raw, uint32_t n, float lox, float loy, float loz,
-                                                          float ivx, float ivy, float ivz, unsigned long long *__restrict__ keys) {
+                                                          float ivx, float ivy, float ivz, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float x = raw[3 * (size_t)i], y = raw[3 * (size_t)i + 1], z = raw[3 * (size_t)i + 2];
-  unsigned long long code;
-  if (!(isfinite(x) && isfinite(y) && isfinite(z))) code = 1ull << 30;
+  uint32_t code;
+  if (!(isfinite(x) && isfinite(y) && isfinite(z))) code = 1u << 30;
   else {
     const uint32_t qx = min(1023u, (uint32_t)fmaxf(0.f, __fmul_rn(__fsub_rn(x, lox), ivx)));
     const uint32_t qy = min(1023u, (uint32_t)fmaxf(0.f, __fmul_rn(__fsub_rn(y, loy), ivy)));
     const uint32_t qz = min(1023u, (uint32_t)fmaxf(0.f, __fmul_rn(__fsub_rn(z, loz), ivz)));
     code = expand_bits10_dev(qx) | (expand_bits10_dev(qy) << 1) | (expand_bits10_dev(qz) << 2);
   }
-  keys[i] = (code << 32) | (unsigned long long)i;
+  keys[i] = code;
+  vals[i] = i;
 }
 
-__global__ __launch_bounds__(256) void morton_gather_kernel(const float *__restrict__ raw, const unsigned long long *__restrict__ keys,
+__global__ __launch_bounds__(256) void morton_gather_kernel(const float *__restrict__ raw, const uint32_t *__restrict__ order,
                                                              uint32_t n, float4 *__restrict__ xyzw, int32_t *__restrict__ perm) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint32_t o = (uint32_t)(keys[i] & 0xffffffffull);
+  const uint32_t o = order[i];
   perm[i] = (int32_t)o;
   xyzw[i] = make_float4(raw[3 * (size_t)o], raw[3 * (size_t)o + 1], raw[3 * (size_t)o + 2], __int_as_float((int)o));
 }
 
 // d_raw: n*3 floats in input order (device).  Outputs: d_xyzw (n float4, sorted), d_perm (n, sorted position -> input index).
+// The order is that of the keys (Morton code, then input index): a STABLE sort of the 31-bit codes with the indices as
+// values (four radix passes over 8 bytes per point; round 2 sorted 64-bit code-and-index keys in eight).
 hipError_t morton_order_device(hipStream_t stream, const float *d_raw, size_t n, const float lo[3], const float inv[3],
                                float4 *d_xyzw, int32_t *d_perm) {
   if (n == 0) return hipSuccess;
-  unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+  uint32_t *d_keys = nullptr, *d_keys2 = nullptr, *d_vals = nullptr, *d_vals2 = nullptr;
   void *d_tmp = nullptr;
-  hipError_t e = hipMalloc((void **)&d_keys, 8 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_keys2, 8 * n);
+  hipError_t e = tmp_malloc(stream, (void **)&d_keys, 4 * n);
+  if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_keys2, 4 * n);
+  if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_vals, 4 * n);
+  if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_vals2, 4 * n);
   if (e == hipSuccess) {
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(morton_key_kernel, dim3(nb), dim3(256), 0, stream, d_raw, (uint32_t)n, lo[0], lo[1], lo[2], inv[0], inv[1],
-                       inv[2], d_keys);
+                       inv[2], d_keys, d_vals);
     size_t tb = 0;
-    e = rocprim::radix_sort_keys(nullptr, tb, d_keys, d_keys2, n, 0, 63, stream);
-    if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tb, 16));
-    if (e == hipSuccess) e = rocprim::radix_sort_keys(d_tmp, tb, d_keys, d_keys2, n, 0, 63, stream);
+    e = rocprim::radix_sort_pairs(nullptr, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 31, stream);
+    if (e == hipSuccess) e = tmp_malloc(stream, &d_tmp, tb);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 31, stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(morton_gather_kernel, dim3(nb), dim3(256), 0, stream, d_raw, d_keys2, (uint32_t)n, d_xyzw, d_perm);
+      hipLaunchKernelGGL(morton_gather_kernel, dim3(nb), dim3(256), 0, stream, d_raw, d_vals2, (uint32_t)n, d_xyzw, d_perm);
       e = hipStreamSynchronize(stream);
     }
   }
-  for (void *p : {(void *)d_keys, (void *)d_keys2, d_tmp})
-    if (p) (void)hipFree(p);
+  for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_vals, (void *)d_vals2, d_tmp}) tmp_free(stream, p);
   return e;
 }
 
@@ -438,7 +442,7 @@ hipError_t concat_device(hipStream_t stream, const CloudView &a, const float *d_
                          float hi[3]) {
   const uint32_t n = a.n + b.n;
   uint32_t *d_mm = nullptr;
-  hipError_t e = hipMalloc((void **)&d_mm, 32);
+  hipError_t e = tmp_malloc(stream, (void **)&d_mm, 32);
   uint32_t init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0u, 0u, 0u, 0};
   if (e == hipSuccess) e = hipMemcpyAsync(d_mm, init, sizeof init, hipMemcpyHostToDevice, stream);
   uint32_t res[8];
@@ -447,7 +451,7 @@ hipError_t concat_device(hipStream_t stream, const CloudView &a, const float *d_
     e = hipMemcpyAsync(res, d_mm, sizeof res, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
   }
-  if (d_mm) (void)hipFree(d_mm);
+  tmp_free(stream, d_mm);
   if (e != hipSuccess) return e;
   for (int d = 0; d < 3; ++d) {
     auto unkey = [](uint32_t k) { const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; std::memcpy(&f, &u, 4); return f; };
@@ -518,10 +522,10 @@ int select_cloud_device(ope_ctx *ctx, const ope_cloud *cloud, const int32_t *d_i
   int32_t *d_perm = nullptr;
   const CloudView cv = cloud->view();
   hipError_t e = hipMalloc((void **)&c->d_xyzw, sizeof(float4) * std::max<size_t>(n_sel, 1));
-  if (e == hipSuccess && n_sel) e = hipMalloc((void **)&d_inv, 4 * std::max<size_t>(cloud->n, 1));
-  if (e == hipSuccess && n_sel) e = hipMalloc((void **)&d_raw, 12 * n_sel);
-  if (e == hipSuccess && n_sel) e = hipMalloc((void **)&d_perm, 4 * n_sel);
-  if (e == hipSuccess && n_sel) e = hipMalloc((void **)&d_mm, 48);
+  if (e == hipSuccess && n_sel) e = tmp_malloc(ctx->stream, (void **)&d_inv, 4 * std::max<size_t>(cloud->n, 1));
+  if (e == hipSuccess && n_sel) e = tmp_malloc(ctx->stream, (void **)&d_raw, 12 * n_sel);
+  if (e == hipSuccess && n_sel) e = tmp_malloc(ctx->stream, (void **)&d_perm, 4 * n_sel);
+  if (e == hipSuccess && n_sel) e = tmp_malloc(ctx->stream, (void **)&d_mm, 48);
   uint32_t res[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0u, 0u, 0u, 0, 0u, 0, 0, 0};
   if (e == hipSuccess && n_sel) {
     e = hipMemcpyAsync(d_mm, res, sizeof res, hipMemcpyHostToDevice, ctx->stream);
@@ -550,13 +554,116 @@ int select_cloud_device(ope_ctx *ctx, const ope_cloud *cloud, const int32_t *d_i
       }
     }
   }
-  for (void *p : {(void *)d_inv, (void *)d_raw, (void *)d_perm, (void *)d_mm})
-    if (p) (void)hipFree(p);
+  for (void *p : {(void *)d_inv, (void *)d_raw, (void *)d_perm, (void *)d_mm}) tmp_free(ctx->stream, p);
   if (e != hipSuccess) {
     ope_cloud_free(c);
     return set_err(ctx, OPE_EHIP, std::string("cloud selection: ") + hipGetErrorString(e));
   }
   *out = c;
+  return OPE_OK;
+}
+
+// ---- the same for ORDER-PRESERVING filters (NaN removal, pass-through, outlier removal: PCL emits the survivors in input
+// order): the survivors keep their relative order along the parent's Morton curve, so nothing is sorted again — two prefix
+// sums (the survivors' rank in input order = their new original index; their rank in sorted order = their new position)
+// and one scatter.  keep: one byte per ORIGINAL index.  d_idx_out (optional, device, room for every point): the survivors'
+// original indices in input order.
+__global__ __launch_bounds__(256) void keep_flags_kernel(CloudView c, const unsigned char *__restrict__ keep, uint32_t *__restrict__ f_orig,
+                                                         uint32_t *__restrict__ f_sorted) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i > c.n) return;
+  if (i == c.n) { f_orig[i] = 0u; f_sorted[i] = 0u; return; }
+  f_orig[i] = keep[i] ? 1u : 0u;
+  f_sorted[i] = keep[(uint32_t)__float_as_int(c.xyzw[i].w)] ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void compact_kernel(CloudView c, const uint32_t *__restrict__ f_sorted, const uint32_t *__restrict__ r_orig,
+                                                      const uint32_t *__restrict__ r_sorted, float4 *__restrict__ xyzw_out, float4 *__restrict__ nrm_out,
+                                                      int32_t *__restrict__ idx_out, uint32_t *__restrict__ mn, uint32_t *__restrict__ mx,
+                                                      uint32_t *__restrict__ n_finite) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  float v[3] = {0.f, 0.f, 0.f};
+  bool fin = false;
+  if (p < c.n && f_sorted[p]) {
+    const float4 q = c.xyzw[p];
+    const uint32_t o = (uint32_t)__float_as_int(q.w), o_new = r_orig[o], dst = r_sorted[p];
+    xyzw_out[dst] = make_float4(q.x, q.y, q.z, __int_as_float((int)o_new));
+    if (nrm_out) nrm_out[dst] = c.nrm[p];
+    if (idx_out) idx_out[o_new] = (int32_t)o;
+    fin = p < c.n_valid;
+    v[0] = q.x; v[1] = q.y; v[2] = q.z;
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const uint32_t u = (uint32_t)__float_as_int(v[d]);
+    const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    uint32_t lo = fin ? key : 0xffffffffu, hi = fin ? key : 0u;
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+      hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+    }
+    if ((threadIdx.x & 63u) == 0) { atomicMin(mn + d, lo); atomicMax(mx + d, hi); }
+  }
+  const unsigned long long m = __ballot(fin);
+  if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_finite, (uint32_t)__popcll(m));
+}
+
+int compact_cloud_device(ope_ctx *ctx, const ope_cloud *cloud, const unsigned char *d_keep, ope_cloud **out, int32_t *d_idx_out, size_t *n_out) {
+  *out = nullptr;
+  if (n_out) *n_out = 0;
+  const size_t n = cloud->n;
+  hipStream_t st = ctx->stream;
+  uint32_t *d_fo = nullptr, *d_fs = nullptr, *d_ro = nullptr, *d_rs = nullptr, *d_mm = nullptr;
+  float4 *d_x = nullptr, *d_n = nullptr;
+  void *d_tmp = nullptr;
+  size_t tb = 0;
+  uint32_t res[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0u, 0u, 0u, 0, 0u, 0, 0, 0};
+  uint32_t count = 0;
+  hipError_t e = tmp_malloc(st, (void **)&d_fo, 4 * (n + 1));
+  if (e == hipSuccess) e = tmp_malloc(st, (void **)&d_fs, 4 * (n + 1));
+  if (e == hipSuccess) e = tmp_malloc(st, (void **)&d_ro, 4 * (n + 1));
+  if (e == hipSuccess) e = tmp_malloc(st, (void **)&d_rs, 4 * (n + 1));
+  if (e == hipSuccess) e = tmp_malloc(st, (void **)&d_mm, 48);
+  if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, tb, d_fo, d_ro, 0u, n + 1, rocprim::plus<uint32_t>(), st);
+  if (e == hipSuccess) e = tmp_malloc(st, &d_tmp, tb);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(keep_flags_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, cloud->view(), d_keep, d_fo, d_fs);
+    size_t t1 = tb;
+    e = rocprim::exclusive_scan(d_tmp, t1, d_fo, d_ro, 0u, n + 1, rocprim::plus<uint32_t>(), st);
+    size_t t2 = tb;
+    if (e == hipSuccess) e = rocprim::exclusive_scan(d_tmp, t2, d_fs, d_rs, 0u, n + 1, rocprim::plus<uint32_t>(), st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&count, d_ro + n, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  ope_cloud *c = nullptr;
+  if (e == hipSuccess) {
+    // (the new cloud's own buffers outlive the call: plain allocations)
+    c = new ope_cloud();
+    c->ctx = ctx;
+    c->n = count;
+    c->host_valid = false;
+    e = hipMalloc((void **)&d_x, sizeof(float4) * std::max<size_t>(count, 1));
+    if (e == hipSuccess && cloud->d_nrm) e = hipMalloc((void **)&d_n, sizeof(float4) * std::max<size_t>(count, 1));
+    c->d_xyzw = d_x;
+    c->d_nrm = d_n;
+  }
+  if (e == hipSuccess && n) {
+    e = hipMemcpyAsync(d_mm, res, sizeof res, hipMemcpyHostToDevice, st);
+    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cloud->view(), d_fs, d_ro, d_rs, d_x, d_n, d_idx_out, d_mm, d_mm + 4,
+                       d_mm + 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(res, d_mm, sizeof res, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  for (void *p : {(void *)d_fo, (void *)d_fs, (void *)d_ro, (void *)d_rs, (void *)d_mm, d_tmp}) tmp_free(st, p);
+  if (e != hipSuccess) {
+    if (c) ope_cloud_free(c);
+    return set_err(ctx, OPE_EHIP, std::string("cloud compaction: ") + hipGetErrorString(e));
+  }
+  auto unkey = [](uint32_t k) { const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; std::memcpy(&f, &u, 4); return f; };
+  c->n_valid = res[8];
+  if (c->n_valid > 0)
+    for (int d = 0; d < 3; ++d) { c->bb_lo[d] = unkey(res[d]); c->bb_hi[d] = unkey(res[4 + d]); }
+  *out = c;
+  if (n_out) *n_out = count;
   return OPE_OK;
 }
 
@@ -586,14 +693,14 @@ static int uniform_sampling_dev(ope_ctx *ctx, const ope_cloud *cloud, float leaf
   unsigned char *d_flags = nullptr;
   unsigned int *d_count = nullptr;
   void *d_tmp = nullptr;
-  hipError_t e = hipMalloc((void **)&d_keys, 8 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_keys2, 8 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_vals, 4 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_vals2, 4 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_win, 4 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_out, 4 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_flags, n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_count, 4);
+  hipError_t e = tmp_malloc(ctx->stream, (void **)&d_keys, 8 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_keys2, 8 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_vals, 4 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_vals2, 4 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_win, 4 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_out, 4 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_flags, n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_count, 4);
   unsigned int count = 0;
   if (e == hipSuccess) {
     const unsigned nb = (unsigned)((n + 255) / 256);
@@ -604,7 +711,7 @@ static int uniform_sampling_dev(ope_ctx *ctx, const ope_cloud *cloud, float leaf
     if (e == hipSuccess)
       e = rocprim::select(nullptr, tmp_sel, d_win, d_flags, d_out, d_count, n, ctx->stream);
     const size_t tmp_bytes = std::max(tmp_sort, tmp_sel);
-    if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16));
+    if (e == hipSuccess) e = tmp_malloc(ctx->stream, &d_tmp, tmp_bytes);
     size_t tb = tmp_bytes;
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 64, ctx->stream);
     if (e == hipSuccess) {
@@ -616,10 +723,9 @@ static int uniform_sampling_dev(ope_ctx *ctx, const ope_cloud *cloud, float leaf
     if (e == hipSuccess) e = hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
-  for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_vals, (void *)d_vals2, (void *)d_win, (void *)d_flags, (void *)d_count, d_tmp})
-    if (p) (void)hipFree(p);
+  for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_vals, (void *)d_vals2, (void *)d_win, (void *)d_flags, (void *)d_count, d_tmp}) tmp_free(ctx->stream, p);
   if (e != hipSuccess) {
-    if (d_out) (void)hipFree(d_out);
+    tmp_free(ctx->stream, d_out);
     return set_err(ctx, OPE_EHIP, std::string("ope_uniform_sampling: ") + hipGetErrorString(e));
   }
   *d_out_ret = d_out;
@@ -636,7 +742,7 @@ extern "C" int ope_uniform_sampling(ope_ctx *ctx, const ope_cloud *cloud, float 
   if (rc != OPE_OK) return rc;
   hipError_t e = hipSuccess;
   if (count) e = hipMemcpy(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost);
-  if (d_out) (void)hipFree(d_out);
+  tmp_free(ctx->stream, d_out);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_uniform_sampling: ") + hipGetErrorString(e));
   *n_out = count;
   return OPE_OK;
@@ -653,7 +759,7 @@ extern "C" int ope_uniform_sampling_cloud(ope_ctx *ctx, const ope_cloud *cloud, 
   hipError_t e = hipSuccess;
   if (count && out_idx) e = hipMemcpyAsync(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream);
   rc = e == hipSuccess ? select_cloud_device(ctx, cloud, d_out, count, out) : set_err(ctx, OPE_EHIP, std::string("ope_uniform_sampling_cloud: ") + hipGetErrorString(e));
-  if (d_out) (void)hipFree(d_out);
+  tmp_free(ctx->stream, d_out);
   if (rc == OPE_OK && n_out) *n_out = count;
   return rc;
 }
@@ -666,11 +772,11 @@ extern "C" int ope_cloud_select(ope_ctx *ctx, const ope_cloud *cloud, const int3
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   int32_t *d_idx = nullptr;
   if (n) {
-    OPE_HIP(ctx, hipMalloc((void **)&d_idx, 4 * n));
+    OPE_HIP(ctx, tmp_malloc(ctx->stream, (void **)&d_idx, 4 * n));
     const hipError_t e = hipMemcpyAsync(d_idx, idx, 4 * n, hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) { (void)hipFree(d_idx); return set_err(ctx, OPE_EHIP, std::string("ope_cloud_select: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { tmp_free(ctx->stream, d_idx); return set_err(ctx, OPE_EHIP, std::string("ope_cloud_select: ") + hipGetErrorString(e)); }
   }
   const int rc = select_cloud_device(ctx, cloud, d_idx, n, out);
-  if (d_idx) (void)hipFree(d_idx);
+  tmp_free(ctx->stream, d_idx);
   return rc;
 }
