@@ -399,6 +399,35 @@ hipError_t morton_order_device(hipStream_t stream, const float *d_raw, size_t n,
   return e;
 }
 
+// Bounding box + finite count of the points a block has seen: wave reduction, then the block's waves through LDS, then ONE atomic
+// per block and word (15 625 waves each firing seven same-address atomics made these kernels take 1-3 ms; round 3).
+__device__ __forceinline__ void block_bbox_commit(const float v[3], bool fin, uint32_t *__restrict__ mn, uint32_t *__restrict__ mx, uint32_t *__restrict__ n_finite) {
+  __shared__ uint32_t s_lo[3][4], s_hi[3][4], s_cnt[4];
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const uint32_t u = (uint32_t)__float_as_int(v[d]);
+    const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    uint32_t lo = fin ? key : 0xffffffffu, hi = fin ? key : 0u;
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+      hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+    }
+    if ((threadIdx.x & 63u) == 0) { s_lo[d][wave] = lo; s_hi[d][wave] = hi; }
+  }
+  const unsigned long long m = __ballot(fin);
+  if ((threadIdx.x & 63u) == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int d = threadIdx.x;
+    atomicMin(mn + d, min(min(s_lo[d][0], s_lo[d][1]), min(s_lo[d][2], s_lo[d][3])));
+    atomicMax(mx + d, max(max(s_hi[d][0], s_hi[d][1]), max(s_hi[d][2], s_hi[d][3])));
+  } else if (threadIdx.x == 3 && n_finite) {
+    const uint32_t c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (c) atomicAdd(n_finite, c);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // ope_cloud_concat: raw (original-order) xyz of [T * a ; b] and its bounding box, on the device.
 // pcl::transformPointCloud (float, ((r0 x + r1 y) + r2 z) + t, non-finite points passed through) followed by
@@ -423,19 +452,9 @@ __global__ __launch_bounds__(256) void concat_kernel(CloudView a, const float *_
     }
     raw[3 * (size_t)o] = x; raw[3 * (size_t)o + 1] = y; raw[3 * (size_t)o + 2] = z;
   }
-  // bounding box of the finite points: order-preserving integer keys, wave reduction, one atomic per wave and axis
+  // bounding box of the finite points: order-preserving integer keys, one atomic per block and word
   const float v[3] = {x, y, z};
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const uint32_t u = (uint32_t)__float_as_int(v[d]);
-    const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    uint32_t lo = fin ? key : 0xffffffffu, hi = fin ? key : 0u;
-    for (int off = 32; off >= 1; off >>= 1) {
-      lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
-      hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
-    }
-    if ((threadIdx.x & 63u) == 0) { atomicMin(mn + d, lo); atomicMax(mx + d, hi); }
-  }
+  block_bbox_commit(v, fin, mn, mx, nullptr);
 }
 
 hipError_t concat_device(hipStream_t stream, const CloudView &a, const float *d_T_rows, const CloudView &b, float *d_raw, float lo[3],
@@ -488,19 +507,7 @@ __global__ __launch_bounds__(256) void select_gather_kernel(CloudView c, const u
     v[0] = q.x; v[1] = q.y; v[2] = q.z;
     raw[3 * (size_t)j] = q.x; raw[3 * (size_t)j + 1] = q.y; raw[3 * (size_t)j + 2] = q.z;
   }
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const uint32_t u = (uint32_t)__float_as_int(v[d]);
-    const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    uint32_t lo = fin ? key : 0xffffffffu, hi = fin ? key : 0u;
-    for (int off = 32; off >= 1; off >>= 1) {
-      lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
-      hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
-    }
-    if ((threadIdx.x & 63u) == 0) { atomicMin(mn + d, lo); atomicMax(mx + d, hi); }
-  }
-  const unsigned long long m = __ballot(fin);
-  if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_finite, (uint32_t)__popcll(m));
+  block_bbox_commit(v, fin, mn, mx, n_finite);
 }
 
 // normals of the selected points, in the new cloud's sorted order
@@ -592,19 +599,7 @@ __global__ __launch_bounds__(256) void compact_kernel(CloudView c, const uint32_
     fin = p < c.n_valid;
     v[0] = q.x; v[1] = q.y; v[2] = q.z;
   }
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const uint32_t u = (uint32_t)__float_as_int(v[d]);
-    const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    uint32_t lo = fin ? key : 0xffffffffu, hi = fin ? key : 0u;
-    for (int off = 32; off >= 1; off >>= 1) {
-      lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
-      hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
-    }
-    if ((threadIdx.x & 63u) == 0) { atomicMin(mn + d, lo); atomicMax(mx + d, hi); }
-  }
-  const unsigned long long m = __ballot(fin);
-  if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_finite, (uint32_t)__popcll(m));
+  block_bbox_commit(v, fin, mn, mx, n_finite);
 }
 
 int compact_cloud_device(ope_ctx *ctx, const ope_cloud *cloud, const unsigned char *d_keep, ope_cloud **out, int32_t *d_idx_out, size_t *n_out) {

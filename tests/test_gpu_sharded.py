@@ -304,6 +304,62 @@ def test_peer_to_peer_slots_carry_the_sums_between_ranks_on_one_gpu(tmp_path, wo
     print(f"peer-to-peer, {world} ranks on one GPU, {ns} x {nt}: {meta[4] * 1e6:.0f} us per iteration")
 
 
+def _p2p_lm_worker(rank, world, port, ns, nt, max_it, out_dir):
+    """The LM estimator (BuildModel's, regmeshpcd.cpp:162,193) with normal shooting, sharded over ranks whose sums travel
+    through the peer-to-peer slots: per iteration the 17 sums and the estimator's 91."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ope = importlib.import_module("object-pose-estimation_amd")
+    sharded = importlib.import_module("object-pose-estimation_amd.sharded")
+    synth = importlib.import_module("object-pose-estimation_amd.synth")
+    torch.cuda.set_device(0)
+    ctx = ope.Context(0)
+    if world > 1:
+        handles = [None] * world
+        dist.all_gather_object(handles, ctx.comm_p2p_open())
+        ctx.comm_p2p_connect(handles, rank)
+        assert ctx.comm_transport() == ope.COMM_P2P
+    src = synth.scene_cloud(ns, clutter_frac=0.0); tgt = synth.model_surface(nt, 1)
+    sn, _ = ctx.normals(ctx.upload(src), 12)
+    ct = ctx.upload(tgt); ctx.normals(ct, 12, fetch=False)
+    ix = ctx.build_index(ct)
+    lo, hi = sharded.shard_range(ns, world, rank)
+    cs = ctx.upload(src[lo:hi], sn[lo:hi])
+    p = ope.default_icp_params(max_iterations=max_it, transformation_epsilon=1e-8, euclidean_fitness_epsilon=1e-8, check_every=0,
+                               corr_mode=ope.CORR_NORMAL_SHOOTING, k_normal_shooting=20, use_surface_normal_rej=1, surface_normal_thr=0.7,
+                               estimator=ope.EST_POINT_TO_PLANE_LM)
+    ctx.icp_set_global_sizes(ns, nt)
+    ctx.icp_begin(cs, ix, p, None)
+    ctx.icp_iterate(max_it)                    # no host synchronisation inside: the LM minimisation runs on the device
+    out = ctx.icp_end()
+    allT = [None] * world
+    dist.all_gather_object(allT, np.asarray(out.T))
+    if rank == 0:
+        assert all(np.array_equal(allT[0], T) for T in allT)
+        np.save(os.path.join(out_dir, f"lm_T_w{world}.npy"), out.T)
+        np.save(os.path.join(out_dir, f"lm_meta_w{world}.npy"), np.array([out.iterations, out.n_corr, out.state]))
+    if world > 1:
+        ctx.comm_destroy()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_lm_estimator_sharded_over_the_peer_to_peer_slots_matches_one_rank(tmp_path):
+    """Round 2's LM estimator reduced once per functor evaluation with a host read-back and could only shard through RCCL;
+    the estimator now works on 91 sums taken once per iteration, which either transport carries.  Two ranks on the box's
+    one GPU against one rank: same stop, same correspondences, transforms equal to the sums' rounding."""
+    for world in (1, 2):
+        mp.spawn(_p2p_lm_worker, args=(world, _free_port(), 50000, 10000, 25, str(tmp_path)), nprocs=world, join=True)
+    T1 = np.load(tmp_path / "lm_T_w1.npy"); T2 = np.load(tmp_path / "lm_T_w2.npy")
+    m1 = np.load(tmp_path / "lm_meta_w1.npy"); m2 = np.load(tmp_path / "lm_meta_w2.npy")
+    assert m1[0] == m2[0] and m1[1] == m2[1] and m1[2] == m2[2], (m1, m2)
+    assert np.linalg.norm(T1.astype(np.float64) - T2.astype(np.float64)) < 1e-5
+
+
 def _p2p_fault_worker(rank, world, port, out_dir):
     """Rank 1 stops one iteration short; rank 0's last exchange must end in OPE_ECOMM after the bounded wait, not hang."""
     sys.path.insert(0, ROOT)
@@ -337,8 +393,19 @@ def _p2p_fault_worker(rank, world, port, out_dir):
     except ope.OpeError as e:
         err, iters = str(e), -1
     dt = time.perf_counter() - t0
+    # after a timed-out exchange the ranks' sequence numbers no longer agree: the communicator is unusable until re-created
+    refused = ""
+    if err:
+        try:
+            ctx.icp_begin(cs, ix, p, None)
+        except ope.OpeError as e:
+            refused = f"{e.code}:{e}"
+        ctx.comm_destroy()
+        ctx.icp_begin(cs, ix, p, None)        # without a communicator the context runs again (unsharded)
+        ctx.icp_iterate(2)
+        assert ctx.icp_end().iterations == 2
     res = [None] * world
-    dist.all_gather_object(res, (iters, err, dt))
+    dist.all_gather_object(res, (iters, err, dt, refused))
     if rank == 0:
         import json
         json.dump(res, open(os.path.join(out_dir, "p2p_fault.json"), "w"))
@@ -357,6 +424,8 @@ def test_peer_to_peer_exchange_gives_up_on_a_missing_peer_instead_of_hanging(tmp
     assert r1[0] == 5 and r1[1] == ""
     assert r0[0] == -1 and "did not arrive" in r0[1], r0
     assert 3.0 < r0[2] < 20.0, r0            # the bounded wait, not a hang (and not an immediate failure either)
+    ope = importlib.import_module("object-pose-estimation_amd")
+    assert r0[3].startswith(f"{ope.OPE_ECOMM}:") and "re-created" in r0[3], r0   # a stale slot must never be taken for fresh sums
 
 
 @pytest.mark.timeout(600)

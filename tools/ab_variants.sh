@@ -5,6 +5,6 @@ out=gpurun_out/$1.log; shift
 mkdir -p gpurun_out; : > $out
 for v in "$@"; do
   echo "== $v faronly" >> $out; PROBE_LIB=$v python3 tools/faronly_probe.py >> $out 2>&1 || echo "FAILED rc=$?" >> $out
-  echo "== $v c3" >> $out; PROBE_LIB=$v python3 tools/foot_probe.py steady,window 2 >> $out 2>&1 || echo "FAILED rc=$?" >> $out
+  echo "== $v c3" >> $out; PROBE_LIB=$v python3 tools/c3_probe.py steady,window 2 >> $out 2>&1 || echo "FAILED rc=$?" >> $out
 done
 grep -v amdgpu.ids $out | cut -c1-300
