@@ -367,13 +367,6 @@ int ope_ctx_create(ope_ctx **out, int device_ordinal) {
     return set_err(nullptr, OPE_EHIP, "hipSetDevice/hipStreamCreate failed");
   }
   ctx->stream = ctx->own_stream;
-  {
-    // temporaries come from the device's default memory pool (tmp_malloc): let it keep what it has been given
-    hipMemPool_t pool = nullptr;
-    uint64_t keep = UINT64_MAX;
-    if (hipDeviceGetDefaultMemPool(&pool, device_ordinal) == hipSuccess && pool) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    (void)hipGetLastError();
-  }
   if (hipMalloc(&ctx->d_state, sizeof(IcpState)) != hipSuccess ||
       hipMalloc(&ctx->d_partials, sizeof(double) * kNumSumsMax * kAccMaxBlocks) != hipSuccess ||
       hipMalloc((void **)&ctx->d_work_counter, 256) != hipSuccess ||
@@ -402,6 +395,7 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
   if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
   if (ctx->d_lm_stats) (void)hipFree(ctx->d_lm_stats);
+  tmp_release_stream(ctx->stream);   // the cached temporaries of this context's stream
   if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
   if (ctx->ev_acc_done) (void)hipEventDestroy(ctx->ev_acc_done);
   if (ctx->ev_plan_done) (void)hipEventDestroy(ctx->ev_plan_done);
@@ -496,7 +490,7 @@ int ope_cloud_upload(ope_ctx *ctx, const void *base, size_t n, size_t stride_byt
   hipError_t e = hipMalloc((void **)&c->d_xyzw, sizeof(float4) * std::max<size_t>(n, 1));
   if (e == hipSuccess && n) e = tmp_malloc(ctx->stream, (void **)&d_raw, 12 * n);
   if (e == hipSuccess && n) e = tmp_malloc(ctx->stream, (void **)&d_perm, 4 * n);
-  if (e == hipSuccess && n) e = hipMemcpyAsync(d_raw, c->h_xyz.data(), 12 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n) e = h2d_copy(ctx->stream, d_raw, c->h_xyz.data(), 12 * n);
   if (e == hipSuccess && n) e = morton_order_device(ctx->stream, d_raw, n, lo, inv, c->d_xyzw, d_perm);
   if (e == hipSuccess && n) e = hipMemcpy(c->perm.data(), d_perm, 4 * n, hipMemcpyDeviceToHost);
   tmp_free(ctx->stream, d_raw);
@@ -506,6 +500,7 @@ int ope_cloud_upload(ope_ctx *ctx, const void *base, size_t n, size_t stride_byt
     return set_err(ctx, OPE_EHIP, std::string("ope_cloud_upload: ") + hipGetErrorString(e));
   }
   *out = c;
+  OPE_DUMP_HASH("cloud_upload xyzw", c->d_xyzw, 16 * n, true);
   if (normal_off >= 0) {
     std::vector<float> nrm(n * 3);
     for (size_t i = 0; i < n; ++i) std::memcpy(&nrm[3 * i], b + i * stride_bytes + (size_t)normal_off, 12);
@@ -529,7 +524,7 @@ int ope_cloud_set_normals(ope_ctx *ctx, ope_cloud *cloud, const float *normals_x
     packed[4 * i + 3] = 0.f;
   }
   if (!cloud->d_nrm) OPE_HIP(ctx, hipMalloc((void **)&cloud->d_nrm, sizeof(float4) * std::max<size_t>(n, 1)));
-  if (n) OPE_HIP(ctx, hipMemcpy(cloud->d_nrm, packed.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+  if (n) OPE_HIP(ctx, h2d_copy(ctx->stream, cloud->d_nrm, packed.data(), sizeof(float4) * n));
   return OPE_OK;
 }
 
@@ -585,7 +580,7 @@ int ope_cloud_concat(ope_ctx *ctx, const ope_cloud *a, const float T_a[16], cons
   if (e == hipSuccess && T_a) {
     colmajor_to_rows(T_a, rows);
     e = hipMalloc((void **)&d_rows, sizeof rows);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows, sizeof rows, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = h2d_copy(ctx->stream, d_rows, rows, sizeof rows);
   }
   float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   if (e == hipSuccess && n) e = concat_device(ctx->stream, a->view(), d_rows, b->view(), d_raw, lo, hi);
@@ -654,6 +649,8 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
     ix->grid_mode = dp.grid;
     ix->grid_fill = dp.grid_fill;
     ix->grid_max_cells = dp.grid_max_cells;
+    OPE_DUMP_HASH("index_build nodes", ix->d_nodes, 48 * ((size_t)2 << ix->depth), true);
+    OPE_DUMP_HASH("index_build pts", ix->d_pts, 16 * ix->n, true);
     *out = ix;
     return OPE_OK;
   }
@@ -688,13 +685,13 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
   std::memcpy(ix->bb_hi, target->bb_hi, sizeof ix->bb_hi);
   for (int d = 0; d < 3; ++d) ix->pivot[d] = 0.5 * ((double)target->bb_lo[d] + (double)target->bb_hi[d]);
   hipError_t e = hipMalloc((void **)&ix->d_nodes, sizeof(float) * hb.nodes.size());
-  if (e == hipSuccess) e = hipMemcpy(ix->d_nodes, hb.nodes.data(), sizeof(float) * hb.nodes.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = h2d_copy(ctx->stream, ix->d_nodes, hb.nodes.data(), sizeof(float) * hb.nodes.size());
   if (e == hipSuccess) e = hipMalloc((void **)&ix->d_pts, sizeof(float4) * (n + kPtsPad));
   if (e == hipSuccess) e = hipMemset(ix->d_pts + n, 0, sizeof(float4) * kPtsPad);
-  if (e == hipSuccess) e = hipMemcpy(ix->d_pts, hb.pts4.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = h2d_copy(ctx->stream, ix->d_pts, hb.pts4.data(), sizeof(float4) * n);
   if (e == hipSuccess && !hb.nrm4.empty()) {
     e = hipMalloc((void **)&ix->d_nrm, sizeof(float4) * n);
-    if (e == hipSuccess) e = hipMemcpy(ix->d_nrm, hb.nrm4.data(), sizeof(float4) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = h2d_copy(ctx->stream, ix->d_nrm, hb.nrm4.data(), sizeof(float4) * n);
   }
   if (e != hipSuccess) {
     ope_index_free(ix);
@@ -725,7 +722,7 @@ static int upload_T(ope_ctx *ctx, const float *T, float **d_T) {
   colmajor_to_rows(T, rows);
   int rc = ensure_scratch(ctx, 1 << 16);
   if (rc != OPE_OK) return rc;
-  OPE_HIP(ctx, hipMemcpyAsync(ctx->d_scratch, rows, sizeof rows, hipMemcpyHostToDevice, ctx->stream));
+  OPE_HIP(ctx, h2d_copy(ctx->stream, ctx->d_scratch, rows, sizeof rows));
   *d_T = static_cast<float *>(ctx->d_scratch);
   return OPE_OK;
 }
@@ -1065,6 +1062,20 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   // the pinned block is reused for read-back: make sure the upload is finished with it first
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
+#ifdef OPE_DEVELOPER
+  if (dev_env("OPE_DUMP_HASH")) {   // developer probe: checksums of everything the run reads, to stderr
+    auto fnv = [&](const void *d, size_t bytes) -> unsigned long long {
+      std::vector<unsigned char> h(bytes);
+      if (bytes && d) (void)hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost);
+      unsigned long long x = 1469598103934665603ull;
+      if (d) for (unsigned char c : h) { x ^= c; x *= 1099511628211ull; }
+      return x;
+    };
+    std::fprintf(stderr, "[hash] begin src n %zu valid %zu xyzw %016llx nrm %016llx | tgt n %zu depth %d nodes %016llx pts %016llx nrm %016llx\n", src->n,
+                 src->n_valid, fnv(src->d_xyzw, 16 * src->n), fnv(src->d_nrm, 16 * src->n), tgt->n, tgt->depth,
+                 fnv(tgt->d_nodes, 48 * ((size_t)2 << tgt->depth)), fnv(tgt->d_pts, 16 * tgt->n), fnv(tgt->d_nrm, 16 * tgt->n));
+  }
+#endif
   ctx->run_src = src;
   ctx->run_tgt = tgt;
   ctx->corr_run_n = src->n;
@@ -1369,7 +1380,7 @@ int ope_fitness(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const 
   colmajor_to_rows(T, rows);
   float *d_T = static_cast<float *>(ctx->d_scratch);
   double *d_part = reinterpret_cast<double *>(static_cast<unsigned char *>(ctx->d_scratch) + 256);
-  OPE_HIP(ctx, hipMemcpyAsync(d_T, rows, sizeof rows, hipMemcpyHostToDevice, ctx->stream));
+  OPE_HIP(ctx, h2d_copy(ctx->stream, d_T, rows, sizeof rows));
   launch_fitness(ctx->stream, nblocks, src->view(), tgt->view(), d_T, max_range, d_part);
   std::vector<double> hp(2 * (size_t)nblocks);
   OPE_HIP(ctx, hipMemcpyAsync(hp.data(), d_part, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, ctx->stream));
@@ -1393,8 +1404,8 @@ int ope_rigid_transform_svd(ope_ctx *ctx, const float *src_xyz, const float *tgt
   if (e == hipSuccess) e = hipMalloc((void **)&d_tgt, 12 * n);
   if (e == hipSuccess) e = hipMalloc((void **)&d_T, 64);
   if (e == hipSuccess) e = hipMalloc((void **)&d_part, sizeof(double) * kNumSums * nblocks);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_src, src_xyz, 12 * n, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_tgt, tgt_xyz, 12 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = h2d_copy(ctx->stream, d_src, src_xyz, 12 * n);
+  if (e == hipSuccess) e = h2d_copy(ctx->stream, d_tgt, tgt_xyz, 12 * n);
   if (e == hipSuccess) {
     launch_pairs_svd(ctx->stream, d_src, d_tgt, (uint32_t)n, d_part, nblocks, d_T);
     e = hipMemcpyAsync(out_T, d_T, 64, hipMemcpyDeviceToHost, ctx->stream);

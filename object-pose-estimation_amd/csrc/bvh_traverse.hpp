@@ -594,7 +594,10 @@ struct KnnVisitor {
 // sequence of K compare/select steps, skipped for the whole wave when no lane has a candidate.  (Round 2 put a
 // four-entry per-lane LDS queue in front of it, so that the wave inserts from all queues together instead of at nearly
 // every presented point: normal shooting k = 20 on C3 0.612 ms per iteration against 0.619 without, k = 10 0.391 / 0.381,
-// normals unchanged, eight entries 0.84 — the insertions are not what the k-NN walks wait for; not kept.)
+// normals unchanged, eight entries 0.84 — the insertions are not what the k-NN walks wait for; not kept.  Round 3 repeated
+// it with the queue drained only when a lane's is full and at the walk's end, exact to the last correspondence: 8 entries
+// at four waves per SIMD 0.574 ms against 0.537, 14 entries at three waves 0.711; and with a 32-entry buffer selected from
+// at the end, under the previous launch's bound: 2.05 ms.  Same conclusion.)
 template <int K>
 struct KnnRegVisitor {
   float d[K];

@@ -98,7 +98,7 @@ static bool p2p_self_test(ope_ctx *ctx) {
   const int n = ctx->comm_nranks;
   double pat[kP2pMaxSums], got[kP2pMaxSums];
   for (int k = 0; k < kP2pMaxSums; ++k) pat[k] = 1000.0 * (ctx->comm_rank + 1) + k + 0.25;
-  bool ok = hipMemcpyAsync(ctx->p2p_scratch, pat, sizeof pat, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+  bool ok = h2d_copy(ctx->stream, ctx->p2p_scratch, pat, sizeof pat) == hipSuccess;
   ctx->p2p_seq = 1;
   if (ok) {
     launch_icp_p2p_update(ctx->stream, nullptr, ctx->p2p_scratch, kP2pMaxSums, p2p_view(ctx), ctx->p2p_seq, 1000000000ull /* 10 s */, false,
@@ -129,7 +129,7 @@ static void p2p_setup_over_rccl(ope_ctx *ctx) {
   ncclComm_t comm = (ncclComm_t)ctx->nccl_comm;
   auto agree = [&](bool mine_ok) {   // min over ranks
     int v = mine_ok ? 1 : 0, out = 0;
-    (void)hipMemcpyAsync(d_ok, &v, sizeof v, hipMemcpyHostToDevice, ctx->stream);
+    (void)h2d_copy(ctx->stream, d_ok, &v, sizeof v);
     if (r.AllReduce(d_ok, d_ok, 1, ncclInt, ncclMin, comm, ctx->stream) != ncclSuccess) return false;
     if (hipMemcpyAsync(&out, d_ok, sizeof out, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
@@ -140,7 +140,7 @@ static void p2p_setup_over_rccl(ope_ctx *ctx) {
   bool ok = agree(have_mem && n >= 2 && n <= kP2pMaxRanks && r.AllGather && p2p_alloc(ctx, &mine));
   if (ok) {
     unsigned char *d_mine = d_handles + sizeof(hipIpcMemHandle_t) * (size_t)n;
-    const bool step = hipMemcpyAsync(d_mine, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+    const bool step = h2d_copy(ctx->stream, d_mine, &mine, sizeof mine) == hipSuccess &&
                       r.AllGather(d_mine, d_handles, sizeof mine, ncclChar, comm, ctx->stream) == ncclSuccess &&
                       hipMemcpyAsync(handles.data(), d_handles, sizeof(hipIpcMemHandle_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                       hipStreamSynchronize(ctx->stream) == hipSuccess;

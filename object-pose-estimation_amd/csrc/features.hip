@@ -622,9 +622,10 @@ static int normals_impl(ope_ctx *ctx, ope_cloud *cloud, const ope_index *index, 
   } else {
     const float qn = std::numeric_limits<float>::quiet_NaN();
     std::vector<float> nan4(n * 4, qn);
-    OPE_HIP(ctx, hipMemcpy(cloud->d_nrm, nan4.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    OPE_HIP(ctx, h2d_copy(ctx->stream, cloud->d_nrm, nan4.data(), sizeof(float4) * n));
     if (want_host) packed = nan4;
   }
+  OPE_DUMP_HASH("normals d_nrm", cloud->d_nrm, 16 * n, true);
   if (!want_host) return OPE_OK;
   { const int rch = cloud->ensure_host(); if (rch != OPE_OK) return rch; }
   for (size_t i = 0; i < n; ++i) {
@@ -779,9 +780,9 @@ int ope_sacia(ope_ctx *ctx, const ope_cloud *src, const float *src_feat33, const
     int32_t *d_nn = nullptr;
     std::vector<int32_t> nn(uniq.size() * K);
     hipError_t e = hipMalloc((void **)&d_tf, sizeof(float) * 33 * (size_t)nt);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_tf, tgt_feat33, sizeof(float) * 33 * (size_t)nt, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = h2d_copy(ctx->stream, d_tf, tgt_feat33, sizeof(float) * 33 * (size_t)nt);
     if (e == hipSuccess) e = hipMalloc((void **)&d_qf, sizeof(float) * qf.size());
-    if (e == hipSuccess) e = hipMemcpyAsync(d_qf, qf.data(), sizeof(float) * qf.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = h2d_copy(ctx->stream, d_qf, qf.data(), sizeof(float) * qf.size());
     if (e == hipSuccess) e = hipMalloc((void **)&d_nn, sizeof(int32_t) * nn.size());
     if (e == hipSuccess) {
       {
@@ -822,7 +823,7 @@ int ope_sacia(ope_ctx *ctx, const ope_cloud *src, const float *src_feat33, const
   double *d_part = nullptr;
   std::vector<double> part((size_t)H * bx);
   hipError_t e = hipMalloc((void **)&d_rows, sizeof(float) * rows.size());
-  if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows.data(), sizeof(float) * rows.size(), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = h2d_copy(ctx->stream, d_rows, rows.data(), sizeof(float) * rows.size());
   if (e == hipSuccess) e = hipMalloc((void **)&d_part, sizeof(double) * part.size());
   if (e == hipSuccess) {
     {

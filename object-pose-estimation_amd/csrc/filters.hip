@@ -205,6 +205,7 @@ static int box_filter(ope_ctx *ctx, const ope_cloud *cloud, const float lo[3], c
   if (count) e = hipMemcpy(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost);
   tmp_free(ctx->stream, d_out);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string(who) + ": " + hipGetErrorString(e));
+  OPE_DUMP_HASH(who, out_idx, 4 * (size_t)count, false);
   *n_out = count;
   return OPE_OK;
 }
@@ -292,7 +293,7 @@ extern "C" int ope_voxel_grid_rgb(ope_ctx *ctx, const ope_cloud *cloud, const fl
   hipError_t e = hipMalloc((void **)&d_keys, 8 * n);
   if (e == hipSuccess && rgb) e = hipMalloc((void **)&d_rgb, 4 * n);
   if (e == hipSuccess && rgb) e = hipMalloc((void **)&d_out_rgb, 4 * nv);
-  if (e == hipSuccess && rgb) e = hipMemcpyAsync(d_rgb, rgb, 4 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && rgb) e = h2d_copy(ctx->stream, d_rgb, rgb, 4 * n);
   if (e == hipSuccess) e = hipMalloc((void **)&d_keys2, 8 * n);
   if (e == hipSuccess) e = hipMalloc((void **)&d_vals, 4 * n);
   if (e == hipSuccess) e = hipMalloc((void **)&d_vals2, 4 * n);
@@ -445,8 +446,8 @@ extern "C" int ope_reject_pairs(ope_ctx *ctx, int kind, const float *a, const fl
   hipError_t e = hipMalloc((void **)&d_a, 12 * n);
   if (e == hipSuccess) e = hipMalloc((void **)&d_b, 12 * n);
   if (e == hipSuccess) e = hipMalloc((void **)&d_k, n);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_a, a, 12 * n, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_b, b, 12 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = h2d_copy(ctx->stream, d_a, a, 12 * n);
+  if (e == hipSuccess) e = h2d_copy(ctx->stream, d_b, b, 12 * n);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(reject_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, kind, d_a, d_b, (uint32_t)n, threshold, d_k);
     e = hipMemcpyAsync(keep, d_k, n, hipMemcpyDeviceToHost, ctx->stream);

@@ -1496,7 +1496,7 @@ extern "C" int ope_debug_visit_counts(ope_ctx *ctx, const ope_cloud *q, const op
   OPE_HIP(ctx, hipMalloc((void **)&d_n, 4 * n));
   OPE_HIP(ctx, hipMalloc((void **)&d_p, 4 * n));
   OPE_HIP(ctx, hipMalloc((void **)&d_T, sizeof rows));
-  OPE_HIP(ctx, hipMemcpy(d_T, rows, sizeof rows, hipMemcpyHostToDevice));
+  OPE_HIP(ctx, h2d_copy(ctx->stream, d_T, rows, sizeof rows));
   hipLaunchKernelGGL(debug_visit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, q->view(), ix->view(),
                      d_T, d_n, d_p);
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1657,7 +1657,7 @@ extern "C" int ope_debug_chunk_profile(ope_ctx *ctx, const ope_cloud *q, const o
   OPE_HIP(ctx, hipMalloc((void **)&d_T, sizeof rows));
   OPE_HIP(ctx, hipMalloc((void **)&d_out, sizeof(long long) * 10 * nch));
   OPE_HIP(ctx, hipMemset(d_out, 0, sizeof(long long) * 10 * nch));
-  OPE_HIP(ctx, hipMemcpy(d_T, rows, sizeof rows, hipMemcpyHostToDevice));
+  OPE_HIP(ctx, h2d_copy(ctx->stream, d_T, rows, sizeof rows));
   const unsigned nb = (unsigned)((nch + kAccBlock / 64 - 1) / (kAccBlock / 64));
   hipLaunchKernelGGL(debug_chunk_kernel, dim3(nb), dim3(kAccBlock), 0, ctx->stream, q->view(), ix->view(), d_T, ctx->d_hint,
                      (use_hint && ctx->d_hint) ? 1 : 0, d_out);

@@ -9,6 +9,9 @@
 #include <mutex>
 #include <string>
 #include <utility>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/ope.h"
@@ -261,25 +264,150 @@ struct ope_index {
 
 namespace ope {
 
-// Temporaries of one entry point: stream-ordered allocations from the device's default memory pool, whose release threshold
-// ope_ctx_create raises so that the pool keeps what it has been given (a hipMalloc / hipFree pair of a few MB costs ~0.5 ms and
-// the free synchronises the device: the front-end stages were made of them).  Buffers that outlive the call (clouds, indexes)
-// stay plain hipMalloc.
-#ifdef OPE_NO_POOL   // (A/B build)
-inline hipError_t tmp_malloc(hipStream_t, void **p, size_t bytes) { return hipMalloc(p, std::max<size_t>(bytes, 16)); }
-inline void tmp_free(hipStream_t, void *p) { if (p) (void)hipFree(p); }
-#elif defined(OPE_POISON_TMP)   // (A/B build: every temporary starts out as 0xA5 bytes — a read of memory nobody wrote changes results)
-inline hipError_t tmp_malloc(hipStream_t s, void **p, size_t bytes) {
-  const hipError_t e = hipMallocAsync(p, std::max<size_t>(bytes, 16), s);
-  return e != hipSuccess ? e : hipMemsetAsync(*p, 0xA5, std::max<size_t>(bytes, 16), s);
+// Temporaries of one entry point: blocks from a cache over hipMalloc, one free list per stream (a hipMalloc / hipFree pair of a
+// few MB costs ~0.5 ms and the free synchronises the device: the front-end stages were made of them).  A block goes back to
+// the list at tmp_free and is handed out again to later work ON THE SAME STREAM, which runs behind the work that used it
+// before; ope_ctx_destroy returns its stream's blocks to the device.  Buffers that outlive the call (clouds, indexes) stay
+// plain hipMalloc.
+// (Round 3 first took these from the device's memory pool, hipMallocAsync / hipFreeAsync.  In a fresh process the first
+// use of a newly grown pool block came back ZERO, or partly written, to the kernels behind a completed, synchronised copy into
+// it: 4-15 of 16 runs of the C++ facade uploaded a 749-point cloud as zeros, tools/flake_hash.sh.  Memory from hipMalloc
+// never did.)
+struct TmpCache {
+  struct Block { void *p; size_t cap; hipStream_t stream; int device; };
+  std::mutex mu;
+  std::vector<Block> idle, live;
+  size_t idle_bytes = 0;
+};
+inline TmpCache &tmp_cache() { static TmpCache *c = new TmpCache(); return *c; }   // never destroyed: outlives the HIP runtime's teardown
+constexpr size_t kTmpCacheMaxIdleBytes = (size_t)4 << 30;
+
+inline void tmp_trim_locked(TmpCache &c, hipStream_t only_stream, bool all) {
+  for (size_t k = 0; k < c.idle.size();) {
+    if (all || c.idle[k].stream == only_stream) {
+      (void)hipFree(c.idle[k].p);   // (synchronises the device: nothing still reads the block)
+      c.idle_bytes -= c.idle[k].cap;
+      c.idle[k] = c.idle.back();
+      c.idle.pop_back();
+    } else ++k;
+  }
 }
-inline void tmp_free(hipStream_t s, void *p) { if (p) (void)hipFreeAsync(p, s); }
+
+inline hipError_t tmp_malloc(hipStream_t s, void **p, size_t bytes) {
+  *p = nullptr;
+  bytes = std::max<size_t>(bytes, 256);
+  size_t gran = 256;
+  while (gran * 16 < bytes) gran <<= 1;                 // sizes in steps of 1/16 .. 1/8 of the request
+  const size_t cap = (bytes + gran - 1) / gran * gran;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  TmpCache &c = tmp_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  size_t best = c.idle.size();
+  for (size_t k = 0; k < c.idle.size(); ++k)
+    if (c.idle[k].stream == s && c.idle[k].device == dev && c.idle[k].cap >= cap && c.idle[k].cap <= 2 * cap &&
+        (best == c.idle.size() || c.idle[k].cap < c.idle[best].cap))
+      best = k;
+  TmpCache::Block b{nullptr, cap, s, dev};
+  if (best != c.idle.size()) {
+    b = c.idle[best];
+    c.idle_bytes -= b.cap;
+    c.idle[best] = c.idle.back();
+    c.idle.pop_back();
+  } else {
+    hipError_t e = hipMalloc(&b.p, cap);
+    if (e != hipSuccess) {   // out of memory: give the idle blocks back and try once more
+      (void)hipGetLastError();
+      tmp_trim_locked(c, nullptr, true);
+      e = hipMalloc(&b.p, cap);
+      if (e != hipSuccess) return e;
+    }
+  }
+  c.live.push_back(b);
+  *p = b.p;
+#ifdef OPE_POISON_TMP   // (A/B build: every temporary starts out as 0xA5 bytes — a read of memory nobody wrote changes results)
+  return hipMemsetAsync(b.p, 0xA5, bytes, s);
 #else
-inline hipError_t tmp_malloc(hipStream_t s, void **p, size_t bytes) { return hipMallocAsync(p, std::max<size_t>(bytes, 16), s); }
-inline void tmp_free(hipStream_t s, void *p) { if (p) (void)hipFreeAsync(p, s); }
+  return hipSuccess;
 #endif
+}
+
+inline void tmp_free(hipStream_t, void *p) {
+  if (!p) return;
+  TmpCache &c = tmp_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  for (size_t k = 0; k < c.live.size(); ++k)
+    if (c.live[k].p == p) {
+      c.idle.push_back(c.live[k]);
+      c.idle_bytes += c.live[k].cap;
+      c.live[k] = c.live.back();
+      c.live.pop_back();
+      if (c.idle_bytes > kTmpCacheMaxIdleBytes) tmp_trim_locked(c, nullptr, true);
+      return;
+    }
+  (void)hipFree(p);   // not one of ours
+}
+
+// a stream is going away: its idle blocks go back to the device
+inline void tmp_release_stream(hipStream_t s) {
+  TmpCache &c = tmp_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  tmp_trim_locked(c, s, false);
+}
 
 int set_err(ope_ctx *ctx, int code, const std::string &msg);
+
+// Host -> device copy from ANY host memory (the caller's arrays, vectors, stack variables), complete when it returns: through a
+// pinned staging block and a stream-ordered DMA, so that no entry point depends on what hipMemcpyAsync does with pageable
+// memory (staged at call time, pinned in place, or written through the BAR, by size and release).  Introduced while hunting the
+// facade's run-to-run differences (round 3, see tmp_malloc for what they were); every upload synchronises soon after anyway.
+inline hipError_t h2d_copy(hipStream_t stream, void *dst, const void *src, size_t bytes) {
+  static std::mutex mu;
+  static unsigned char *stage = nullptr;
+  static size_t cap = 0;
+  constexpr size_t kChunk = (size_t)32 << 20;
+  if (bytes == 0) return hipSuccess;
+  std::lock_guard<std::mutex> lock(mu);
+  const size_t want = std::min(std::max(bytes, (size_t)65536), kChunk);
+  if (cap < want) {
+    if (stage) (void)hipHostFree(stage);
+    stage = nullptr; cap = 0;
+    const hipError_t e = hipHostMalloc((void **)&stage, want, hipHostMallocPortable);
+    if (e != hipSuccess) return e;
+    cap = want;
+  }
+  for (size_t off = 0; off < bytes; off += cap) {
+    const size_t c = std::min(cap, bytes - off);
+    std::memcpy(stage, static_cast<const unsigned char *>(src) + off, c);
+    hipError_t e = hipMemcpyAsync(static_cast<unsigned char *>(dst) + off, stage, c, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+#ifdef OPE_DEVELOPER
+// developer probe (OPE_DUMP_HASH=1): FNV-1a checksum of a host or device buffer to stderr
+inline void dev_dump_hash(const char *what, const void *p, size_t bytes, bool device) {
+  static const bool on = std::getenv("OPE_DUMP_HASH") != nullptr;
+  if (!on) return;
+  std::vector<unsigned char> h(bytes);
+  if (bytes && p) { if (device) (void)hipMemcpy(h.data(), p, bytes, hipMemcpyDeviceToHost); else std::memcpy(h.data(), p, bytes); }
+  unsigned long long x = 1469598103934665603ull;
+  if (p) for (unsigned char c : h) { x ^= c; x *= 1099511628211ull; }
+  std::fprintf(stderr, "[hash] %s bytes %zu %016llx\n", what, bytes, x);
+  if (const char *dir = std::getenv("OPE_DUMP_DIR")) {   // and the buffer itself, numbered in call order
+    static int seq = 0;
+    char path[512];
+    std::snprintf(path, sizeof path, "%s/%03d_%zu.bin", dir, seq++, bytes);
+    if (bytes <= 65536) if (FILE *f = std::fopen(path, "wb")) { std::fwrite(h.data(), 1, bytes, f); std::fclose(f); }
+  }
+}
+#define OPE_DUMP_HASH(WHAT, P, BYTES, DEVICE) ope_dump_hash_fn(WHAT, P, BYTES, DEVICE)
+inline void ope_dump_hash_fn(const char *w, const void *p, size_t b, bool d) { dev_dump_hash(w, p, b, d); }
+#else
+#define OPE_DUMP_HASH(WHAT, P, BYTES, DEVICE) ((void)0)
+#endif
 
 // RAII HIP-event bracket around ONE kernel launch on the context stream, recorded under `name` together with the
 // launch's algorithmic bytes (SURVEY.md §8d formulas) when ope_profile_kernels(ctx, 1) is on; otherwise a no-op.

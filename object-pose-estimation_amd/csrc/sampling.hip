@@ -463,7 +463,7 @@ hipError_t concat_device(hipStream_t stream, const CloudView &a, const float *d_
   uint32_t *d_mm = nullptr;
   hipError_t e = tmp_malloc(stream, (void **)&d_mm, 32);
   uint32_t init[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0u, 0u, 0u, 0};
-  if (e == hipSuccess) e = hipMemcpyAsync(d_mm, init, sizeof init, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = h2d_copy(stream, d_mm, init, sizeof init);
   uint32_t res[8];
   if (e == hipSuccess) {
     hipLaunchKernelGGL(concat_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a, d_T_rows, b, d_raw, d_mm, d_mm + 4);
@@ -535,7 +535,7 @@ int select_cloud_device(ope_ctx *ctx, const ope_cloud *cloud, const int32_t *d_i
   if (e == hipSuccess && n_sel) e = tmp_malloc(ctx->stream, (void **)&d_mm, 48);
   uint32_t res[12] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0u, 0u, 0u, 0, 0u, 0, 0, 0};
   if (e == hipSuccess && n_sel) {
-    e = hipMemcpyAsync(d_mm, res, sizeof res, hipMemcpyHostToDevice, ctx->stream);
+    e = h2d_copy(ctx->stream, d_mm, res, sizeof res);
     hipLaunchKernelGGL(inverse_perm_kernel, dim3((unsigned)((cloud->n + 255) / 256)), dim3(256), 0, ctx->stream, cv, d_inv);
     hipLaunchKernelGGL(select_gather_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, ctx->stream, cv, d_inv, d_idx, (uint32_t)n_sel, d_raw,
                        d_mm, d_mm + 4, d_mm + 8);
@@ -642,7 +642,7 @@ int compact_cloud_device(ope_ctx *ctx, const ope_cloud *cloud, const unsigned ch
     c->d_nrm = d_n;
   }
   if (e == hipSuccess && n) {
-    e = hipMemcpyAsync(d_mm, res, sizeof res, hipMemcpyHostToDevice, st);
+    e = h2d_copy(st, d_mm, res, sizeof res);
     hipLaunchKernelGGL(compact_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cloud->view(), d_fs, d_ro, d_rs, d_x, d_n, d_idx_out, d_mm, d_mm + 4,
                        d_mm + 8);
     if (e == hipSuccess) e = hipMemcpyAsync(res, d_mm, sizeof res, hipMemcpyDeviceToHost, st);
@@ -739,6 +739,7 @@ extern "C" int ope_uniform_sampling(ope_ctx *ctx, const ope_cloud *cloud, float 
   if (count) e = hipMemcpy(out_idx, d_out, 4 * (size_t)count, hipMemcpyDeviceToHost);
   tmp_free(ctx->stream, d_out);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_uniform_sampling: ") + hipGetErrorString(e));
+  OPE_DUMP_HASH("uniform_sampling idx", out_idx, 4 * (size_t)count, false);
   *n_out = count;
   return OPE_OK;
 }
@@ -768,7 +769,7 @@ extern "C" int ope_cloud_select(ope_ctx *ctx, const ope_cloud *cloud, const int3
   int32_t *d_idx = nullptr;
   if (n) {
     OPE_HIP(ctx, tmp_malloc(ctx->stream, (void **)&d_idx, 4 * n));
-    const hipError_t e = hipMemcpyAsync(d_idx, idx, 4 * n, hipMemcpyHostToDevice, ctx->stream);
+    const hipError_t e = h2d_copy(ctx->stream, d_idx, idx, 4 * n);
     if (e != hipSuccess) { tmp_free(ctx->stream, d_idx); return set_err(ctx, OPE_EHIP, std::string("ope_cloud_select: ") + hipGetErrorString(e)); }
   }
   const int rc = select_cloud_device(ctx, cloud, d_idx, n, out);

@@ -181,3 +181,21 @@ def test_dense_model_second_frame_skips_the_coarse_stage(tmp_path):
     _check(frames, model, [scene, scene2], seed=3)
     # the pipeline finds the object: alignedSource lies on the scene (fitness), and frame 2's re-anchoring fit is frame 1's motion
     assert _frob(frames[1]["rigid"][:3, :3], (frames[0]["fine"] @ frames[0]["coarse"])[:3, :3]) < 5e-3
+
+
+def test_facade_runs_are_reproducible_across_processes(tmp_path):
+    """Three fresh processes on the same files print the same frames, digit for digit.  (Round 3: the first use of a newly
+    grown block of the device memory pool could reach the kernels as zeros, so 4-15 of 16 facade processes uploaded one of
+    their small clouds wrongly and the fine poses differed from run to run in the fourth digit; temporaries now come from a
+    cache over hipMalloc, tools/flake_hash.sh is the probe that found it.)"""
+    model = synth.model_surface(30_000, 1)
+    gt = np.eye(4); gt[:3, :3] = synth.rot_xyz(20.0, -15.0, 40.0); gt[:3, 3] = [0.03, -0.02, 0.7]
+    scene = (synth.model_surface(30_000, 2).astype(np.float64) @ gt[:3, :3].T + gt[:3, 3]).astype(np.float32)
+    mp_, p1 = str(tmp_path / "model.pcd"), str(tmp_path / "s1.pcd")
+    pcd.write_pcd(mp_, model); pcd.write_pcd(p1, scene)
+    outs = []
+    for _ in range(3):
+        r = subprocess.run([EXE, mp_, p1, "--seed", "3"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("frame ")])
+    assert outs[0] and outs[0] == outs[1] == outs[2]
