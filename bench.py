@@ -312,10 +312,15 @@ def main() -> int:
         kms = kmn / max(knn, 1)
         ns_bytes = 60.0 * n_scene + 24.0 * n_model      # SURVEY 8d, "with normals": 60 B per source point + 24 B per target point
         ns_gbs = ns_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        ns_traffic = None
+        try:
+            ns_traffic = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json"))).get(args.workload + "-ns", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            ns_traffic = None
         ns_leg = {"workload": "C3-ns: the same clouds, normal shooting k = 20 + surface-normal rejector 0.7 (estimateFinePose's correspondence estimation), SVD estimator",
                   "steps": Kn, "warmup": Wn, "ms_per_step": dtn / Kn * 1e3, "iterations_per_s": Kn / dtn, "n_corr": int(on.n_corr),
                   "normals_and_index_ms": t_prep * 1e3,
-                  "roofline": {"bound": "hbm", "achieved": ns_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ns_gbs / HBM_PEAK_GBS, "traffic": None,
+                  "roofline": {"bound": "hbm", "achieved": ns_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ns_gbs / HBM_PEAK_GBS, "traffic": ns_traffic,
                                "kernel": "icp_accumulate_kernel<2,true,false,*,20>", "kernel_ms": kms, "launches_timed": knn,
                                "algorithmic_bytes_per_launch": ns_bytes}}
 
@@ -336,7 +341,7 @@ def main() -> int:
         algo_bytes = 36.0 * n_local + 12.0 * n_model
         achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
         traffic, traffic_source = None, None
-        tf = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
         if world == 1 and os.path.exists(tf):
             try:
                 rec = json.load(open(tf)).get(args.workload)

@@ -598,11 +598,19 @@ struct KnnVisitor {
 // it with the queue drained only when a lane's is full and at the walk's end, exact to the last correspondence: 8 entries
 // at four waves per SIMD 0.574 ms against 0.537, 14 entries at three waves 0.711; and with a 32-entry buffer selected from
 // at the end, under the previous launch's bound: 2.05 ms.  Same conclusion.)
+#ifdef OPE_KNN_STATS   // (developer counters: executions at wave level are counted by the first active lane)
+#define OPE_KNN_STAT(J) do { if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) ++stat[J]; } while (0)
+#else
+#define OPE_KNN_STAT(J) do { } while (0)
+#endif
 template <int K>
 struct KnnRegVisitor {
   float d[K];
   uint32_t p[K];
   int count;
+#ifdef OPE_KNN_STATS
+  uint32_t stat[5] = {0, 0, 0, 0, 0};   // presentations, insertion sequences, node steps, - (wave level); passing candidates (per lane)
+#endif
   uint32_t leaf;   // leaf of the current nearest entry (next iteration's start hint)
   // bound: only points strictly closer than this can enter the list (+inf: plain k-NN; a finite value that is known to
   // lie above the K-th neighbour's distance gives the same list and prunes from the first box on)
@@ -616,7 +624,12 @@ struct KnnRegVisitor {
   __device__ __forceinline__ float bound() const { return d[K - 1]; }
   __device__ __forceinline__ void point(float dist, const v4f &, uint32_t i, uint32_t lf) {
     const bool ins = dist < d[K - 1];
+#ifdef OPE_KNN_STATS
+    OPE_KNN_STAT(0);             // point presentations (wave level)
+    if (ins) ++stat[4];          // candidates that pass (per lane)
+#endif
     if (__ballot(ins) == 0ull) return;
+    OPE_KNN_STAT(1);             // insertion sequences executed (wave level)
     if (ins && dist < d[0]) leaf = lf;
     count += (ins && count < K) ? 1 : 0;
     // Sorted insert of `dist` into ascending d[]: new d[j] = median(d[j-1], d[j], dist) — one v_med3_f32 per slot —
@@ -634,7 +647,7 @@ struct KnnRegVisitor {
     p[0] = lt_hi ? i : p[0];
     d[0] = fminf(d[0], dist);
   }
-  __device__ __forceinline__ void on_node() {}
+  __device__ __forceinline__ void on_node() { OPE_KNN_STAT(2); }
 };
 
 constexpr int kKnnBlock = 256;

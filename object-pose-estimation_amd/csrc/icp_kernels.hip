@@ -95,6 +95,9 @@ __device__ __forceinline__ void add_query_sums(double *acc, lds_cfloat_ptr cs2, 
 // if the nearest SOURCE point of target point j is i again.  The reference searches a kd-tree rebuilt
 // over the transformed source every iteration; here the source index is built once in the source's own
 // frame and queried with F^-1 * t_j (a rigid map preserves the ranking up to fp32 rounding).
+#ifdef OPE_KNN_STATS
+__device__ unsigned long long g_knn_stats[8];
+#endif
 template <int MODE, bool NRM, bool RECIP = false, bool PACKET = false, int KREG = 20>
 __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !RECIP) ? kAccWavesPerSimd : 4) void icp_accumulate_kernel(
     CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
@@ -299,6 +302,13 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
         todo = retry;
         bound0 = INFINITY;
       }
+#ifdef OPE_KNN_STATS
+      {
+        unsigned long long t[5];
+        for (int j = 0; j < 5; ++j) { t[j] = v.stat[j]; for (int off = 32; off >= 1; off >>= 1) t[j] += __shfl_xor(t[j], off, 64); }
+        if (lane_id == 0) { for (int j = 0; j < 5; ++j) atomicAdd(&g_knn_stats[j], t[j]); atomicAdd(&g_knn_stats[5], 1ull); }
+      }
+#endif
       if (!active) v.init(false);
       if (active) {
         hint[i] = v.leaf;
@@ -1667,3 +1677,11 @@ extern "C" int ope_debug_chunk_profile(ope_ctx *ctx, const ope_cloud *q, const o
   return OPE_OK;
 }
 #endif  // OPE_DEVELOPER
+
+#ifdef OPE_KNN_STATS
+extern "C" int ope_dev_knn_stats(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ope::g_knn_stats), 64) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ope::g_knn_stats), z, 64) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
