@@ -118,6 +118,8 @@ __device__ __forceinline__ void bvh_traverse(const BvhView &t, float qx, float q
 // together) 442 us vs 283 us; one unified 6-load trip per lane state 467 us; round 2: back up -> step -> leaf scan within
 // one trip for a lane that can flow through (fewer trips, the same phases per trip): tree kernel 155-163 us vs 153-156 on
 // the C3 frame, 97-98 vs 95-97 without clutter (the costly chunks are served by packet and group walks, not by this loop).
+// Round 3: two levels per trip (the four grandchildren, 192 contiguous bytes, instead of the two children): 149.5 vs 143 us on a
+// clutter-only launch, 162-165 vs 154 on C3 — extra box tests and eight spilled VGPRs cost more than the halved trips gain.
 // node_done: `node` has been dealt with already (start by backing up).
 template <class Visitor>
 __device__ __forceinline__ void bvh_walk(const BvhView &t, float qx, float qy, float qz, Visitor &v, float *stk, int stk_stride,
@@ -126,35 +128,6 @@ __device__ __forceinline__ void bvh_walk(const BvhView &t, float qx, float qy, f
   for (;;) {
     if (node_done) {
       node_done = false;
-#ifdef OPE_STEP2
-    } else if (node < (leaf0 >> 1)) {
-      // two levels per trip: the four grandchildren (192 contiguous bytes) instead of the two children — a descent that
-      // dies after one or two levels (most do) costs one dependent trip instead of two; the bound of a child is the
-      // smaller of its two children's bounds (tighter than its own box)
-      v.on_node();
-      const float4 *o = t.nodes + 12 * (size_t)node;
-      const v4f a0 = ld16(o), a1 = ld16(o + 1), a2 = ld16(o + 2), b0 = ld16(o + 3), b1 = ld16(o + 4), b2 = ld16(o + 5);
-      const v4f e0 = ld16(o + 6), e1 = ld16(o + 7), e2 = ld16(o + 8), f0 = ld16(o + 9), f1 = ld16(o + 10), f2 = ld16(o + 11);
-      const float d00 = obb_dist2(a0, a1, a2, qx, qy, qz), d01 = obb_dist2(b0, b1, b2, qx, qy, qz);
-      const float d10 = obb_dist2(e0, e1, e2, qx, qy, qz), d11 = obb_dist2(f0, f1, f2, qx, qy, qz);
-      const float lb0 = fminf(d00, d01), lb1 = fminf(d10, d11);
-      const bool go1 = lb1 < lb0;
-      const float cn = go1 ? lb1 : lb0, cf = go1 ? lb0 : lb1;
-      if (!v.prune(cn)) {
-        const uint32_t child = 2 * node + (go1 ? 1u : 0u);
-        const bool pc = !v.prune(cf);
-        trail = (trail << 1) | (pc ? 1u : 0u);
-        if (pc) { stk[(31 - __clz(child)) * stk_stride] = cf; minb = fminf(minb, cf); }
-        const float g0 = go1 ? d10 : d00, g1 = go1 ? d11 : d01;
-        const bool right = g1 < g0;
-        const float gf = right ? g0 : g1;
-        node = 2 * child + (right ? 1u : 0u);
-        const bool pg = !v.prune(gf);
-        trail = (trail << 1) | (pg ? 1u : 0u);
-        if (pg) { stk[(31 - __clz(node)) * stk_stride] = gf; minb = fminf(minb, gf); }
-        continue;
-      }
-#endif
     } else if (node < leaf0) {
       v.on_node();
       v4f c0, c1, c2, c3, c4, c5;
