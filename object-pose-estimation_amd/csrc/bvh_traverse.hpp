@@ -236,6 +236,156 @@ struct NearestVisitor {
 template <> struct leaf_rescan_is_harmless<NearestVisitor> { static constexpr bool value = true; };
 
 // ------------------------------------------------------------------------------------------
+// Per-lane 1-NN walk with DEFERRED leaf scans (round 3).  In the flat loop of bvh_walk a trip costs the wave a node step AND a
+// leaf scan AND a back-up as soon as its lanes are at different phases of their walks, which on the chunks that end a launch
+// (clutter far from the surface: ~50 node steps and ~9 leaf scans per lane) is every trip: in-kernel stamps put the leaf
+// scan at half of such a trip although a lane needs it on one trip in seven.  Here a lane that reaches a leaf only notes it
+// (a queue of `qcap` entries in the unused rows of its parked-bound column) and walks on; the wave scans the noted leaves
+// together, position by position, when no lane can walk any further (queues full, or walks finished), and then resumes.
+// Exact: a deferred leaf is scanned before the walk returns, and a bound that is tested against an older `best` only
+// lets more through.  The leaf of the start hint is scanned up front (it gives the bound everything else is pruned with)
+// and so is the first leaf of a walk that has no candidate yet.
+#ifndef OPE_SCAN_BATCH
+#define OPE_SCAN_BATCH 8u
+#endif
+__device__ __forceinline__ void scan_leaf_nearest(const BvhView &t, uint32_t node, float qx, float qy, float qz, NearestVisitor &v) {
+  const uint32_t j = node - (1u << t.depth);
+  const uint32_t s = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
+  const uint32_t e = (uint32_t)(((unsigned long long)(j + 1) * t.n) >> t.depth);
+  const uint32_t pos0 = v.pos;
+#define OPE_LEAF_POINT_SEL(P, IDX)                                                                       \
+  {                                                                                                      \
+    const float d_ = sq_dist3(__fsub_rn(qx, P.x), __fsub_rn(qy, P.y), __fsub_rn(qz, P.z));               \
+    const bool c_ = d_ < v.best;                                                                         \
+    v.best = c_ ? d_ : v.best;                                                                           \
+    v.pos = c_ ? (IDX) : v.pos;                                                                          \
+  }
+  if (e - s >= OPE_SCAN_BATCH) {
+    for (uint32_t i = s;; i += OPE_SCAN_BATCH) {
+      const bool last = i + OPE_SCAN_BATCH >= e;
+      const uint32_t b = last ? e - OPE_SCAN_BATCH : i;
+      const float4 *p = t.pts + b;
+#if OPE_SCAN_BATCH == 8
+      const v4f p0 = ld16(p), p1 = ld16(p + 1), p2 = ld16(p + 2), p3 = ld16(p + 3), p4 = ld16(p + 4), p5 = ld16(p + 5),
+                p6 = ld16(p + 6), p7 = ld16(p + 7);
+#else
+      const v4f p0 = ld16(p), p1 = ld16(p + 1), p2 = ld16(p + 2), p3 = ld16(p + 3);
+#endif
+      OPE_LEAF_POINT_SEL(p0, b);
+      OPE_LEAF_POINT_SEL(p1, b + 1u);
+      OPE_LEAF_POINT_SEL(p2, b + 2u);
+      OPE_LEAF_POINT_SEL(p3, b + 3u);
+#if OPE_SCAN_BATCH == 8
+      OPE_LEAF_POINT_SEL(p4, b + 4u);
+      OPE_LEAF_POINT_SEL(p5, b + 5u);
+      OPE_LEAF_POINT_SEL(p6, b + 6u);
+      OPE_LEAF_POINT_SEL(p7, b + 7u);
+#endif
+      if (last) break;
+    }
+  } else {
+    for (uint32_t i = s; i < e; ++i) {
+      const v4f p0 = ld16(t.pts + i);
+      OPE_LEAF_POINT_SEL(p0, i);
+    }
+  }
+#undef OPE_LEAF_POINT_SEL
+  v.leaf = (v.pos != pos0) ? node : v.leaf;
+}
+
+__device__ __forceinline__ void bvh_traverse_deferred(const BvhView &t, float qx, float qy, float qz, NearestVisitor &v, float *stk,
+                                                      int stk_stride, uint32_t start_leaf, int qcap) {
+  const uint32_t leaf0 = 1u << t.depth;
+  const int D = t.depth;
+  uint32_t node = 1;
+  uint32_t trail = 0;
+  float minb = INFINITY;
+  bool node_done = false;
+  if (start_leaf != 0) {
+    node = start_leaf;
+    trail = leaf0 - 1u;
+    for (int k = 0; k < D; k += 4) {
+      v4f a0, b0, c0, a1, b1, c1, a2, b2, c2, a3, b3, c3;
+      const uint32_t s0 = (start_leaf >> k) ^ 1u;
+      const uint32_t s1 = (k + 1 < D) ? ((start_leaf >> (k + 1)) ^ 1u) : s0;
+      const uint32_t s2 = (k + 2 < D) ? ((start_leaf >> (k + 2)) ^ 1u) : s0;
+      const uint32_t s3 = (k + 3 < D) ? ((start_leaf >> (k + 3)) ^ 1u) : s0;
+      load_node(t, s0, a0, b0, c0);
+      load_node(t, s1, a1, b1, c1);
+      load_node(t, s2, a2, b2, c2);
+      load_node(t, s3, a3, b3, c3);
+      const float e0 = obb_dist2(a0, b0, c0, qx, qy, qz), e1 = obb_dist2(a1, b1, c1, qx, qy, qz),
+                  e2 = obb_dist2(a2, b2, c2, qx, qy, qz), e3 = obb_dist2(a3, b3, c3, qx, qy, qz);
+      stk[(D - k) * stk_stride] = e0;
+      if (k + 1 < D) stk[(D - k - 1) * stk_stride] = e1;
+      if (k + 2 < D) stk[(D - k - 2) * stk_stride] = e2;
+      if (k + 3 < D) stk[(D - k - 3) * stk_stride] = e3;
+      minb = fminf(minb, fminf(fminf(e0, e1), fminf(e2, e3)));
+    }
+    scan_leaf_nearest(t, start_leaf, qx, qy, qz, v);   // the bound everything else is pruned with
+    node_done = true;
+  } else {
+    v4f a, b, c;
+    load_node(t, 1, a, b, c);
+    if (v.prune(obb_dist2(a, b, c, qx, qy, qz))) return;
+  }
+  uint32_t *lq = reinterpret_cast<uint32_t *>(stk) + (D + 1) * stk_stride;   // rows D+1 .. D+qcap of this lane's column
+  int nq = 0;
+  bool walking = true, stall = false;
+  for (;;) {
+    // ---- walk: node steps and back-ups only
+    while (__ballot(walking && !stall && nq < qcap) != 0ull) {
+      if (walking && !stall && nq < qcap) {
+        bool descend = false;
+        if (!node_done) {
+          if (node < leaf0) {
+            v4f c0, c1, c2, c3, c4, c5;
+            load_node(t, 2 * node, c0, c1, c2);
+            load_node(t, 2 * node + 1, c3, c4, c5);
+            const float d0 = obb_dist2(c0, c1, c2, qx, qy, qz);
+            const float d1 = obb_dist2(c3, c4, c5, qx, qy, qz);
+            const bool right = d1 < d0;
+            const float dn = right ? d1 : d0;
+            const float df = right ? d0 : d1;
+            if (!v.prune(dn)) {
+              node = 2 * node + (right ? 1u : 0u);
+              const bool pend = !v.prune(df);
+              trail = (trail << 1) | (pend ? 1u : 0u);
+              if (pend) { stk[(31 - __clz(node)) * stk_stride] = df; minb = fminf(minb, df); }
+              descend = true;
+            }
+          } else {
+            lq[nq * stk_stride] = node;
+            ++nq;
+            stall = v.pos == kNoPos;   // no candidate yet: this leaf is scanned before the walk goes on
+          }
+        }
+        node_done = false;
+        if (!descend) {
+          // back up to the deepest pending sibling whose parked bound still beats the current best
+          if (v.prune(minb)) walking = false;
+          else {
+            for (;;) {
+              if (trail == 0) { walking = false; break; }
+              const int k = __builtin_ctz(trail);
+              node = (node >> k) ^ 1u;
+              trail = (trail >> k) & ~1u;
+              if (!v.prune(stk[(31 - __clz(node)) * stk_stride])) break;
+            }
+          }
+        }
+      }
+    }
+    // ---- scan what the lanes have noted, position by position
+    for (int r = 0; __ballot(r < nq) != 0ull; ++r)
+      if (r < nq) scan_leaf_nearest(t, lq[r * stk_stride], qx, qy, qz, v);
+    nq = 0;
+    stall = false;
+    if (__ballot(walking) == 0ull) return;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Packet traversal: ONE walk for the 64 queries of a coherent chunk.  Morton-adjacent surface points were matched to
 // a handful of leaves in the previous iteration and walk nearly the same nodes; here the walk's control state (node,
 // pending bits) is wave-uniform, so nodes and leaf points are fetched through the SCALAR cache (one s_load per record

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
   __shared__ double s_red[BLOCK / 64][kNumSumsMax];
-  __shared__ float s_stk[kMaxDepth + 1][BLOCK];  // pending-sibling bounds of the traversal
+  __shared__ float s_stk[kMaxDepth + 2][BLOCK];  // pending-sibling bounds of the traversal (rows 1 .. D) and, above them, the deferred walk's leaf queue
   float *stk = &s_stk[0][threadIdx.x];
   extern __shared__ unsigned char s_dyn[];  // MODE 1: k-NN lists
 
@@ -251,7 +251,9 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
 #else
         const bool done = PACKET && bvh_traverse_packet(tgt, x, y, z, active, v, h, stk, BLOCK);
 #endif
-        if (!done && active) bvh_traverse(tgt, x, y, z, v, stk, BLOCK, h);
+        // (the queue of deferred leaves lives in the rows of the parked-bound column above the tree's depth: 8 entries up to
+        // 2^13 leaves, at least one always)
+        if (!done && active) bvh_traverse_deferred(tgt, x, y, z, v, stk, BLOCK, h, min(8, kMaxDepth + 1 - tgt.depth));
       }
       if (owner && v.leaf != h) hint[i] = v.leaf;   // most start leaves survive an iteration: 4 MB of writes saved on C3
       const bool found = active && v.pos != kNoPos;
