@@ -354,6 +354,22 @@ def test_empty_and_tiny_clouds_through_every_feature_entry_point(ctx):
     # k-NN asked for more neighbours than the kernel's list holds is refused, not truncated
     with pytest.raises(ope.OpeError):
         ctx.knn(c3, ctx.build_index(c3), 64)
+    # the device-resident forms: empty in, empty out (and usable: a further stage on the empty cloud is empty again); an
+    # all-NaN cloud has nothing finite to keep; the host forms on the same inputs agree
+    allnan_x = np.full((7, 3), np.nan, np.float32)
+    allnan = ctx.upload(allnan_x)
+    for c, x in ((empty, np.empty((0, 3), np.float32)), (allnan, allnan_x)):
+        for out, idx in (ctx.remove_nan_cloud(c, want_idx=True), ctx.pass_through_cloud(c, [-1] * 3, [1] * 3, want_idx=True),
+                         ctx.uniform_sampling_cloud(c, 0.1, want_idx=True)):
+            assert out.n == 0 and len(idx) == 0 and ctx.download(out).shape == (0, 3)
+            again, _ = ctx.pass_through_cloud(out, [-1] * 3, [1] * 3)
+            assert again.n == 0
+        assert len(ctx.uniform_sampling(c, 0.1)) == 0 and len(ctx.pass_through(c, [-1] * 3, [1] * 3)) == 0
+    sor_dev, sor_idx = ctx.statistical_outlier_removal_cloud(allnan, 30, 1.0, want_idx=True)
+    np.testing.assert_array_equal(sor_idx, ctx.statistical_outlier_removal(allnan, 30, 1.0))
+    np.testing.assert_array_equal(sor_idx, oracle.statistical_outlier_removal(allnan_x, 30, 1.0))
+    assert sor_dev.n == len(sor_idx)
+    assert ctx.select(c3, np.empty(0, np.int32)).n == 0
 
 
 # ---------------------------------------------------------------- StatisticalOutlierRemoval (processingpcd.cpp:62-77)
