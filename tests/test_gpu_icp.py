@@ -544,6 +544,36 @@ def test_icp_large_launch_each_kernel_matches_oracle_d2_bit_exact(ctx, kernel):
     assert ctx.icp_end().iterations == 3
 
 
+@pytest.mark.parametrize("nt,leaf,depth_note", [(70, 16, "three levels"), (3_000, 1, "leaf size 1"), (300_000, 4, "depth 17: four queue rows"),
+                                               (1_200_000, 1, "depth 20: ONE queue row")])
+def test_deferred_leaf_scans_on_shallow_and_deep_trees(ctx, nt, leaf, depth_note):
+    """The per-lane walk notes the leaves it reaches in the rows of its LDS column above the tree's depth (up to eight, at
+    least one) and scans them later (bvh_traverse_deferred): trees from three levels to the depth cap, queries on the surface
+    and far from it, launches with and without start leaves — squared distances bit for bit against oracle.KdTree."""
+    ope = load_pkg()
+    rng = np.random.default_rng(nt)
+    tgt = synth.model_surface(nt, 3)
+    near = (tgt[rng.integers(0, nt, 12_000)] + rng.normal(0, 2e-3, (12_000, 3))).astype(np.float32)
+    far = rng.uniform(-0.3, 0.3, (4_000, 3)).astype(np.float32)
+    src = np.concatenate([near, far])[rng.permutation(16_000)]
+    tree = oracle.KdTree(tgt)
+    cs = ctx.upload(src)
+    ix = ctx.build_index(ctx.upload(tgt), leaf_size=leaf, grid=0)
+    params = ope.default_icp_params(tree_walk=1, max_iterations=3, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0,
+                                    mse_threshold_absolute=-1.0)
+    ctx.icp_begin(cs, ix, params, None)
+    for it in (1, 2, 3):
+        Tprev = ctx.icp_current_transform()
+        ctx.icp_iterate(1)
+        ctx.icp_current_transform()
+        q, m, d2 = ctx.icp_correspondences(len(src))
+        oi, od, _ = tree.knn(oracle.transform_points(src, Tprev), 1)
+        np.testing.assert_array_equal(d2, od[:, 0])
+        assert_same_index_or_exact_tie(oracle.transform_points(src, Tprev), tgt, m, oi[:, 0], d2)
+    assert_only_kernel(ctx, "tree_lane", 3)
+    ctx.icp_end()
+
+
 def test_icp_large_launch_default_kernel_choice_matches_oracle(ctx):
     """The same case with the library's own choice (grid = 1: the run starts on the grid kernel and may move to the tree
     kernel when the device-side count of far queries says so): whatever ran, the result is the oracle's."""
