@@ -15,7 +15,7 @@ namespace ope {
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
-                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *, const uint32_t *);
+                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *, const uint32_t *, hipEvent_t, hipEvent_t);
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
 void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
@@ -28,7 +28,7 @@ hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t,
                             float4 **, float4 **, float4 **);
 void launch_icp_accumulate_grid(hipStream_t, int, bool, const CloudView &, const BvhView &, const GridView &, const IcpState *, double *, int32_t *,
                                 float *, uint32_t *, uint32_t *, const uint32_t *, unsigned char *, const uint32_t *, uint32_t *, const uint32_t *,
-                                double *);
+                                double *, hipEvent_t, hipEvent_t);
 int grid_plan(hipStream_t, bool, const unsigned char *, uint32_t, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, const uint32_t *,
               uint32_t *, uint32_t, uint32_t, float, float, void *, size_t);
 size_t grid_plan_tmp_bytes(uint32_t, uint32_t);
@@ -227,16 +227,13 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
       }
     }
     const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
-    if (timed) OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], ctx->stream));
     ++ctx->kernel_launches[OPE_KERNEL_GRID];
     launch_icp_accumulate_grid(ctx->stream, ctx->acc_blocks, nrm, ctx->run_src->view(), ctx->run_tgt->view(), ctx->run_tgt->grid, ctx->d_state,
                                ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_hint, ctx->d_ghint, ctx->d_qorder, ctx->d_qclass,
                                ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8,
-                               atomic_sums ? sums_ptr(ctx) : nullptr);
-    if (timed) {
-      OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
-      ++ctx->prof_used;
-    }
+                               atomic_sums ? sums_ptr(ctx) : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr,
+                               timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr);
+    if (timed) ++ctx->prof_used;
     return OPE_OK;
   }
   if (ctx->grid_auto && grid_probe_poll(ctx, it_done) > 0) {
@@ -313,7 +310,6 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   const bool nrm = p.corr_mode == OPE_CORR_NORMAL_SHOOTING || p.use_surface_normal_rej || p.use_self_occluded_rej ||
                    p.estimator == OPE_EST_POINT_TO_PLANE_LLS;   // (LM reads the target normals in its own kernel)
   const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
-  if (timed) OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used], ctx->stream));
   const bool recip = p.use_reciprocal != 0;
   // packet walks for coherent chunks pay off when the launch fills the GPU (C3: 195 -> 184 us); on an underfilled
   // one (a 1/8 shard, C2) the longer dependent chain of a packet costs more than its gathers save (77 -> 88 us)
@@ -327,11 +323,9 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
                         recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
                         ctx->plan_valid ? ctx->d_plan_order[ctx->plan_cur] : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr,
                         (ctx->plan_valid && ctx->plan_cur_slots) ? ctx->d_plan_slots[ctx->plan_cur] : nullptr,
-                        (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && !dev_env("OPE_NO_KNN_BOUND")) ? ctx->d_knn_rk : nullptr, ctx->d_plan_out + 8 * ctx->plan_cur);
-  if (timed) {
-    OPE_HIP(ctx, hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], ctx->stream));
-    ++ctx->prof_used;
-  }
+                        (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && !dev_env("OPE_NO_KNN_BOUND")) ? ctx->d_knn_rk : nullptr, ctx->d_plan_out + 8 * ctx->plan_cur,
+                        timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr);
+  if (timed) ++ctx->prof_used;
   return OPE_OK;
 }
 

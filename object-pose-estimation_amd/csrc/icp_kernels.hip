@@ -16,6 +16,7 @@
 //       iterations back-to-back and polls only every `check_every` iterations.
 // Sharded (multi-GPU) runs split the second launch: reduce -> [all-reduce of S] -> update.
 #include <cstdlib>
+#include <hip/hip_ext.h>
 
 #include "bvh_traverse.hpp"
 #include "lm_solve.hpp"
@@ -1338,17 +1339,24 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
                            const BvhView &tgt, const BvhView &srcix, const IcpState *st, double *partials,
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
                            const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
-                           int k_normal_shooting, double *S_atomic, const uint32_t *slot_list, float *knn_rk, const uint32_t *plan_out) {
-#define OPE_LAUNCH_ACC(M, N, R, BLK, LDS)                                                                       \
-  hipLaunchKernelGGL((icp_accumulate_kernel<M, N, R>), dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, \
-                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out)
+                           int k_normal_shooting, double *S_atomic, const uint32_t *slot_list, float *knn_rk, const uint32_t *plan_out,
+                           hipEvent_t e0, hipEvent_t e1) {
+  // e0 / e1 (ope_icp_profile): the launch's own start and stop time stamps, taken by the dispatch itself (hipExtLaunchKernelGGL).
+  // Round 3 measured what a hipEventRecord before and after every launch costs the loop it times: 7-11 us per iteration (two
+  // more packets with barriers between dependent dispatches), 5 % of the number the bench reports.
+#define OPE_KLAUNCH(KERNEL, BLK, LDS)                                                                                         \
+  do {                                                                                                                        \
+    if (e0 != nullptr)                                                                                                        \
+      hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, e0, e1, 0, src, tgt, srcix, st, partials, corr_match, \
+                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out); \
+    else                                                                                                                      \
+      hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, partials, corr_match, corr_d2,   \
+                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out);      \
+  } while (0)
+#define OPE_LAUNCH_ACC(M, N, R, BLK, LDS) OPE_KLAUNCH((icp_accumulate_kernel<M, N, R>), BLK, LDS)
   if (mode == 0 && !recip && packet) {
-    if (nrm)
-      hipLaunchKernelGGL((icp_accumulate_kernel<0, true, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out);
-    else
-      hipLaunchKernelGGL((icp_accumulate_kernel<0, false, false, true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, srcix, st,
-                         partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out);
+    if (nrm) OPE_KLAUNCH((icp_accumulate_kernel<0, true, false, true>), kAccBlock, 0);
+    else OPE_KLAUNCH((icp_accumulate_kernel<0, false, false, true>), kAccBlock, 0);
     return;
   }
   if (mode == 0) {
@@ -1358,9 +1366,7 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
     // normal shooting: the k-nearest list lives in registers for EVERY k <= 32 (instantiations at k rounded up to a
     // multiple of four, and at the class default 10): the LDS list of round 1 took 2.4 ms per C3 iteration where the
     // register list takes ~0.5 ms, and held the kernel at two waves per SIMD
-#define OPE_LAUNCH_NS(KR)                                                                                                          \
-  hipLaunchKernelGGL((icp_accumulate_kernel<2, true, false, false, KR>), dim3(nblocks), dim3(kKnnBlock), 0, stream, src, tgt, srcix, st, \
-                     partials, corr_match, corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out)
+#define OPE_LAUNCH_NS(KR) OPE_KLAUNCH((icp_accumulate_kernel<2, true, false, false, KR>), kKnnBlock, 0)
     const int k = k_normal_shooting;
     if (k == 10) OPE_LAUNCH_NS(10);
     else if (k <= 4) OPE_LAUNCH_NS(4);
@@ -1374,6 +1380,7 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
 #undef OPE_LAUNCH_NS
   }
 #undef OPE_LAUNCH_ACC
+#undef OPE_KLAUNCH
 }
 
 // Blocks of the 1-NN accumulate kernel (tree or grid instantiation) that one CU holds at a time: a launch of more blocks
@@ -1394,13 +1401,19 @@ int icp_accumulate_blocks_per_cu(bool nrm, bool packet, bool grid) {
 void launch_icp_accumulate_grid(hipStream_t stream, int nblocks, bool nrm, const CloudView &src, const BvhView &tgt, const GridView &grid,
                                 const IcpState *st, double *partials, int32_t *corr_match, float *corr_d2, uint32_t *hint, uint32_t *ghint,
                                 const uint32_t *qorder, unsigned char *qclass, const uint32_t *chunk_order, uint32_t *chunk_cost,
-                                const uint32_t *plan_info, double *S_atomic) {
-  if (nrm)
-    hipLaunchKernelGGL((icp_accumulate_grid_kernel<true>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, grid, st, partials, corr_match,
-                       corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic);
-  else
-    hipLaunchKernelGGL((icp_accumulate_grid_kernel<false>), dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, grid, st, partials, corr_match,
-                       corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic);
+                                const uint32_t *plan_info, double *S_atomic, hipEvent_t e0, hipEvent_t e1) {
+#define OPE_KLAUNCH(KERNEL)                                                                                                   \
+  do {                                                                                                                        \
+    if (e0 != nullptr)                                                                                                        \
+      hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, e0, e1, 0, src, tgt, grid, st, partials, corr_match, \
+                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic);              \
+    else                                                                                                                      \
+      hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, grid, st, partials, corr_match, corr_d2, \
+                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic);                          \
+  } while (0)
+  if (nrm) OPE_KLAUNCH((icp_accumulate_grid_kernel<true>));
+  else OPE_KLAUNCH((icp_accumulate_grid_kernel<false>));
+#undef OPE_KLAUNCH
 }
 
 void launch_icp_reduce_update(hipStream_t stream, IcpState *st, const double *partials, double *S, int nblocks,
