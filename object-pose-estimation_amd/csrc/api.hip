@@ -15,7 +15,7 @@ namespace ope {
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
-                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *, const uint32_t *, hipEvent_t, hipEvent_t);
+                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *, const uint32_t *, hipEvent_t, hipEvent_t, bool);
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
 void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
@@ -28,7 +28,7 @@ hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t,
                             float4 **, float4 **, float4 **);
 void launch_icp_accumulate_grid(hipStream_t, int, bool, const CloudView &, const BvhView &, const GridView &, const IcpState *, double *, int32_t *,
                                 float *, uint32_t *, uint32_t *, const uint32_t *, unsigned char *, const uint32_t *, uint32_t *, const uint32_t *,
-                                double *, hipEvent_t, hipEvent_t);
+                                double *, hipEvent_t, hipEvent_t, bool);
 int grid_plan(hipStream_t, bool, const unsigned char *, uint32_t, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, const uint32_t *,
               uint32_t *, uint32_t, uint32_t, float, float, void *, size_t);
 size_t grid_plan_tmp_bytes(uint32_t, uint32_t);
@@ -195,10 +195,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     // slots over kOctSlotShare — did away with these launches and with a good schedule: steady state 172-186 us against
     // 152-157; a slot lasts 51-60 us whatever its chunk costs per lane.  Measured, not kept.)
     const bool measuring = !no_plan && nch > 1 && ((((nx & (nx - 1)) == 0 && nx <= plan_every) || nx % plan_every == 0 || nx == ctx->force_plan_at));
-    if (measuring != ctx->measuring_flag) {
-      OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 12, measuring ? 0x01 : 0x00, 4, ctx->stream));
-      ctx->measuring_flag = measuring;
-    }
+    ctx->measuring_flag = measuring;   // handed to the launch as a kernel argument (round 2 kept it in device memory: two memset dispatches per plan step on the critical path)
   }
   if (ctx->use_grid) {
     // GRID instantiation (1-NN, no reciprocal check, device-built index).  Plan steps at the same launches as below;
@@ -232,7 +229,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
                                ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_hint, ctx->d_ghint, ctx->d_qorder, ctx->d_qclass,
                                ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8,
                                atomic_sums ? sums_ptr(ctx) : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr,
-                               timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr);
+                               timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr, ctx->measuring_flag);
     if (timed) ++ctx->prof_used;
     return OPE_OK;
   }
@@ -324,7 +321,8 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
                         ctx->plan_valid ? ctx->d_plan_order[ctx->plan_cur] : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr,
                         (ctx->plan_valid && ctx->plan_cur_slots) ? ctx->d_plan_slots[ctx->plan_cur] : nullptr,
                         (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && !dev_env("OPE_NO_KNN_BOUND")) ? ctx->d_knn_rk : nullptr, ctx->d_plan_out + 8 * ctx->plan_cur,
-                        timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr);
+                        timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr,
+                        ctx->measuring_flag);
   if (timed) ++ctx->prof_used;
   return OPE_OK;
 }

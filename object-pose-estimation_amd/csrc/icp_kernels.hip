@@ -105,7 +105,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
     const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list,
-    float *__restrict__ knn_rk, const uint32_t *__restrict__ plan_out) {
+    float *__restrict__ knn_rk, const uint32_t *__restrict__ plan_out, uint32_t measuring_launch) {
   if (st->done) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
@@ -157,9 +157,9 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   const uint32_t n_waves = gridDim.x * (BLOCK / 64);
   const uint32_t wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
   const uint32_t n_chunks = (src.n_valid + 63u) / 64u;
-  // plan_info[4] != 0: a measuring launch (the one before a plan step) — every chunk takes the per-lane walk, so that the
+  // measuring_launch (a kernel argument: the host knows it when it launches): the launch before a plan step — every chunk takes the per-lane walk, so that the
   // costs the plan sorts are all of one kind and none is older than one launch
-  const bool measuring = chunk_order && plan_info[4] != 0u;
+  const bool measuring = chunk_order && measuring_launch != 0u;
   // plan_out: what the plan step computed for this chunk order ([0] chunks walked by groups, [5] / [7] chunks with a wave to
   // themselves); plan_info: the launch's flags
   const uint32_t n_heavy = (OCT_OK && chunk_order && !measuring) ? min(plan_out[0], n_chunks) : 0u;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     CloudView src, BvhView tgt, GridView grid, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ hint, uint32_t *__restrict__ ghint,
     const uint32_t *__restrict__ qorder, unsigned char *__restrict__ qclass, const uint32_t *__restrict__ chunk_order,
-    uint32_t *__restrict__ chunk_cost, const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic) {
+    uint32_t *__restrict__ chunk_cost, const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, uint32_t measuring_launch) {
   if (st->done) return;
   constexpr int BLOCK = kAccBlock;
   __shared__ double s_red[BLOCK / 64][kNumSumsMax];
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
   const uint32_t n_grid_q = min(plan_info[1], src.n_valid);
   const uint32_t n_tree_q = src.n_valid - n_grid_q;
   const uint32_t n_gc = (n_grid_q + 63u) / 64u, n_tc = (n_tree_q + 63u) / 64u;
-  const bool measuring = chunk_order && plan_info[4] != 0u;   // see icp_accumulate_kernel
+  const bool measuring = chunk_order && measuring_launch != 0u;   // see icp_accumulate_kernel
   const uint32_t n_heavy = (chunk_order && !measuring) ? min(plan_info[0], n_tc) : 0u;
   // waves 0 .. n_alone-1: one of the costliest per-lane tree chunks each and nothing else; all other waves, in snake
   // order: 8 slots per heavy tree chunk (8-lane group walks), the other tree chunks, the grid chunks (see icp_accumulate_kernel)
@@ -1340,7 +1340,8 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
                            const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
                            int k_normal_shooting, double *S_atomic, const uint32_t *slot_list, float *knn_rk, const uint32_t *plan_out,
-                           hipEvent_t e0, hipEvent_t e1) {
+                           hipEvent_t e0, hipEvent_t e1, bool measuring) {
+  const uint32_t mflag = measuring ? 1u : 0u;
   // e0 / e1 (ope_icp_profile): the launch's own start and stop time stamps, taken by the dispatch itself (hipExtLaunchKernelGGL).
   // Round 3 measured what a hipEventRecord before and after every launch costs the loop it times: 7-11 us per iteration (two
   // more packets with barriers between dependent dispatches), 5 % of the number the bench reports.
@@ -1348,10 +1349,10 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
   do {                                                                                                                        \
     if (e0 != nullptr)                                                                                                        \
       hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, e0, e1, 0, src, tgt, srcix, st, partials, corr_match, \
-                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out); \
+                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag); \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, partials, corr_match, corr_d2,   \
-                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out);      \
+                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag); \
   } while (0)
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS) OPE_KLAUNCH((icp_accumulate_kernel<M, N, R>), BLK, LDS)
   if (mode == 0 && !recip && packet) {
@@ -1401,15 +1402,16 @@ int icp_accumulate_blocks_per_cu(bool nrm, bool packet, bool grid) {
 void launch_icp_accumulate_grid(hipStream_t stream, int nblocks, bool nrm, const CloudView &src, const BvhView &tgt, const GridView &grid,
                                 const IcpState *st, double *partials, int32_t *corr_match, float *corr_d2, uint32_t *hint, uint32_t *ghint,
                                 const uint32_t *qorder, unsigned char *qclass, const uint32_t *chunk_order, uint32_t *chunk_cost,
-                                const uint32_t *plan_info, double *S_atomic, hipEvent_t e0, hipEvent_t e1) {
+                                const uint32_t *plan_info, double *S_atomic, hipEvent_t e0, hipEvent_t e1, bool measuring) {
+  const uint32_t mflag = measuring ? 1u : 0u;
 #define OPE_KLAUNCH(KERNEL)                                                                                                   \
   do {                                                                                                                        \
     if (e0 != nullptr)                                                                                                        \
       hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, e0, e1, 0, src, tgt, grid, st, partials, corr_match, \
-                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic);              \
+                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag);       \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, grid, st, partials, corr_match, corr_d2, \
-                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic);                          \
+                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag);                   \
   } while (0)
   if (nrm) OPE_KLAUNCH((icp_accumulate_grid_kernel<true>));
   else OPE_KLAUNCH((icp_accumulate_grid_kernel<false>));
