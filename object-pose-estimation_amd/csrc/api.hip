@@ -120,15 +120,16 @@ static bool atomic_sums(const ope_ctx *ctx) { return ctx->run_params.determinist
 // share of such queries is counted on the device from the correspondences' d2 at the plan steps, read back asynchronously
 // (no host synchronisation) and acted on with hysteresis: to the tree kernel above kGridMaxTreeShare, back to the grid
 // kernel below kGridMinTreeShare.  Either kernel is exact: the choice only moves time.
-static int grid_probe_issue(ope_ctx *ctx) {
+static int grid_probe_issue(ope_ctx *ctx, hipStream_t stream = nullptr) {
   if (ctx->grid_probe_pending || !ctx->grid_probe_event || !ctx->grid_auto) return OPE_OK;
+  if (stream == nullptr) stream = ctx->stream;
   // "far": further than eight cells from the target — clutter, whose ball no 27-cell scan will ever cover; a source that is
   // merely a few cells off at the start of a run is not counted (round 2 counted beyond ONE cell and therefore had to wait
   // for the loop to settle before it could trust the count)
   const float cell = 8.0f / ctx->run_tgt->grid.inv;
-  grid_count_far(ctx->stream, ctx->d_corr_d2, (uint32_t)ctx->run_src->n_valid, cell * cell, ctx->d_work_counter + 8);
-  OPE_HIP(ctx, hipMemcpyAsync(ctx->h_grid_probe, ctx->d_work_counter + 10, 4, hipMemcpyDeviceToHost, ctx->stream));
-  OPE_HIP(ctx, hipEventRecord(ctx->grid_probe_event, ctx->stream));
+  grid_count_far(stream, ctx->d_corr_d2, (uint32_t)ctx->run_src->n_valid, cell * cell, ctx->d_work_counter + 8);
+  OPE_HIP(ctx, hipMemcpyAsync(ctx->h_grid_probe, ctx->d_work_counter + 10, 4, hipMemcpyDeviceToHost, stream));
+  OPE_HIP(ctx, hipEventRecord(ctx->grid_probe_event, stream));
   ctx->grid_probe_pending = true;
   return OPE_OK;
 }
@@ -256,10 +257,6 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   const bool plan_step = !no_plan && nch > 1 && it_done >= 1 &&
                          (((it_done & (it_done - 1)) == 0 && it_done <= plan_every) || it_done % plan_every == 0 || it_done == ctx->force_plan_at);
   if (plan_step) {
-    if (ctx->grid_auto && it_done >= 8) {
-      const int rcp = grid_probe_issue(ctx);
-      if (rcp != OPE_OK) return rcp;
-    }
     // Chunks costlier than `factor` x the median chunk are walked by 8-lane groups: a third of the dependent trips for
     // ~2.7x the lane-cycles.  That trade pays while the launch is bound by its slowest wave, i.e. while there are few
     // chunks per resident wave; once the waves are busy for several rounds the extra lane-cycles only lengthen the launch.
@@ -282,6 +279,15 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     if (async) {
       OPE_HIP(ctx, hipEventRecord(ctx->ev_acc_done, ctx->stream));       // every launch before this one has finished ...
       OPE_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_acc_done, 0));         // ... before the costs are copied (this launch overwrites them)
+    }
+    // the count of far queries that may move the run back to the grid kernel rides on the same side stream (three dispatches
+    // off the launch stream; it reads the distances while this launch rewrites them: a count of two consecutive launches'
+    // values, for a decision that is polled without waiting anyway)
+    if (ctx->grid_auto && it_done >= 8) {
+      const int rcp = grid_probe_issue(ctx, ps);
+      if (rcp != OPE_OK) return rcp;
+    }
+    if (async) {
       OPE_HIP(ctx, hipMemcpyAsync(ctx->d_cost_snap, ctx->d_chunk_cost, 4 * (size_t)nch, hipMemcpyDeviceToDevice, ps));
       costs = ctx->d_cost_snap;
     }
