@@ -59,6 +59,9 @@ def main() -> int:
     ap.add_argument("--leaf", type=int, default=0, help="index leaf size override (0 = library default)")
     ap.add_argument("--no-grid", action="store_true", help="OBB tree only (A/B against the bucketed search)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--update-launch", default="overlapped", choices=["overlapped", "in-line"],
+                    help="ope_icp_params.update_launch (include/ope.h): the library's default, or accumulate -> update -> accumulate "
+                         "on one stream as in rounds 1-2 (A/B; and what a profiler that serialises dispatches, rocprofv3 --pmc, wants)")
     ap.add_argument("--no-ns", action="store_true", help="skip the normal-shooting leg (the correspondence estimation the reference's "
                                                           "estimateFinePose really installs), reported beside `value` at N = 1")
     ap.add_argument("--no-coarse", action="store_true", help="skip the FPFH + SAC-IA initial alignment (identity start)")
@@ -239,7 +242,8 @@ def main() -> int:
     # separately: an iteration is cheaper once the scene has settled on the model)
     S = args.steady
     params = ope.default_icp_params(max_iterations=W + K + S + 1, transformation_epsilon=0.0,
-                                    euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0, check_every=0)
+                                    euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0, check_every=0,
+                                    update_launch=0 if args.update_launch == "overlapped" else 1)
     ctx.icp_set_global_sizes(n_scene, n_model)
     ctx.icp_begin(cs, ix, params, guess)
 
@@ -282,6 +286,7 @@ def main() -> int:
     elapsed, kern_avg_ms, kern_n = timed(K, True)
     launch_ms = getattr(timed, "last_launch_ms", None)
     kernels_timed = ctx.icp_kernel_launches()
+    overlapped_updates = ctx.icp_overlapped_updates()
     T_timed = ctx.icp_current_transform()
     steady = None
     if S > 0:
@@ -393,7 +398,8 @@ def main() -> int:
                        "parallelism": f"scene-sharded x{world}, model index replicated, 17xfp64 all-reduce/iter"
                                       + (f" ({args.comm}" + ({ope.COMM_P2P: ": peer-to-peer slots", ope.COMM_RCCL: ": ncclAllReduce"}.get(ctx.comm_transport(), "") if not use_torch_comm else "") + ")" if launched else ""),
                        "start": "identity" if guess is None else "FPFH + SAC-IA coarse pose",
-                       "final_mse": out.last_mse, "n_corr": int(out.n_corr)},
+                       "final_mse": out.last_mse, "n_corr": int(out.n_corr),
+                       "update_launch": args.update_launch, "overlapped_updates_so_far": overlapped_updates},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "icp_accumulate_kernel", "kernel_ms": kern_avg_ms, "launches_timed": kern_n,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OPE_ABI_VERSION 3
+#define OPE_ABI_VERSION 4
 
 enum {
   OPE_OK = 0,
@@ -194,8 +194,18 @@ typedef struct {
    * per-lane walks only.  OPE_WALK_LANE (1) / OPE_WALK_PACKET (2) force the instantiation (every walk is exact: the choice
    * moves time, and lets a test pin each kernel by name, see ope_icp_kernel_launches). */
   int tree_walk;
+  /* How the per-iteration update step (Umeyama / Cholesky lane + convergence test) is launched in ope_icp_run /
+   * ope_icp_iterate.  OPE_UPDATE_OVERLAPPED (0, default): on a stream of its own next to the accumulate launch it follows,
+   * waiting on the device for that launch's blocks, while the next accumulate launch is already being dispatched and its
+   * blocks wait for the update's word: one kernel boundary per iteration instead of two around a 64-thread launch.  Taken by
+   * plain 1-NN runs of one rank (not: normal shooting, reciprocal, deterministic_sums, the LM estimator, sharded runs, batches
+   * of one iteration), the others launch in line whatever this says.  Every device-side wait is bounded (2 s: OPE_EHIP).
+   * OPE_UPDATE_IN_LINE (1): accumulate -> update -> accumulate on the one stream, as in rounds 1-2 (a profiler that
+   * serialises dispatches, e.g. rocprofv3 --pmc, wants this).  Same arithmetic either way. */
+  int update_launch;
 } ope_icp_params;
 enum { OPE_WALK_AUTO = 0, OPE_WALK_LANE = 1, OPE_WALK_PACKET = 2 };
+enum { OPE_UPDATE_OVERLAPPED = 0, OPE_UPDATE_IN_LINE = 1 };
 
 typedef struct {
   int iterations;        /* nr_iterations_ */
@@ -214,6 +224,8 @@ void ope_icp_default_params(ope_icp_params *p);
  * between kernels (ope_index_params.grid = 1); tests use this to assert which kernel their comparison exercised. */
 enum { OPE_KERNEL_GRID = 0, OPE_KERNEL_TREE_LANE = 1, OPE_KERNEL_TREE_PACKET = 2, OPE_KERNEL_KNN = 3, OPE_KERNEL_KINDS = 4 };
 int ope_icp_kernel_launches(const ope_ctx *ctx, int64_t counts[OPE_KERNEL_KINDS]);
+/* How many update steps of the current (or last) run were launched overlapped (ope_icp_params.update_launch). */
+int64_t ope_icp_overlapped_updates(const ope_ctx *ctx);
 
 /* Registration::align(output, guess) -> IterativeClosestPoint::computeTransformation
  * (registration_mod.hpp:176-219, icp_mod.hpp:119-272).  guess may be NULL (identity).

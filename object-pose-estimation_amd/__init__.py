@@ -68,6 +68,7 @@ class IcpParams(C.Structure):
         ("estimator", C.c_int),
         ("deterministic_sums", C.c_int),
         ("tree_walk", C.c_int),
+        ("update_launch", C.c_int),
     ]
 
 
@@ -145,6 +146,7 @@ ABI = [
     ("ope_icp_end", C.c_int, [_vp, _fp, C.POINTER(IcpResult)]),
     ("ope_icp_set_global_sizes", C.c_int, [_vp, C.c_int64, C.c_int64]),
     ("ope_icp_kernel_launches", C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    ("ope_icp_overlapped_updates", C.c_int64, [_vp]),
     ("ope_icp_profile_launches", C.c_int, [_vp, _fp, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ope_cloud_select", C.c_int, [_vp, _vp, _ip, C.c_size_t, C.POINTER(_vp)]),
     ("ope_remove_nan_cloud", C.c_int, [_vp, _vp, C.POINTER(_vp), _ip, C.POINTER(C.c_size_t)]),
@@ -456,6 +458,10 @@ class Context:
         c = (C.c_int64 * 4)()
         self._chk(lib().ope_icp_kernel_launches(self.h, c))
         return dict(zip(("grid", "tree_lane", "tree_packet", "knn"), (int(v) for v in c)))
+
+    def icp_overlapped_updates(self) -> int:
+        """Update steps of the current / last run that were launched overlapped (ope_icp_params.update_launch)."""
+        return int(lib().ope_icp_overlapped_updates(self.h))
 
     def icp_set_global_sizes(self, n_src_total: int, n_tgt_total: int):
         self._chk(lib().ope_icp_set_global_sizes(self.h, n_src_total, n_tgt_total))

@@ -15,7 +15,8 @@ namespace ope {
 // launchers defined in icp_kernels.hip
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
-                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *, const uint32_t *, hipEvent_t, hipEvent_t, bool);
+                           uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *, const uint32_t *, hipEvent_t, hipEvent_t, bool,
+                           uint32_t *, uint32_t);
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
 void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
@@ -28,7 +29,7 @@ hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t,
                             float4 **, float4 **, float4 **);
 void launch_icp_accumulate_grid(hipStream_t, int, bool, const CloudView &, const BvhView &, const GridView &, const IcpState *, double *, int32_t *,
                                 float *, uint32_t *, uint32_t *, const uint32_t *, unsigned char *, const uint32_t *, uint32_t *, const uint32_t *,
-                                double *, hipEvent_t, hipEvent_t, bool);
+                                double *, hipEvent_t, hipEvent_t, bool, uint32_t *, uint32_t);
 int grid_plan(hipStream_t, bool, const unsigned char *, uint32_t, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, const uint32_t *,
               uint32_t *, uint32_t, uint32_t, float, float, void *, size_t);
 size_t grid_plan_tmp_bytes(uint32_t, uint32_t);
@@ -39,6 +40,7 @@ hipError_t build_grid_device(hipStream_t, const float4 *, const float4 *, size_t
                              float4 **, float4 **, uint32_t **, uint32_t **);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
 void launch_icp_update(hipStream_t, IcpState *, double *, int, const float *);
+void launch_icp_update_chained(hipStream_t, IcpState *, int, uint32_t *, uint32_t, uint32_t);
 void launch_lm_stats(hipStream_t, int, const CloudView &, const BvhView &, const IcpState *, const int32_t *, double *);
 void launch_icp_lm_update(hipStream_t, IcpState *, double *, double *);
 void launch_lm_pos_to_orig(hipStream_t, const BvhView &, int32_t *, uint32_t);
@@ -105,6 +107,19 @@ static void abort_run(ope_ctx *ctx) {
 static double *sums_ptr(ope_ctx *ctx) {
   if (ctx->d_sums_ext) return ctx->d_sums_ext;
   return reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(ctx->d_state) + offsetof(IcpState, S));
+}
+
+// the three words the overlapped update launches and the accumulate launches meet at (icp_kernels.hip: acc_launch_begin);
+// cleared with the rest of the block by ope_icp_begin
+static uint32_t *chain_ptr(ope_ctx *ctx) { return ctx->d_work_counter + 32; }
+
+// The launch stream waits for the overlapped updates enqueued so far (no host synchronisation).
+static int chain_join(ope_ctx *ctx) {
+  if (!ctx->chain_open) return OPE_OK;
+  ctx->chain_open = false;
+  OPE_HIP(ctx, hipEventRecord(ctx->ev_chain_u, ctx->upd_stream));
+  OPE_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_chain_u, 0));
+  return OPE_OK;
 }
 
 // One accumulate launch, optionally bracketed by HIP events on the launch stream (bench.py's roofline leg).
@@ -230,7 +245,8 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
                                ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_hint, ctx->d_ghint, ctx->d_qorder, ctx->d_qclass,
                                ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8,
                                atomic_sums ? sums_ptr(ctx) : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr,
-                               timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr, ctx->measuring_flag);
+                               timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr, ctx->measuring_flag,
+                               ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq);
     if (timed) ++ctx->prof_used;
     return OPE_OK;
   }
@@ -328,7 +344,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
                         (ctx->plan_valid && ctx->plan_cur_slots) ? ctx->d_plan_slots[ctx->plan_cur] : nullptr,
                         (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && !dev_env("OPE_NO_KNN_BOUND")) ? ctx->d_knn_rk : nullptr, ctx->d_plan_out + 8 * ctx->plan_cur,
                         timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr,
-                        ctx->measuring_flag);
+                        ctx->measuring_flag, ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq);
   if (timed) ++ctx->prof_used;
   return OPE_OK;
 }
@@ -371,6 +387,9 @@ int ope_ctx_create(ope_ctx **out, int device_ordinal) {
       hipMalloc((void **)&ctx->d_lm_stats, sizeof(double) * 96) != hipSuccess ||
       hipMalloc((void **)&ctx->d_plan_out, 64) != hipSuccess || hipMemset(ctx->d_plan_out, 0, 64) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->plan_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->upd_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_chain_s, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_chain_u, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_acc_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_plan_done, hipEventDisableTiming) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState)) != hipSuccess) {
@@ -395,6 +414,9 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->d_lm_stats) (void)hipFree(ctx->d_lm_stats);
   tmp_release_stream(ctx->stream);   // the cached temporaries of this context's stream
   if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
+  if (ctx->upd_stream) { (void)hipStreamSynchronize(ctx->upd_stream); (void)hipStreamDestroy(ctx->upd_stream); }
+  if (ctx->ev_chain_s) (void)hipEventDestroy(ctx->ev_chain_s);
+  if (ctx->ev_chain_u) (void)hipEventDestroy(ctx->ev_chain_u);
   if (ctx->ev_acc_done) (void)hipEventDestroy(ctx->ev_acc_done);
   if (ctx->ev_plan_done) (void)hipEventDestroy(ctx->ev_plan_done);
   for (void *q : {(void *)ctx->d_plan_out, (void *)ctx->d_cost_snap, (void *)ctx->d_plan_sorted[0], (void *)ctx->d_plan_sorted[1], (void *)ctx->d_plan_order[0],
@@ -812,7 +834,10 @@ void ope_icp_default_params(ope_icp_params *p) {
   p->estimator = OPE_EST_SVD;
   p->deterministic_sums = 0;
   p->tree_walk = OPE_WALK_AUTO;
+  p->update_launch = OPE_UPDATE_OVERLAPPED;
 }
+
+int64_t ope_icp_overlapped_updates(const ope_ctx *ctx) { return ctx ? (int64_t)ctx->chain_seq : 0; }
 
 int ope_icp_kernel_launches(const ope_ctx *ctx, int64_t counts[OPE_KERNEL_KINDS]) {
   if (!ctx || !counts) return OPE_EINVAL;
@@ -873,6 +898,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   if (p.estimator != OPE_EST_SVD && p.estimator != OPE_EST_POINT_TO_PLANE_LLS && p.estimator != OPE_EST_POINT_TO_PLANE_LM)
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown estimator");
   if (p.tree_walk < OPE_WALK_AUTO || p.tree_walk > OPE_WALK_PACKET) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown tree_walk");
+  if (p.update_launch != OPE_UPDATE_OVERLAPPED && p.update_launch != OPE_UPDATE_IN_LINE) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown update_launch");
   if ((p.estimator == OPE_EST_POINT_TO_PLANE_LLS || p.estimator == OPE_EST_POINT_TO_PLANE_LM) && !tgt->d_nrm)
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: the point-to-plane estimator needs target normals (build the index from a cloud with normals)");
   if (p.use_surface_normal_rej && !tgt->d_nrm)
@@ -881,6 +907,11 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: 1 <= k_normal_shooting <= 32");
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   if (ctx->plan_pending) OPE_HIP(ctx, hipStreamSynchronize(ctx->plan_stream));   // a plan of the previous run still in the making reads the buffers below
+  {
+    const int rcj = chain_join(ctx);   // overlapped updates of a run that was never polled or ended
+    if (rcj != OPE_OK) return rcj;
+    ctx->chain_u_synced = false;
+  }
   // From here on the context's run state is being rebuilt: any failure leaves NO run behind (not the previous one
   // with new buffers, and not stale align-strength sizes).
   const int64_t keep_ns = ctx->n_src_total, keep_nt = ctx->n_tgt_total;
@@ -1092,6 +1123,26 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     const int per_cu = icp_accumulate_blocks_per_cu(nrm, packet, tgt->has_grid && tgt->grid_mode == 2);
     if (per_cu > 0) ctx->acc_blocks = std::min(ctx->acc_blocks, per_cu * ctx->n_cu);
   }
+  // Overlapped update launches (icp_kernels.hip, acc_launch_begin): plain 1-NN runs of one rank with atomic sums and an
+  // estimator whose update is icp_update_kernel.  The accumulate launch then stays short of what the GPU holds, so that the
+  // update's wave finds room beside it whenever it arrives.
+  ctx->chained = p.update_launch == OPE_UPDATE_OVERLAPPED && !ctx->chain_broken && p.corr_mode == OPE_CORR_NEAREST && !p.use_reciprocal &&
+                 p.deterministic_sums == 0 && p.estimator != OPE_EST_POINT_TO_PLANE_LM && ctx->nccl_comm == nullptr && !ctx->p2p_ok &&
+                 !dev_env("OPE_NO_CHAIN");
+  ctx->chain_on = false;
+  ctx->chain_seq = 0;
+  if (ctx->chained) {
+    const bool nrm = p.use_surface_normal_rej || p.use_self_occluded_rej || p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
+    int per_cu = icp_accumulate_blocks_per_cu(nrm, false, false);
+    per_cu = std::min(per_cu, icp_accumulate_blocks_per_cu(nrm, true, false));
+    if (tgt->has_grid) per_cu = std::min(per_cu, icp_accumulate_blocks_per_cu(nrm, false, true));
+    // one block slot left free on EVERY XCD: blocks are dealt to the eight XCDs round-robin and which XCD the update's one
+    // workgroup is dealt to is not fixed; with the slot it always finds room, also when it arrives together with a launch
+    // whose blocks are all about to wait for it (a host that enqueues no faster than the GPU works)
+    constexpr int kXcds = 8;   // gfx950
+    if (per_cu > 0) ctx->acc_blocks = std::max(1, std::min(ctx->acc_blocks, per_cu * ctx->n_cu - kXcds));
+    else ctx->chained = false;
+  }
   if (const char *e = dev_env("OPE_ACC_BLOCKS")) ctx->acc_blocks = std::max(1, std::min(atoi(e), (int)kAccMaxBlocks));
   if (ctx->n_src_total <= 0) ctx->n_src_total = (int64_t)src->n;
   if (ctx->n_tgt_total <= 0) ctx->n_tgt_total = (int64_t)tgt->n_total;
@@ -1104,7 +1155,10 @@ int ope_icp_accumulate(ope_ctx *ctx) {
   if (ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LM)
     return set_err(ctx, OPE_EINVAL, "ope_icp_accumulate: the LM estimator iterates inside ope_icp_iterate / ope_icp_run (it reduces over the correspondences several times per iteration)");
   const bool atomic = atomic_sums(ctx);
-  int rc = enqueue_accumulate(ctx, atomic);
+  int rc = chain_join(ctx);
+  if (rc != OPE_OK) return rc;
+  ctx->chain_on = false;
+  rc = enqueue_accumulate(ctx, atomic);
   if (rc != OPE_OK) return rc;
   if (!atomic)
     launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, /*do_update=*/false, ctx->d_work_counter);
@@ -1119,6 +1173,10 @@ void *ope_icp_sums_device(ope_ctx *ctx) {
 
 int ope_icp_set_sums_buffer(ope_ctx *ctx, void *device_ptr) {
   if (!ctx) return OPE_EINVAL;
+  {
+    const int rcj = chain_join(ctx);
+    if (rcj != OPE_OK) return rcj;
+  }
   ctx->d_sums_ext = static_cast<double *>(device_ptr);
   // accumulate launches add into the sums: a buffer handed over mid-run starts from zero like the built-in one
   // (before a run it is cleared by ope_icp_begin, which knows how many sums the estimator uses)
@@ -1133,6 +1191,28 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
   const bool sharded = ctx->nccl_comm != nullptr || ctx->p2p_ok;
   static const bool split_update = dev_env("OPE_SPLIT_UPDATE") != nullptr;  // developer A/B switch
   const bool atomic = atomic_sums(ctx);
+  // Overlapped update launches (icp_kernels.hip, acc_launch_begin): the updates go to their own stream, which waits for the
+  // launch stream once per run; the launch stream waits for it only when something is about to read or rewrite the state
+  // (chain_join: poll, end, the step-wise entry points, the next begin).  In between nothing on the host or in the streams
+  // orders an update against the accumulate launches — the kernels do.
+  const bool chained = ctx->chained && !sharded && atomic && ctx->d_sums_ext == nullptr;
+  if (chained) {
+    if (!ctx->chain_u_synced) {   // once per run (and after in-line updates): the update stream sees what the launch stream did to the state
+      OPE_HIP(ctx, hipEventRecord(ctx->ev_chain_s, ctx->stream));
+      OPE_HIP(ctx, hipStreamWaitEvent(ctx->upd_stream, ctx->ev_chain_s, 0));
+      ctx->chain_u_synced = true;
+    }
+    ctx->chain_open = true;
+  } else {
+    const int rcj = chain_join(ctx);
+    if (rcj != OPE_OK) return rcj;
+    ctx->chain_u_synced = false;
+  }
+  struct ChainFlag {   // enqueue_accumulate hands the chain words to the launches of THIS batch only
+    ope_ctx *c;
+    ~ChainFlag() { c->chain_on = false; }
+  } chain_flag{ctx};
+  ctx->chain_on = chained;
   for (int b = 0; b < n_iterations; ++b) {
     TraceRange r_iter(ctx, "icp_iter");
     int rc;
@@ -1142,6 +1222,11 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
     }
     if (rc != OPE_OK) return rc;
     TraceRange r_red(ctx, "reduce");
+    if (chained) {
+      launch_icp_update_chained(ctx->upd_stream, ctx->d_state, run_nsums(ctx), chain_ptr(ctx), ctx->chain_seq, (uint32_t)ctx->acc_blocks);
+      ++ctx->chain_seq;
+      continue;
+    }
     if (ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LM) {
       // correspondences are in place (corr_match = index positions); their 17 sums give n and the MSE, one more pass gives
       // the 91 sums the minimiser works on (lm.hip); in sharded runs both sets are summed over the ranks; the minimisation
@@ -1238,6 +1323,11 @@ int ope_debug_chunk_costs(ope_ctx *ctx, uint32_t *cost, uint32_t *order, uint32_
 
 int ope_icp_update(ope_ctx *ctx) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_update: no run in progress");
+  {
+    const int rcj = chain_join(ctx);
+    if (rcj != OPE_OK) return rcj;
+    ctx->chain_u_synced = false;
+  }
   launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx), nullptr);
   OPE_HIP(ctx, hipGetLastError());
   ++ctx->iters_enqueued;
@@ -1257,9 +1347,17 @@ static void fill_result(const ope_ctx *ctx, ope_icp_result *r) {
 
 int ope_icp_poll(ope_ctx *ctx, ope_icp_result *result) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_poll: no run in progress");
+  {
+    const int rcj = chain_join(ctx);
+    if (rcj != OPE_OK) return rcj;
+  }
   OPE_HIP(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (result) fill_result(ctx, result);
+  if (ctx->h_state->chain_error) {
+    ctx->chain_broken = true;
+    return set_err(ctx, OPE_EHIP, "an overlapped update launch waited 2 s for its accumulate launch (GPU shared with other work, or serialised by a profiler?): the run was ended; later runs on this context launch their updates in line (ope_icp_params.update_launch = OPE_UPDATE_IN_LINE does so from the start)");
+  }
   if (ctx->h_state->comm_error) {
     // the ranks' sequence numbers no longer agree and the slots hold the words of the aborted exchange: a later run could
     // accept them as fresh.  The communicator is unusable from here on (ope_icp_begin refuses) until it is re-created.

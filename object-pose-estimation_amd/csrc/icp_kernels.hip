@@ -30,6 +30,50 @@ __device__ uint32_t *g_chunk_stats = nullptr;
 
 typedef const __attribute__((address_space(3))) float *lds_cfloat_ptr;   // a pointer that stays an LDS pointer
 
+// ---- update launches overlapped with the accumulate launches (round 3; host side: api.hip, ope_icp_iterate) -------------
+// In line, an iteration is accumulate -> update -> accumulate on one stream, and the two kernel boundaries around the
+// 64-thread update launch cost the iteration 13-17 us (tools/gap_probe.sh).  Overlapped, update j is launched on a stream of
+// its own next to accumulate launch j, is resident long before that launch ends and waits ON THE DEVICE for its blocks
+// (chain[0], one ticket per block, taken after the block's sums are in); accumulate launch j + 1 follows launch j on the
+// launch stream — the one boundary left runs while the update lane computes — and its blocks wait for update j's word
+// (chain[1] = number of updates published) before they read the transform.  Every wait is bounded (kChainTimeoutTicks of the
+// 100 MHz clock): a launch whose partner never shows up sets chain[2] / IcpState::chain_error and ends, so every wave of
+// every launch reaches its exit.
+// The two kernels run at the same time on different XCDs, each with an L2 of its own, so the handful of words they share —
+// the three chain words, the sums, the transform rows, "done" — are only ever touched with agent-scope atomics (sc1: served
+// at the point all XCDs agree on), ordered by s_waitcnt alone.  NO agent-scope fences: on this part a release fence writes the
+// XCD's whole L2 back and an acquire fence invalidates it, and one such fence per block (the first build) evicted the
+// L2-resident index under the blocks still walking it: 145 -> 260 us per launch.
+constexpr unsigned long long kChainTimeoutTicks = 200000000ull;   // 2 s
+__device__ __forceinline__ uint32_t chain_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void chain_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void chain_wait_own_memory_ops() { __builtin_amdgcn_s_waitcnt(0); }   // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's stores and atomics have been acknowledged
+// Head of an accumulate launch: in-line runs (chain == nullptr) early-out on the "done" flag; overlapped runs first wait for
+// update chain_seq - 1.  Returns false (for the whole block) if the launch has nothing to do.
+__device__ __forceinline__ bool acc_launch_begin(const IcpState *st, uint32_t *chain, uint32_t chain_seq) {
+  if (chain == nullptr) return st->done == 0;
+  __shared__ uint32_t s_go[1];
+  if (threadIdx.x == 0) {
+    uint32_t go = 1u;
+    const unsigned long long t0 = wall_clock64();
+    while ((int32_t)(chain_load(chain + 1) - chain_seq) < 0) {
+      if (wall_clock64() - t0 > kChainTimeoutTicks) { go = 0u; atomicOr(chain + 2, 1u); break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (go != 0u && __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) go = 0u;   // (issued after the word above has arrived)
+    *s_go = go;
+  }
+  __syncthreads();
+  return *s_go != 0u;
+}
+// Tail of an accumulate launch: the block's sums are in (fp64 atomics) -> one ticket.
+__device__ __forceinline__ void acc_launch_end(uint32_t *chain) {
+  if (chain == nullptr) return;
+  chain_wait_own_memory_ops();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(chain, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // One query's contribution to the wave's running sums {n, Σs, Σt, Σ t sᵀ, Σd²} (+ 27 normal-equation sums with the
 // point-to-plane estimator): 16-lane row sums by DPP, then one ds_add_f64 per row and component into `acc` (LDS).
 // t: the matched target point, tn: its normal (point-to-plane only); lanes with ok == false contribute zeros.
@@ -105,8 +149,9 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
     const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list,
-    float *__restrict__ knn_rk, const uint32_t *__restrict__ plan_out, uint32_t measuring_launch) {
-  if (st->done) return;
+    float *__restrict__ knn_rk, const uint32_t *__restrict__ plan_out, uint32_t measuring_launch, uint32_t *chain_arg, uint32_t chain_seq) {
+  uint32_t *const chain = (MODE == 0 && !RECIP) ? chain_arg : nullptr;   // overlapped update launches exist for the plain 1-NN run only (api.hip)
+  if (!acc_launch_begin(st, chain, chain_seq)) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
   __shared__ double s_red[BLOCK / 64][kNumSumsMax];
@@ -127,7 +172,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     if ((double)f < max_d2) f = nextafterf(f, INFINITY);
     best0 = nextafterf(f, INFINITY);
   }
-  if (threadIdx.x < 12) s_const[threadIdx.x] = st->Ff[threadIdx.x];
+  if (threadIdx.x < 12) s_const[threadIdx.x] = chain != nullptr ? __hip_atomic_load(&st->Ff[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st->Ff[threadIdx.x];   // (an overlapped update wrote it while this launch was already resident)
   else if (threadIdx.x < 15) s_const[threadIdx.x] = (float)st->pivot[threadIdx.x - 12];
   else if (threadIdx.x == 15) s_const[15] = best0;
   __syncthreads();
@@ -393,6 +438,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     if (S_atomic != nullptr) unsafeAtomicAdd(S_atomic + threadIdx.x, v);
     else partials[threadIdx.x * kAccMaxBlocks + blockIdx.x] = v;
   }
+  acc_launch_end(chain);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -479,8 +525,9 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     CloudView src, BvhView tgt, GridView grid, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ hint, uint32_t *__restrict__ ghint,
     const uint32_t *__restrict__ qorder, unsigned char *__restrict__ qclass, const uint32_t *__restrict__ chunk_order,
-    uint32_t *__restrict__ chunk_cost, const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, uint32_t measuring_launch) {
-  if (st->done) return;
+    uint32_t *__restrict__ chunk_cost, const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, uint32_t measuring_launch,
+    uint32_t *chain, uint32_t chain_seq) {
+  if (!acc_launch_begin(st, chain, chain_seq)) return;
   constexpr int BLOCK = kAccBlock;
   __shared__ double s_red[BLOCK / 64][kNumSumsMax];
   __shared__ float s_stk[kMaxDepth + 1][BLOCK];
@@ -493,7 +540,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     if ((double)f < max_d2) f = nextafterf(f, INFINITY);
     best0 = nextafterf(f, INFINITY);
   }
-  if (threadIdx.x < 12) s_const[threadIdx.x] = st->Ff[threadIdx.x];
+  if (threadIdx.x < 12) s_const[threadIdx.x] = chain != nullptr ? __hip_atomic_load(&st->Ff[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st->Ff[threadIdx.x];   // (an overlapped update wrote it while this launch was already resident)
   else if (threadIdx.x < 15) s_const[threadIdx.x] = (float)st->pivot[threadIdx.x - 12];
   else if (threadIdx.x == 15) s_const[15] = best0;
   __syncthreads();
@@ -637,6 +684,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     if (S_atomic != nullptr) unsafeAtomicAdd(S_atomic + threadIdx.x, v);
     else partials[threadIdx.x * kAccMaxBlocks + blockIdx.x] = v;
   }
+  acc_launch_end(chain);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1085,6 +1133,64 @@ __global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, double *S,
   if ((int)threadIdx.x < nsums) S[threadIdx.x] = 0.0;
 }
 
+// The update launch of an overlapped run (see acc_launch_begin): on its own stream, resident while accumulate launch `seq`
+// still runs.  The state is fetched first (nothing writes it during an accumulate launch), then lane 0 waits for the
+// launch's `nblocks` tickets, the sums are read and consumed as in icp_update_kernel, the ticket word is left at zero and
+// the update is published (chain[1] = seq + 1) to the blocks of launch seq + 1, which are waiting or about to start.
+// A run that is over ("done") had no tickets to wait for: the word is published all the same, so that the launches still
+// enqueued behind it drain.  192 VGPRs (it needs 96): the wave must fit into the block slot that api.hip leaves free on every
+// XCD beside an accumulate launch (two of its waves per SIMD).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(192))) void icp_update_chained_kernel(IcpState *st, int nsums, uint32_t *chain,
+                                                                                                uint32_t seq, uint32_t nblocks) {
+  __shared__ double s_S[kNumSumsMax];
+  __shared__ IcpState s_st;
+  __shared__ uint32_t s_mode;   // 0: the run is over, 1: update, 2: the accumulate launch did not report in time
+  const int t = (int)threadIdx.x;
+  state_to_lds(&s_st, st);      // (written by the update before this one, a finished kernel of this stream: plain loads)
+  if (t == 0) {
+    uint32_t mode = 1u;
+    if (__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) mode = 0u;
+    else {
+      const unsigned long long t0 = wall_clock64();
+      while (chain_load(chain) < nblocks) {
+        if (wall_clock64() - t0 > kChainTimeoutTicks) { mode = 2u; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    s_mode = mode;
+  }
+  __syncthreads();
+  const uint32_t mode = s_mode;
+  constexpr int kSumsWord0 = (int)(offsetof(IcpState, S) / 4), kSumsWords = 2 * kNumSumsMax, kWords = (int)(sizeof(IcpState) / 4);
+  if (mode == 1u) {
+    // the sums as the blocks' atomics left them (the state's own array: overlapped runs have no caller-owned sums buffer)
+    if (t < kNumSumsMax) s_S[t] = t < nsums ? __hip_atomic_load(&st->S[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    __syncthreads();
+    if (t == 0) icp_update_lane(&s_st, s_S, nullptr);
+    __syncthreads();
+    // The state goes back with plain stores — the next update and the host read it after this kernel has ended — EXCEPT the
+    // sums: a zero left dirty in this XCD's L2 would be written back at the end of this kernel, over what the next launch's
+    // blocks have added by then.  The consumed sums are zeroed, and the words the next launch reads while this kernel is
+    // still running (transform rows, "done") are stored once more, with agent-scope atomics.
+    for (int i = t; i < kWords; i += 64)
+      if (i < kSumsWord0 || i >= kSumsWord0 + kSumsWords) reinterpret_cast<uint32_t *>(st)[i] = reinterpret_cast<const uint32_t *>(&s_st)[i];
+    if (t < nsums) __hip_atomic_store(&st->S[t], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < 12) __hip_atomic_store(&st->Ff[t], s_st.Ff[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 12) __hip_atomic_store(&st->done, s_st.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (mode == 2u && t == 0) {
+    __hip_atomic_store(&st->chain_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&st->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicOr(chain + 2, 2u);
+  }
+  chain_wait_own_memory_ops();
+  __syncthreads();
+  if (t == 0) {
+    chain_store(chain, 0u);
+    chain_wait_own_memory_ops();
+    chain_store(chain + 1, seq + 1u);
+  }
+}
+
 // OPE_EST_POINT_TO_PLANE_LM: the Levenberg-Marquardt minimisation on the 91 sums of lm_stats_kernel (lm.hip, lm_solve.hpp)
 // and the update step in one launch, one lane: nothing comes back to the host between two iterations.  S: the 17 sums of the
 // accumulate launch (n and the MSE feed the convergence test); both sum buffers are left at zero.
@@ -1340,7 +1446,7 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
                            const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
                            int k_normal_shooting, double *S_atomic, const uint32_t *slot_list, float *knn_rk, const uint32_t *plan_out,
-                           hipEvent_t e0, hipEvent_t e1, bool measuring) {
+                           hipEvent_t e0, hipEvent_t e1, bool measuring, uint32_t *chain, uint32_t chain_seq) {
   const uint32_t mflag = measuring ? 1u : 0u;
   // e0 / e1 (ope_icp_profile): the launch's own start and stop time stamps, taken by the dispatch itself (hipExtLaunchKernelGGL).
   // Round 3 measured what a hipEventRecord before and after every launch costs the loop it times: 7-11 us per iteration (two
@@ -1349,10 +1455,10 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
   do {                                                                                                                        \
     if (e0 != nullptr)                                                                                                        \
       hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, e0, e1, 0, src, tgt, srcix, st, partials, corr_match, \
-                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag); \
+                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq); \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, partials, corr_match, corr_d2,   \
-                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag); \
+                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq); \
   } while (0)
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS) OPE_KLAUNCH((icp_accumulate_kernel<M, N, R>), BLK, LDS)
   if (mode == 0 && !recip && packet) {
@@ -1402,16 +1508,17 @@ int icp_accumulate_blocks_per_cu(bool nrm, bool packet, bool grid) {
 void launch_icp_accumulate_grid(hipStream_t stream, int nblocks, bool nrm, const CloudView &src, const BvhView &tgt, const GridView &grid,
                                 const IcpState *st, double *partials, int32_t *corr_match, float *corr_d2, uint32_t *hint, uint32_t *ghint,
                                 const uint32_t *qorder, unsigned char *qclass, const uint32_t *chunk_order, uint32_t *chunk_cost,
-                                const uint32_t *plan_info, double *S_atomic, hipEvent_t e0, hipEvent_t e1, bool measuring) {
+                                const uint32_t *plan_info, double *S_atomic, hipEvent_t e0, hipEvent_t e1, bool measuring, uint32_t *chain,
+                                uint32_t chain_seq) {
   const uint32_t mflag = measuring ? 1u : 0u;
 #define OPE_KLAUNCH(KERNEL)                                                                                                   \
   do {                                                                                                                        \
     if (e0 != nullptr)                                                                                                        \
       hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, e0, e1, 0, src, tgt, grid, st, partials, corr_match, \
-                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag);       \
+                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq); \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, grid, st, partials, corr_match, corr_d2, \
-                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag);                   \
+                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq); \
   } while (0)
   if (nrm) OPE_KLAUNCH((icp_accumulate_grid_kernel<true>));
   else OPE_KLAUNCH((icp_accumulate_grid_kernel<false>));
@@ -1431,6 +1538,10 @@ void launch_icp_p2p_update(hipStream_t stream, IcpState *st, double *S, int nsum
 
 void launch_icp_lm_update(hipStream_t stream, IcpState *st, double *S, double *stats) {
   hipLaunchKernelGGL(icp_lm_update_kernel, dim3(1), dim3(64), 0, stream, st, S, stats);
+}
+
+void launch_icp_update_chained(hipStream_t stream, IcpState *st, int nsums, uint32_t *chain, uint32_t seq, uint32_t nblocks) {
+  hipLaunchKernelGGL(icp_update_chained_kernel, dim3(1), dim3(64), 0, stream, st, nsums, chain, seq, nblocks);
 }
 
 void launch_icp_update(hipStream_t stream, IcpState *st, double *S, int nsums, const float *Tk_ext) {

@@ -84,7 +84,8 @@ struct IcpState {
   int max_iterations, failure_after_max_iter, min_correspondences;
   int iterations, converged, state, done;
   int corr_mode, k_normal_shooting, use_surface_normal_rej, use_self_occluded_rej, use_reciprocal, estimator;
-  int comm_error, pad2_;   // set by the peer-to-peer exchange when a peer's sums did not arrive in time (run ends)
+  int comm_error;      // set by the peer-to-peer exchange when a peer's sums did not arrive in time (run ends)
+  int chain_error;     // set by an overlapped update launch whose accumulate launch did not report within the bounded wait (run ends)
   // k-NN runs (normal shooting): the transform the previous accumulate launch searched with, so that a query's k-th
   // neighbour distance of that launch plus its own displacement since bounds this launch's search (icp_accumulate_kernel)
   float Fprev[12];
@@ -158,6 +159,17 @@ struct ope_ctx {
   int plan_cur = 0;
   bool plan_pending = false, plan_pending_slots = false, plan_cur_slots = false;
   int acc_launches = 0;
+  // Update launches overlapped with the accumulate launches (api.hip: ope_icp_iterate; icp_kernels.hip: icp_update_chained_kernel):
+  // the update of iteration j is launched on its own stream next to accumulate launch j and waits, on the device, for that
+  // launch's blocks; accumulate launch j + 1 follows launch j on the launch stream and its blocks wait for update j's word.
+  hipStream_t upd_stream = nullptr;
+  hipEvent_t ev_chain_s = nullptr, ev_chain_u = nullptr;
+  bool chained = false;          // this run may overlap (decided by ope_icp_begin)
+  bool chain_on = false;         // the batch being enqueued does overlap
+  bool chain_open = false;       // the update stream holds launches the launch stream has not waited for yet
+  bool chain_u_synced = false;   // the update stream has waited for the launch stream since the state was last written there
+  bool chain_broken = false;     // a bounded wait ran out in an earlier run: later runs launch their updates in line
+  uint32_t chain_seq = 0;        // overlapped accumulate launches of this run so far (= updates published once they are done)
   int64_t kernel_launches[OPE_KERNEL_KINDS] = {0, 0, 0, 0};   // per search kernel, this run (ope_icp_kernel_launches)
   uint32_t *d_hint = nullptr;       // per sorted query: leaf (heap id) of the previous iteration's match, 0 = none
   float *d_knn_rk = nullptr;        // k-NN runs: per sorted query the squared distance of the last list entry of the previous launch (+inf: none)

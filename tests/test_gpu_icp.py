@@ -647,3 +647,70 @@ def test_deterministic_sums_are_bit_reproducible_from_run_to_run():
         ctx.close()
     assert np.array_equal(outs[0].T, outs[1].T) and outs[0].last_mse == outs[1].last_mse and outs[0].n_corr == outs[1].n_corr
     assert np.linalg.norm(outs[0].T.astype(np.float64) - outs[2].T.astype(np.float64)) < 1e-5
+
+
+# ------------------------------------------------------------------ overlapped update launches (ope_icp_params.update_launch)
+# Default runs launch their update step on a stream of its own, waiting on the device for the accumulate launch's blocks
+# (include/ope.h, icp_kernels.hip: acc_launch_begin / icp_update_chained_kernel); OPE_UPDATE_IN_LINE is the sequence of rounds
+# 1-2.  Same arithmetic: the two must agree to the run-to-run noise of the atomic sums, on every search kernel, and
+# ope_icp_overlapped_updates says which of them a comparison exercised.
+@pytest.mark.parametrize("kernel", ["grid", "tree_lane", "tree_packet"])
+def test_overlapped_update_equals_in_line_and_oracle(ctx, kernel):
+    src = synth.scene_cloud(100000)
+    tgt = synth.model_surface(20000, 1)
+    kw = dict(max_iterations=30, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0)
+    over, _, _ = gpu_icp_on(ctx, kernel, src, tgt, update_launch=0, **kw)
+    assert ctx.icp_overlapped_updates() == 30
+    line, _, _ = gpu_icp_on(ctx, kernel, src, tgt, update_launch=1, **kw)
+    assert ctx.icp_overlapped_updates() == 0
+    assert over.iterations == line.iterations == 30 and over.state == line.state and over.n_corr == line.n_corr
+    # (not bit-equal: the order of the blocks' fp64 atomic additions differs from run to run, and thirty iterations with 10 %
+    # clutter turn a last-bit difference of a sum into ~1e-6 of the transform — two in-line runs differ by as much)
+    line2, _, _ = gpu_icp_on(ctx, kernel, src, tgt, update_launch=1, **kw)
+    assert frob(over.T, line.T) < 1e-5 and frob(line2.T, line.T) < 1e-5
+    assert over.last_mse == pytest.approx(line.last_mse, rel=1e-5)
+    ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw))
+    assert frob(over.T, ref.T) < 2e-5 and frob(line.T, ref.T) < 2e-5
+
+
+def test_overlapped_update_run_that_converges_inside_a_batch_drains(ctx):
+    """The run converges after a handful of iterations while fifty launches are enqueued (check_every = 0): the launches behind
+    the converged one find "done", take no tickets and wait for none; iteration count, state and transform as in line."""
+    P = synth.bumpy_torus(20000)
+    Q = apply(rigid(2, -3, 1, [0.004, -0.002, 0.003]), P)
+    ope = load_pkg()
+    res = {}
+    for mode in (0, 1):
+        cs = ctx.upload(P)
+        ix = ctx.build_index(ctx.upload(Q))
+        res[mode] = ctx.icp(cs, ix, ope.default_icp_params(max_iterations=50, transformation_epsilon=1e-9, euclidean_fitness_epsilon=1e-12,
+                                                           check_every=0, update_launch=mode))
+    assert res[0].converged and res[1].converged
+    assert 2 < res[0].iterations < 50
+    assert res[0].iterations == res[1].iterations and res[0].state == res[1].state
+    assert frob(res[0].T, res[1].T) < 1e-6
+
+
+def test_overlapped_batches_interleaved_with_the_step_wise_entry_points(ctx):
+    """iterate (overlapped) -> accumulate + update (in line) -> iterate (overlapped), one iteration per call as bench.py steps:
+    the update stream joins and re-joins the launch stream; result as one in-line run of the same length."""
+    ope = load_pkg()
+    src = synth.scene_cloud(50000)
+    tgt = synth.model_surface(10000, 1)
+    kw = dict(max_iterations=12, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0, check_every=0)
+    cs = ctx.upload(src)
+    ix = ctx.build_index(ctx.upload(tgt))
+    ctx.icp_begin(cs, ix, ope.default_icp_params(update_launch=0, **kw))
+    for _ in range(4):
+        ctx.icp_iterate(1)
+    T4 = ctx.icp_current_transform()
+    for _ in range(3):
+        ctx.icp_accumulate()
+        ctx.icp_update()
+    ctx.icp_iterate(5)
+    mixed = ctx.icp_end()
+    assert ctx.icp_overlapped_updates() == 9 and mixed.iterations == 12
+    line = ctx.icp(cs, ix, ope.default_icp_params(update_launch=1, **kw))
+    assert frob(mixed.T, line.T) < 1e-6
+    ref4 = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **{**kw, "max_iterations": 4}))
+    assert frob(T4, ref4.T) < 2e-5
