@@ -219,6 +219,20 @@ typedef struct {
 
 void ope_icp_default_params(ope_icp_params *p);
 
+/* IterativeClosestPoint::setFixedCorrespondences (vPCL icp_mod.h:268; getFixedCorrespondences :276, clearCorrespondences
+ * :281) — the reference's injection of given pairs into every iteration, unused by its own programs.  index_query /
+ * index_match: ORIGINAL indices into `src` and into the cloud the target index was built from; n = 0 clears.  They stay set
+ * for every later run over the same source cloud and a target of the same size, and take part as the reference has them:
+ * 1-NN estimation lists every given pair in front of the searched ones whatever its distance, with the distance field
+ * (squared distance) * 1e10 — which therefore also enters the MSE of the convergence test — (correspondence_estimation_mod.hpp:
+ * 134-162); normal shooting lists none (…normal_shooting_weighted.hpp:81-101); listed pairs pass the rejectors like any
+ * other; then the FIRST rejector alone is applied to the given pairs and the survivors are appended, a second time for those
+ * already listed (icp_mod.hpp:210-224; only when a rejector is installed).  SVD estimator only; not with reciprocal
+ * correspondences; sharded runs add them on rank 0.  ope_icp_correspondences lists the searched pairs only.  Runs with fixed
+ * correspondences launch their update in line. */
+int ope_icp_set_fixed_correspondences(ope_ctx *ctx, const ope_cloud *src, const ope_cloud *tgt_cloud, const int32_t *index_query,
+                                      const int32_t *index_match, size_t n);
+
 /* How many accumulate launches of the current (or last) run each search kernel served: the bucketed grid kernel, the
  * OBB-tree kernel in its per-lane and in its packet instantiation, the k-NN (normal shooting) kernel.  A run may move
  * between kernels (ope_index_params.grid = 1); tests use this to assert which kernel their comparison exercised. */

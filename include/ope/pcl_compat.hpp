@@ -395,6 +395,11 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
   void addCorrespondenceRejector(const registration::CorrespondenceRejector::Ptr &r) { rejectors_.push_back(r); }
   template <class TE> void setTransformationEstimation(const std::shared_ptr<TE> &) { params_.estimator = TE::ope_estimator; }
   std::shared_ptr<registration::DefaultConvergenceCriteria> getConvergeCriteria() { return criteria_; }
+  // vPCL icp_mod.h:268-281 — the reference's injection of given pairs into every iteration (unused by its own programs).
+  // The pointer is kept, as in the reference; the pairs are read at align().
+  void setFixedCorrespondences(Correspondences *correspondences) { corres_fixed_ = correspondences; }
+  Correspondences getFixedCorrespondences() { return *corres_fixed_; }
+  void clearCorrespondences() { if (corres_fixed_) corres_fixed_->clear(); }
 
   void align(PointCloudSource &output) { align(output, Matrix4f::Identity()); }
   void align(PointCloudSource &output, const Matrix4f &guess) {
@@ -431,8 +436,21 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
       if (tgt_dev_->h && ope_index_build(ctx, tgt_dev_->h, nullptr, &tgt_index_->h) != OPE_OK) log_error("align", ctx);
     }
     if (!src_dev_->h || !tgt_index_->h) return;
+    {
+      // icp_mod.hpp:150-151: the given pairs, if any, go to the correspondence estimation of THIS run (the context is shared
+      // between objects: they are cleared again below)
+      std::vector<int32_t> fq, fm;
+      if (corres_fixed_)
+        for (const Correspondence &c : *corres_fixed_) { fq.push_back(c.index_query); fm.push_back(c.index_match); }
+      if (ope_icp_set_fixed_correspondences(ctx, src_dev_->h, tgt_dev_->h, fq.data(), fm.data(), fq.size()) != OPE_OK) {
+        log_error("align (fixed correspondences)", ctx);
+        return;
+      }
+    }
     ope_icp_result res;
-    if (ope_icp_run(ctx, src_dev_->h, tgt_index_->h, guess.m, &p, final_.m, &res) != OPE_OK) {
+    const int rc_run = ope_icp_run(ctx, src_dev_->h, tgt_index_->h, guess.m, &p, final_.m, &res);
+    if (corres_fixed_ && !corres_fixed_->empty()) (void)ope_icp_set_fixed_correspondences(ctx, nullptr, nullptr, nullptr, nullptr, 0);
+    if (rc_run != OPE_OK) {
       log_error("align", ctx);
       final_ = Matrix4f::Identity();
       return;
@@ -484,6 +502,7 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
   bool uploaded_with_normals_ = false;
   Matrix4f last_incremental_ = Matrix4f::Identity();
   Correspondences correspondences_;
+  Correspondences *corres_fixed_ = nullptr;   // icp_mod.h:326
   std::shared_ptr<CloudHandle> src_dev_, tgt_dev_;
   std::shared_ptr<IndexHandle> tgt_index_;
   ope_icp_params params_;

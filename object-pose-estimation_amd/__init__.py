@@ -147,6 +147,7 @@ ABI = [
     ("ope_icp_set_global_sizes", C.c_int, [_vp, C.c_int64, C.c_int64]),
     ("ope_icp_kernel_launches", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("ope_icp_overlapped_updates", C.c_int64, [_vp]),
+    ("ope_icp_set_fixed_correspondences", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t]),
     ("ope_icp_profile_launches", C.c_int, [_vp, _fp, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ope_cloud_select", C.c_int, [_vp, _vp, _ip, C.c_size_t, C.POINTER(_vp)]),
     ("ope_remove_nan_cloud", C.c_int, [_vp, _vp, C.POINTER(_vp), _ip, C.POINTER(C.c_size_t)]),
@@ -458,6 +459,14 @@ class Context:
         c = (C.c_int64 * 4)()
         self._chk(lib().ope_icp_kernel_launches(self.h, c))
         return dict(zip(("grid", "tree_lane", "tree_packet", "knn"), (int(v) for v in c)))
+
+    def icp_set_fixed_correspondences(self, src: "Cloud", tgt_cloud: "Cloud", index_query=None, index_match=None):
+        """setFixedCorrespondences (icp_mod.h:268): pairs by original indices, for every later run over these clouds; no indices = clear."""
+        q = np.ascontiguousarray(index_query if index_query is not None else [], np.int32)
+        m = np.ascontiguousarray(index_match if index_match is not None else [], np.int32)
+        assert len(q) == len(m)
+        self._chk(lib().ope_icp_set_fixed_correspondences(self.h, src.h if src is not None else None, tgt_cloud.h if tgt_cloud is not None else None,
+                                                          q.ctypes.data_as(C.POINTER(C.c_int32)), m.ctypes.data_as(C.POINTER(C.c_int32)), len(q)))
 
     def icp_overlapped_updates(self) -> int:
         """Update steps of the current / last run that were launched overlapped (ope_icp_params.update_launch)."""

@@ -41,6 +41,8 @@ hipError_t build_grid_device(hipStream_t, const float4 *, const float4 *, size_t
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
 void launch_icp_update(hipStream_t, IcpState *, double *, int, const float *);
 void launch_icp_update_chained(hipStream_t, IcpState *, int, uint32_t *, uint32_t, uint32_t);
+void launch_gather_fixed_pairs(hipStream_t, const CloudView &, const CloudView &, const uint32_t *, uint32_t, float4 *);
+void launch_icp_fixed_pairs(hipStream_t, const IcpState *, const float4 *, uint32_t, double *);
 void launch_lm_stats(hipStream_t, int, const CloudView &, const BvhView &, const IcpState *, const int32_t *, double *);
 void launch_icp_lm_update(hipStream_t, IcpState *, double *, double *);
 void launch_lm_pos_to_orig(hipStream_t, const BvhView &, int32_t *, uint32_t);
@@ -412,6 +414,7 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
   if (ctx->d_work_counter) (void)hipFree(ctx->d_work_counter);
   if (ctx->d_lm_stats) (void)hipFree(ctx->d_lm_stats);
+  if (ctx->d_fixed) (void)hipFree(ctx->d_fixed);
   tmp_release_stream(ctx->stream);   // the cached temporaries of this context's stream
   if (ctx->plan_stream) { (void)hipStreamSynchronize(ctx->plan_stream); (void)hipStreamDestroy(ctx->plan_stream); }
   if (ctx->upd_stream) { (void)hipStreamSynchronize(ctx->upd_stream); (void)hipStreamDestroy(ctx->upd_stream); }
@@ -555,6 +558,7 @@ void ope_cloud_free(ope_cloud *cloud) {
   if (cloud->ctx) (void)hipSetDevice(cloud->ctx->device);
   // the last run's source: its correspondences can no longer be mapped back (ope_icp_correspondences -> OPE_ESTATE)
   if (cloud->ctx && cloud->ctx->run_src == cloud) { cloud->ctx->run_src = nullptr; cloud->ctx->run_active = false; }
+  if (cloud->ctx && cloud->ctx->fixed_src == cloud) { cloud->ctx->fixed_src = nullptr; cloud->ctx->n_fixed = 0; }   // fixed correspondences index a cloud that is gone
   if (cloud->d_xyzw) (void)hipFree(cloud->d_xyzw);
   if (cloud->d_nrm) (void)hipFree(cloud->d_nrm);
   delete cloud;
@@ -899,6 +903,14 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown estimator");
   if (p.tree_walk < OPE_WALK_AUTO || p.tree_walk > OPE_WALK_PACKET) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown tree_walk");
   if (p.update_launch != OPE_UPDATE_OVERLAPPED && p.update_launch != OPE_UPDATE_IN_LINE) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown update_launch");
+  if (ctx->n_fixed > 0) {
+    if (ctx->fixed_src != src || ctx->fixed_tgt_n != tgt->n_total)
+      return set_err(ctx, OPE_EINVAL, "ope_icp_begin: the fixed correspondences were set for another pair of clouds (ope_icp_set_fixed_correspondences with n = 0 clears them)");
+    if (p.estimator != OPE_EST_SVD) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: fixed correspondences are supported with the SVD estimator only");
+    if (p.use_reciprocal) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: fixed correspondences and reciprocal correspondences do not combine (the reference's reciprocal estimation ignores them)");
+    if ((p.use_surface_normal_rej && !ctx->fixed_has_nrm) || ((p.use_self_occluded_rej || p.corr_mode == OPE_CORR_NORMAL_SHOOTING) && !ctx->fixed_has_src_nrm))
+      return set_err(ctx, OPE_EINVAL, "ope_icp_begin: the clouds the fixed correspondences were gathered from had no normals");
+  }
   if ((p.estimator == OPE_EST_POINT_TO_PLANE_LLS || p.estimator == OPE_EST_POINT_TO_PLANE_LM) && !tgt->d_nrm)
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: the point-to-plane estimator needs target normals (build the index from a cloud with normals)");
   if (p.use_surface_normal_rej && !tgt->d_nrm)
@@ -1128,7 +1140,8 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   // update's wave finds room beside it whenever it arrives.
   ctx->chained = p.update_launch == OPE_UPDATE_OVERLAPPED && !ctx->chain_broken && p.corr_mode == OPE_CORR_NEAREST && !p.use_reciprocal &&
                  p.deterministic_sums == 0 && p.estimator != OPE_EST_POINT_TO_PLANE_LM && ctx->nccl_comm == nullptr && !ctx->p2p_ok &&
-                 !dev_env("OPE_NO_CHAIN");
+                 ctx->n_fixed == 0 && !dev_env("OPE_NO_CHAIN");
+  ctx->n_fixed_run = ctx->n_fixed;
   ctx->chain_on = false;
   ctx->chain_seq = 0;
   if (ctx->chained) {
@@ -1150,6 +1163,65 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   return OPE_OK;
 }
 
+// setFixedCorrespondences (vPCL icp_mod.h:268): pairs by ORIGINAL indices into the two clouds; their points (and normals) are
+// gathered once into four float4 per pair, so that the per-iteration launch needs neither cloud's order.
+int ope_icp_set_fixed_correspondences(ope_ctx *ctx, const ope_cloud *src, const ope_cloud *tgt_cloud, const int32_t *index_query,
+                                      const int32_t *index_match, size_t n) {
+  if (!ctx) return OPE_EINVAL;
+  if (ctx->run_active && ctx->n_fixed_run > 0)
+    return set_err(ctx, OPE_ESTATE, "ope_icp_set_fixed_correspondences: the run in progress uses the pairs set before it (end it first)");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->d_fixed) { OPE_HIP(ctx, hipStreamSynchronize(ctx->stream)); OPE_HIP(ctx, hipFree(ctx->d_fixed)); ctx->d_fixed = nullptr; }
+  ctx->n_fixed = 0;
+  ctx->fixed_src = nullptr;
+  ctx->fixed_tgt_n = 0;
+  if (n == 0) return OPE_OK;   // clearCorrespondences (icp_mod.h:281)
+  if (!src || !tgt_cloud || !index_query || !index_match) return set_err(ctx, OPE_EINVAL, "ope_icp_set_fixed_correspondences: bad argument");
+  if (n > ((size_t)1 << 24)) return set_err(ctx, OPE_EINVAL, "ope_icp_set_fixed_correspondences: more than 2^24 pairs");
+  int rc = src->ensure_host();
+  if (rc == OPE_OK) rc = tgt_cloud->ensure_host();
+  if (rc != OPE_OK) return rc;
+  // original index -> position in the Morton order, for the indices that occur
+  auto positions = [&](const ope_cloud *c, const int32_t *idx, std::vector<uint32_t> &pos, int slot) -> bool {
+    std::vector<std::pair<int32_t, uint32_t>> want(n);
+    for (size_t f = 0; f < n; ++f) {
+      if (idx[f] < 0 || (size_t)idx[f] >= c->n) return false;
+      want[f] = {idx[f], (uint32_t)f};
+    }
+    std::sort(want.begin(), want.end());
+    for (size_t p = 0; p < c->perm.size(); ++p) {
+      auto it = std::lower_bound(want.begin(), want.end(), std::make_pair(c->perm[p], (uint32_t)0));
+      for (; it != want.end() && it->first == c->perm[p]; ++it) pos[2 * it->second + slot] = (uint32_t)p;
+    }
+    return true;
+  };
+  std::vector<uint32_t> pos(2 * n, 0u);
+  if (!positions(src, index_query, pos, 0) || !positions(tgt_cloud, index_match, pos, 1))
+    return set_err(ctx, OPE_EINVAL, "ope_icp_set_fixed_correspondences: index out of range");
+  uint32_t *d_pos = nullptr;
+  OPE_HIP(ctx, hipMalloc((void **)&d_pos, sizeof(uint32_t) * 2 * n));
+  if (hipMalloc((void **)&ctx->d_fixed, sizeof(float4) * 4 * n) != hipSuccess) { (void)hipFree(d_pos); ctx->d_fixed = nullptr; return set_err(ctx, OPE_ENOMEM, "ope_icp_set_fixed_correspondences: out of device memory"); }
+  hipError_t e = hipMemcpyAsync(d_pos, pos.data(), sizeof(uint32_t) * 2 * n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    launch_gather_fixed_pairs(ctx->stream, src->view(), tgt_cloud->view(), d_pos, (uint32_t)n, ctx->d_fixed);
+    e = hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(d_pos);
+  if (e != hipSuccess) { (void)hipFree(ctx->d_fixed); ctx->d_fixed = nullptr; return set_err(ctx, OPE_EHIP, "ope_icp_set_fixed_correspondences: gather failed"); }
+  ctx->n_fixed = n;
+  ctx->fixed_src = src;
+  ctx->fixed_tgt_n = tgt_cloud->n;
+  ctx->fixed_has_nrm = src->d_nrm != nullptr && tgt_cloud->d_nrm != nullptr;
+  ctx->fixed_has_src_nrm = src->d_nrm != nullptr;
+  return OPE_OK;
+}
+
+// the given pairs' share of the sums, after an accumulate launch (rank 0 of a sharded run: they are added once)
+static void enqueue_fixed_pairs(ope_ctx *ctx) {
+  if (ctx->n_fixed_run == 0 || ctx->comm_rank != 0) return;
+  launch_icp_fixed_pairs(ctx->stream, ctx->d_state, ctx->d_fixed, (uint32_t)ctx->n_fixed_run, sums_ptr(ctx));
+}
+
 int ope_icp_accumulate(ope_ctx *ctx) {
   if (!ctx || !ctx->run_active) return set_err(ctx, OPE_ESTATE, "ope_icp_accumulate: no run in progress");
   if (ctx->run_params.estimator == OPE_EST_POINT_TO_PLANE_LM)
@@ -1162,6 +1234,7 @@ int ope_icp_accumulate(ope_ctx *ctx) {
   if (rc != OPE_OK) return rc;
   if (!atomic)
     launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, /*do_update=*/false, ctx->d_work_counter);
+  enqueue_fixed_pairs(ctx);
   OPE_HIP(ctx, hipGetLastError());
   return OPE_OK;
 }
@@ -1250,6 +1323,7 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
     if (sharded) {
       if (!atomic)
         launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
+      enqueue_fixed_pairs(ctx);
       if (comm_uses_p2p(ctx)) {
         // exchange through the peers' slots and update in one launch (no collective, no separate update kernel)
         rc = comm_p2p_exchange_update(ctx, ctx->d_state, sums_ptr(ctx), run_nsums(ctx));
@@ -1260,9 +1334,11 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
         launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx), nullptr);
       }
     } else if (atomic) {
+      enqueue_fixed_pairs(ctx);
       launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx), nullptr);
-    } else if (split_update) {
+    } else if (split_update || ctx->n_fixed_run > 0) {
       launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, false, ctx->d_work_counter);
+      enqueue_fixed_pairs(ctx);
       launch_icp_update(ctx->stream, ctx->d_state, sums_ptr(ctx), run_nsums(ctx), nullptr);
     } else {
       launch_icp_reduce_update(ctx->stream, ctx->d_state, ctx->d_partials, sums_ptr(ctx), ctx->acc_blocks, true, ctx->d_work_counter);

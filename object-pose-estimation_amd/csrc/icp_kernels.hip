@@ -1286,6 +1286,78 @@ __global__ __launch_bounds__(256) void icp_p2p_update_kernel(IcpState *st, doubl
 }
 
 // ------------------------------------------------------------------------------------------
+// The reference's injected "fixed correspondences" (setFixedCorrespondences, vPCL icp_mod.h:268; unused by its programs).
+// fix: four float4 per pair {source point, source normal, target point, target normal}, gathered once by
+// ope_icp_set_fixed_correspondences.  One launch after every accumulate launch adds the pairs' terms to the run's sums with
+// the multiplicity the reference gives them:
+//   1-NN estimation lists every given pair, distance field = (squared distance, float) * 1e10
+//   (correspondence_estimation_mod.hpp:134-162); normal shooting lists none and sets the field to the squared distance to
+//   the source normal's line (…normal_shooting_weighted.hpp:81-101); listed pairs pass through the rejectors like any other;
+//   then the FIRST rejector alone is applied to the given pairs once more and the survivors are appended (icp_mod.hpp:210-224).
+__global__ __launch_bounds__(64) void gather_fixed_pairs_kernel(CloudView src, CloudView tgt, const uint32_t *__restrict__ pos, uint32_t n,
+                                                                float4 *__restrict__ fix) {
+  const uint32_t f = blockIdx.x * 64u + threadIdx.x;
+  if (f >= n) return;
+  const uint32_t ps = pos[2 * f], pt = pos[2 * f + 1];
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  fix[4 * f + 0] = src.xyzw[ps];
+  fix[4 * f + 1] = src.nrm ? src.nrm[ps] : z;
+  fix[4 * f + 2] = tgt.xyzw[pt];
+  fix[4 * f + 3] = tgt.nrm ? tgt.nrm[pt] : z;
+}
+
+__global__ __launch_bounds__(64) void icp_fixed_pairs_kernel(const IcpState *__restrict__ st, const float4 *__restrict__ fix, uint32_t n, double *S) {
+  if (st->done) return;
+  __shared__ double s_sum[kNumSums];
+  if (threadIdx.x < kNumSums) s_sum[threadIdx.x] = 0.0;
+  __syncthreads();
+  const bool ns_mode = st->corr_mode == OPE_CORR_NORMAL_SHOOTING;
+  const bool rej_sn = st->use_surface_normal_rej != 0, rej_so = st->use_self_occluded_rej != 0;
+  const double thr_sn = st->surface_normal_thr, thr_so = st->self_occluded_thr;
+  const double px = st->pivot[0], py = st->pivot[1], pz = st->pivot[2];
+  for (uint32_t f = threadIdx.x; f < n; f += 64u) {
+    const float4 s = fix[4 * f], sn = fix[4 * f + 1], t = fix[4 * f + 2], tn = fix[4 * f + 3];
+    const float x = xform_row(st->Ff + 0, s.x, s.y, s.z), y = xform_row(st->Ff + 4, s.x, s.y, s.z), z = xform_row(st->Ff + 8, s.x, s.y, s.z);
+    const float nx = rot_row(st->Ff + 0, sn.x, sn.y, sn.z), ny = rot_row(st->Ff + 4, sn.x, sn.y, sn.z), nz = rot_row(st->Ff + 8, sn.x, sn.y, sn.z);
+    const float vx = __fsub_rn(t.x, x), vy = __fsub_rn(t.y, y), vz = __fsub_rn(t.z, z);
+    float dist;
+    if (!ns_mode) {
+      const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz));
+      dist = (float)((double)d2 * 1e10);
+    } else {
+      const double cx = (double)ny * vz - (double)nz * vy, cy = (double)nz * vx - (double)nx * vz, cz = (double)nx * vy - (double)ny * vx;
+      dist = (float)(cx * cx + cy * cy + cz * cz);
+    }
+    bool pass_sn = true, pass_so = true;
+    if (rej_sn) pass_sn = (double)__fadd_rn(__fadd_rn(__fmul_rn(nx, tn.x), __fmul_rn(ny, tn.y)), __fmul_rn(nz, tn.z)) > thr_sn;
+    if (rej_so) {
+      const double sl = sqrt((double)__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+      pass_so = (double)nx * (-(double)x / sl) + (double)ny * (-(double)y / sl) + (double)nz * (-(double)z / sl) > thr_so;
+    }
+    int mult = (!ns_mode && pass_sn && pass_so) ? 1 : 0;                 // listed by the estimation, through every rejector
+    if (rej_sn || rej_so) mult += (rej_sn ? pass_sn : pass_so) ? 1 : 0;  // the first rejector alone, appended
+    if (mult == 0) continue;
+    const double w = (double)mult;
+    const double sx = (double)x - px, sy = (double)y - py, sz = (double)z - pz;
+    const double tx = (double)t.x - px, ty = (double)t.y - py, tz = (double)t.z - pz;
+    const double term[kNumSums] = {w, w * sx, w * sy, w * sz, w * tx, w * ty, w * tz,
+                                   w * (tx * sx), w * (tx * sy), w * (tx * sz), w * (ty * sx), w * (ty * sy), w * (ty * sz),
+                                   w * (tz * sx), w * (tz * sy), w * (tz * sz), w * (double)dist};
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) unsafeAtomicAdd(&s_sum[k], term[k]);
+  }
+  __syncthreads();
+  if (threadIdx.x < kNumSums && s_sum[threadIdx.x] != 0.0) unsafeAtomicAdd(S + threadIdx.x, s_sum[threadIdx.x]);
+}
+
+void launch_gather_fixed_pairs(hipStream_t stream, const CloudView &src, const CloudView &tgt, const uint32_t *pos, uint32_t n, float4 *fix) {
+  hipLaunchKernelGGL(gather_fixed_pairs_kernel, dim3((n + 63u) / 64u), dim3(64), 0, stream, src, tgt, pos, n, fix);
+}
+void launch_icp_fixed_pairs(hipStream_t stream, const IcpState *st, const float4 *fix, uint32_t n, double *S) {
+  hipLaunchKernelGGL(icp_fixed_pairs_kernel, dim3(1), dim3(64), 0, stream, st, fix, n, S);
+}
+
+// ------------------------------------------------------------------------------------------
 // Stand-alone TransformationEstimationSVD on n given pairs (poseestimator.cpp:429-435):
 // the same 17 sums, about the first source point, then the same umeyama lane.
 __global__ __launch_bounds__(256) void pairs_sums_kernel(const float *__restrict__ src, const float *__restrict__ tgt,

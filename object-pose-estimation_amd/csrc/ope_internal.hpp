@@ -201,6 +201,12 @@ struct ope_ctx {
   int64_t n_src_total = 0, n_tgt_total = 0;
   int iters_enqueued = 0;
   double *d_sums_ext = nullptr;   // caller-owned 17-double buffer (e.g. a torch tensor) or null
+  // setFixedCorrespondences (ope_icp_set_fixed_correspondences): four float4 per pair {source point, source normal, target point, target normal}
+  float4 *d_fixed = nullptr;
+  size_t n_fixed = 0, n_fixed_run = 0;   // as set / as taken by the run in progress
+  const ope_cloud *fixed_src = nullptr;  // the source cloud they index (checked by ope_icp_begin)
+  size_t fixed_tgt_n = 0;                // size of the target cloud they index
+  bool fixed_has_nrm = false, fixed_has_src_nrm = false;
 
   // optional per-launch timing of the accumulate kernel (HIP events on the launch stream)
   bool prof_enabled = false;

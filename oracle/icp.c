@@ -477,6 +477,21 @@ void orc_icp_partial_sums_mt(const float *src_xyz, int ns, const orc_kdtree *tgt
 int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt_xyz, const float *tgt_nrm, int nt,
             const float guess[16], const orc_icp_params *p, float out_T[16], orc_icp_result *res, float *T_hist,
             int32_t *corr_q_out, int32_t *corr_m_out, float *corr_d2_out) {
+  return orc_icp_fixed(src_xyz, src_nrm, ns, tgt_xyz, tgt_nrm, nt, guess, p, NULL, NULL, 0, out_T, res, T_hist, corr_q_out, corr_m_out, corr_d2_out);
+}
+
+/* The loop with the reference's "fixed correspondences" (setFixedCorrespondences, icp_mod.h:268; unused by its programs):
+ *  - 1-NN estimation puts the given pairs in FRONT of the searched ones, whatever their distance, with
+ *    distance = (squared distance, float) * 1e10 (correspondence_estimation_mod.hpp:134-162) — so they also enter the MSE the
+ *    convergence test looks at, at that scale;
+ *  - the normal-shooting estimation only refreshes their distance field (squared distance to the source normal's line) and
+ *    does NOT list them (…normal_shooting_weighted.hpp:81-101);
+ *  - after the rejectors have run over the list, the FIRST rejector alone is applied to the given pairs once more and the
+ *    survivors are appended — a second time for those the list already holds (icp_mod.hpp:210-224; only with a rejector).
+ * corr_*_out then need room for ns + 2 * n_fixed entries. */
+int orc_icp_fixed(const float *src_xyz, const float *src_nrm, int ns, const float *tgt_xyz, const float *tgt_nrm, int nt,
+                  const float guess[16], const orc_icp_params *p, const int32_t *fixed_q, const int32_t *fixed_m, int n_fixed,
+                  float out_T[16], orc_icp_result *res, float *T_hist, int32_t *corr_q_out, int32_t *corr_m_out, float *corr_d2_out) {
   static const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   memset(res, 0, sizeof *res);
   memcpy(out_T, I4, sizeof I4);
@@ -488,18 +503,23 @@ int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt
   int need_src_nrm = (p->corr_mode == 1) || p->use_surface_normal_rej || p->use_self_occluded_rej;
   int need_tgt_nrm = p->use_surface_normal_rej || p->estimator == 1 || p->estimator == 2;
   if ((need_src_nrm && !src_nrm) || (need_tgt_nrm && !tgt_nrm)) return -3;
+  if (n_fixed < 0 || (n_fixed > 0 && (!fixed_q || !fixed_m))) return -4;
+  for (int f = 0; f < n_fixed; ++f)
+    if (fixed_q[f] < 0 || fixed_q[f] >= ns || fixed_m[f] < 0 || fixed_m[f] >= nt) return -4;
+  const size_t cap = (size_t)ns + 2 * (size_t)n_fixed;
+  float *fixed_d = (float *)malloc(sizeof(float) * (size_t)(n_fixed > 0 ? n_fixed : 1));
 
   orc_kdtree *tree = orc_kdtree_build(tgt_xyz, nt, 15);
   orc_kdtree *rtree = NULL;
 
   float *work = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
   float *wnrm = src_nrm ? (float *)malloc(sizeof(float) * 3 * (size_t)ns) : NULL;
-  int32_t *cq = (int32_t *)malloc(sizeof(int32_t) * (size_t)ns);
-  int32_t *cm = (int32_t *)malloc(sizeof(int32_t) * (size_t)ns);
-  float *cd = (float *)malloc(sizeof(float) * (size_t)ns);
-  float *ps = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
-  float *pt = (float *)malloc(sizeof(float) * 3 * (size_t)ns);
-  float *pn = (p->estimator == 1 || p->estimator == 2) ? (float *)malloc(sizeof(float) * 3 * (size_t)ns) : NULL;
+  int32_t *cq = (int32_t *)malloc(sizeof(int32_t) * cap);
+  int32_t *cm = (int32_t *)malloc(sizeof(int32_t) * cap);
+  float *cd = (float *)malloc(sizeof(float) * cap);
+  float *ps = (float *)malloc(sizeof(float) * 3 * cap);
+  float *pt = (float *)malloc(sizeof(float) * 3 * cap);
+  float *pn = (p->estimator == 1 || p->estimator == 2) ? (float *)malloc(sizeof(float) * 3 * cap) : NULL;
   int kk = p->k_normal_shooting > 0 ? p->k_normal_shooting : 1;
   int32_t *nn_i = (int32_t *)malloc(sizeof(int32_t) * (size_t)kk);
   float *nn_d = (float *)malloc(sizeof(float) * (size_t)kk);
@@ -534,6 +554,20 @@ int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt
     if (p->use_reciprocal) {
       if (rtree) orc_kdtree_free(rtree);
       rtree = orc_kdtree_build(work, ns, 15);
+    }
+    for (int f = 0; f < n_fixed; ++f) {
+      const float *q = work + 3 * fixed_q[f], *t = tgt_xyz + 3 * fixed_m[f];
+      const float vx = t[0] - q[0], vy = t[1] - q[1], vz = t[2] - q[2];
+      if (p->corr_mode == 0) {
+        const float d2 = vx * vx + vy * vy + vz * vz;
+        fixed_d[f] = (float)((double)d2 * 1e10);
+        cq[ncorr] = fixed_q[f]; cm[ncorr] = fixed_m[f]; cd[ncorr] = fixed_d[f]; ++ncorr;
+      } else {
+        const float *nq = wnrm + 3 * fixed_q[f];
+        const double N[3] = {nq[0], nq[1], nq[2]}, V[3] = {vx, vy, vz};
+        const double Cx = N[1] * V[2] - N[2] * V[1], Cy = N[2] * V[0] - N[0] * V[2], Cz = N[0] * V[1] - N[1] * V[0];
+        fixed_d[f] = (float)(Cx * Cx + Cy * Cy + Cz * Cz);
+      }
     }
     for (int i = 0; i < ns; ++i) {
       const float *q = work + 3 * i;
@@ -588,6 +622,25 @@ int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt
       }
       ncorr = m;
     }
+    if (n_fixed > 0 && (p->use_surface_normal_rej || p->use_self_occluded_rej)) {
+      /* "Apply the first rejector on the fixed correspondances" (icp_mod.hpp:210-224) */
+      for (int f = 0; f < n_fixed; ++f) {
+        const float *a = wnrm + 3 * fixed_q[f];
+        double score;
+        int keep;
+        if (p->use_surface_normal_rej) {
+          const float *b = tgt_nrm + 3 * fixed_m[f];
+          score = (double)((a[0] * b[0]) + (a[1] * b[1]) + (a[2] * b[2]));
+          keep = score > p->surface_normal_thr;
+        } else {
+          const float *pp = work + 3 * fixed_q[f];
+          const double sl = sqrt((double)(pp[0] * pp[0] + pp[1] * pp[1] + pp[2] * pp[2]));
+          score = (double)((a[0] * (-pp[0] / sl)) + (a[1] * (-pp[1] / sl)) + (a[2] * (-pp[2] / sl)));
+          keep = score > p->self_occluded_thr;
+        }
+        if (keep) { cq[ncorr] = fixed_q[f]; cm[ncorr] = fixed_m[f]; cd[ncorr] = fixed_d[f]; ++ncorr; }
+      }
+    }
     if (ncorr < p->min_correspondences) {
       cc.state = ORC_CONV_NO_CORRESPONDENCES;
       converged = 0;
@@ -633,6 +686,7 @@ int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt
   if (corr_m_out) memcpy(corr_m_out, cm, sizeof(int32_t) * (size_t)ncorr);
   if (corr_d2_out) memcpy(corr_d2_out, cd, sizeof(float) * (size_t)ncorr);
 
+  free(fixed_d);
   free(work); free(wnrm); free(cq); free(cm); free(cd); free(ps); free(pt); free(pn); free(nn_i); free(nn_d);
   orc_kdtree_free(tree);
   if (rtree) orc_kdtree_free(rtree);

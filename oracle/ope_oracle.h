@@ -178,6 +178,12 @@ int orc_icp(const float *src_xyz, const float *src_nrm, int ns,
             float out_T[16], orc_icp_result *res,
             float *T_hist, int32_t *corr_q, int32_t *corr_m, float *corr_d2);
 
+/* The same loop with the reference's injected "fixed correspondences" (icp_mod.h:268, icp_mod.hpp:150-151,210-224;
+ * correspondence_estimation_mod.hpp:134-162): see icp.c.  corr_* need room for ns + 2 * n_fixed entries. */
+int orc_icp_fixed(const float *src_xyz, const float *src_nrm, int ns, const float *tgt_xyz, const float *tgt_nrm, int nt,
+                  const float guess[16], const orc_icp_params *p, const int32_t *fixed_q, const int32_t *fixed_m, int n_fixed,
+                  float out_T[16], orc_icp_result *res, float *T_hist, int32_t *corr_q, int32_t *corr_m, float *corr_d2);
+
 /* Registration::getFitnessScore(max_range) for an arbitrary transform. */
 double orc_fitness(const float *src_xyz, int ns, const float *tgt_xyz, int nt,
                    const float T[16], double max_range, int *n_used);

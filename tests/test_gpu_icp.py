@@ -714,3 +714,75 @@ def test_overlapped_batches_interleaved_with_the_step_wise_entry_points(ctx):
     assert frob(mixed.T, line.T) < 1e-6
     ref4 = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **{**kw, "max_iterations": 4}))
     assert frob(T4, ref4.T) < 2e-5
+
+
+# ------------------------------------------------------------------ fixed correspondences (vPCL icp_mod.h:268, icp_mod.hpp:150-151,210-224)
+def _fixed_case():
+    src = synth.scene_cloud(20000)
+    tgt = synth.model_surface(5000, 1)
+    rng = np.random.default_rng(7)
+    fq = rng.choice(len(src), 40, replace=False).astype(np.int32)
+    fm = rng.choice(len(tgt), 40, replace=False).astype(np.int32)
+    return src, tgt, fq, fm
+
+
+@pytest.mark.parametrize("deterministic", [0, 1])
+def test_fixed_correspondences_1nn_match_oracle(ctx, deterministic):
+    """Given pairs in front of the searched ones, distance field x 1e10 (it enters the MSE), every iteration: transform,
+    correspondence count and MSE against the oracle's restatement; and the run without them is a different one."""
+    ope = load_pkg()
+    src, tgt, fq, fm = _fixed_case()
+    kw = dict(max_iterations=6, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0)
+    cs, ct = ctx.upload(src), ctx.upload(tgt)
+    ix = ctx.build_index(ct)
+    ctx.icp_set_fixed_correspondences(cs, ct, fq, fm)
+    out = ctx.icp(cs, ix, ope.default_icp_params(deterministic_sums=deterministic, **kw))
+    assert ctx.icp_overlapped_updates() == 0                      # such runs launch their update in line
+    ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw), fixed=(fq, fm))
+    assert out.n_corr == ref.n_corr == len(src) + len(fq)
+    assert frob(out.T, ref.T) < 2e-5
+    assert out.last_mse == pytest.approx(ref.last_mse, rel=1e-5)  # dominated by the forty 1e10-scaled distances
+    ctx.icp_set_fixed_correspondences(None, None)                 # clearCorrespondences
+    plain = ctx.icp(cs, ix, ope.default_icp_params(**kw))
+    ref0 = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw))
+    assert plain.n_corr == len(src) and frob(plain.T, ref0.T) < 2e-5 and frob(plain.T, out.T) > 1e-3
+
+
+@pytest.mark.parametrize("mode", ["nn_rejector", "normal_shooting"])
+def test_fixed_correspondences_with_a_rejector_are_counted_as_the_reference_counts_them(ctx, mode):
+    """With a rejector installed the first rejector is applied to the given pairs once more and the survivors are appended
+    (icp_mod.hpp:210-224): twice in the list under 1-NN estimation, once under normal shooting (which lists none itself)."""
+    ope = load_pkg()
+    src, tgt, fq, fm = _fixed_case()
+    sn, tn = oracle.normals_knn(src, 12)[0], oracle.normals_knn(tgt, 12)[0]
+    ns_mode = mode == "normal_shooting"
+    kw = dict(max_iterations=4, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0,
+              use_surface_normal_rej=1, surface_normal_thr=0.3, corr_mode=1 if ns_mode else 0, k_normal_shooting=10)
+    cs, ct = ctx.upload(src, normals=sn), ctx.upload(tgt, normals=tn)
+    ix = ctx.build_index(ct)
+    ctx.icp_set_fixed_correspondences(cs, ct, fq, fm)
+    out = ctx.icp(cs, ix, ope.default_icp_params(**kw))
+    ctx.icp_set_fixed_correspondences(None, None)
+    base = ctx.icp(cs, ix, ope.default_icp_params(**kw))
+    ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw), src_nrm=sn, tgt_nrm=tn, fixed=(fq, fm))
+    ref0 = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw), src_nrm=sn, tgt_nrm=tn)
+    assert abs(base.n_corr - ref0.n_corr) <= 3
+    assert abs(out.n_corr - ref.n_corr) <= 3 and ref.n_corr > ref0.n_corr
+    assert frob(out.T, ref.T) < (5e-4 if ns_mode else 1e-4)
+
+
+def test_fixed_correspondences_are_refused_where_the_reference_has_none(ctx):
+    ope = load_pkg()
+    src, tgt, fq, fm = _fixed_case()
+    cs, ct = ctx.upload(src), ctx.upload(tgt)
+    ix = ctx.build_index(ct)
+    with pytest.raises(ope.OpeError):
+        ctx.icp_set_fixed_correspondences(cs, ct, [len(src)], [0])          # index out of range
+    ctx.icp_set_fixed_correspondences(cs, ct, fq, fm)
+    with pytest.raises(ope.OpeError):
+        ctx.icp(cs, ix, ope.default_icp_params(use_reciprocal=1))
+    other = ctx.upload(src[:1000])
+    with pytest.raises(ope.OpeError):
+        ctx.icp(other, ix, ope.default_icp_params())                        # set for another source cloud
+    ctx.icp_set_fixed_correspondences(None, None)
+    assert ctx.icp(other, ix, ope.default_icp_params(max_iterations=2)).iterations == 2
