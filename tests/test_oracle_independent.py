@@ -365,3 +365,56 @@ def test_voxel_grid_colours_against_a_dictionary_of_voxels():
     got_xyz, got_rgb = oracle.voxel_grid(x, float(leaf), rgb)
     np.testing.assert_array_equal(got_xyz, np.array(want_xyz, np.float32))
     np.testing.assert_array_equal(got_rgb, np.array(want_rgb, np.uint32))
+
+
+# ------------------------------------------------------------------ fixed correspondences (icp_mod.h:268; icp_mod.hpp:150-151,210-224)
+def test_fixed_correspondences_against_a_numpy_loop():
+    """setFixedCorrespondences, written out in numpy from the reference's text and not from oracle/icp.c: per iteration the
+    list is [given pairs, distance = |t - s|^2 * 1e10] + [nearest-neighbour pairs]; with a surface-normal rejector the list is
+    filtered by n_s . n_t > threshold, then the given pairs that pass the same test are appended once more; Umeyama over the
+    list with multiplicities; MSE = mean of the distance fields.  Transform after four iterations, the pair count and the MSE
+    of the last iteration against the oracle, with and without the rejector."""
+    rng = np.random.default_rng(5)
+    P = synth.bumpy_torus(2500)
+    Q = (synth.bumpy_torus(2500, seed=12).astype(np.float64) @ synth.rot_xyz(2, -1, 3).T + [0.003, 0.001, -0.002]).astype(np.float32)
+    nP, nQ = normals_numpy(P, 12)[0].astype(np.float32), normals_numpy(Q, 12)[0].astype(np.float32)
+    fq = rng.choice(len(P), 25, replace=False).astype(np.int32)
+    fm = rng.choice(len(Q), 25, replace=False).astype(np.int32)
+    tree = cKDTree(Q.astype(np.float64))
+    Qd = Q.astype(np.float64)
+    for use_rej in (0, 1):
+        final = np.eye(4)
+        cloud, cn = P.astype(np.float64).copy(), nP.astype(np.float64).copy()
+        for _ in range(4):
+            d, j = tree.query(cloud)
+            lq = np.concatenate([fq, np.arange(len(P))])
+            lm = np.concatenate([fm, j])
+            ld = np.concatenate([((Qd[fm] - cloud[fq]) ** 2).sum(1) * 1e10, d ** 2])
+            if use_rej:
+                ok = (cn[lq] * nQ[lm].astype(np.float64)).sum(1) > 0.5
+                okf = (cn[fq] * nQ[fm].astype(np.float64)).sum(1) > 0.5
+                lq, lm, ld = (np.concatenate([lq[ok], fq[okf]]), np.concatenate([lm[ok], fm[okf]]),
+                              np.concatenate([ld[ok], (((Qd[fm] - cloud[fq]) ** 2).sum(1) * 1e10)[okf]]))
+            a, b = cloud[lq], Qd[lm]
+            ca, cb = a.mean(0), b.mean(0)
+            U, S, Vt = np.linalg.svd((b - cb).T @ (a - ca) / len(a))
+            D = np.eye(3)
+            if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+                D[2, 2] = -1
+            R = U @ D @ Vt
+            T = np.eye(4); T[:3, :3] = R; T[:3, 3] = cb - R @ ca
+            cloud = cloud @ R.T + T[:3, 3]
+            cn = cn @ R.T
+            final = T @ final
+            n_list = len(lq)
+            if _ < 3:   # (the iteration that reaches the maximum returns before the criteria look at the MSE: the reported one is the third's)
+                mse = float(ld.mean())
+        p = oracle.default_icp_params()
+        p.max_iterations = 4; p.transformation_epsilon = 0.0; p.euclidean_fitness_epsilon = 0.0; p.mse_threshold_absolute = -1.0
+        p.acc_mode = 1; p.transform_mode = 1
+        p.use_surface_normal_rej = use_rej; p.surface_normal_thr = 0.5
+        out = oracle.icp(P, Q, p, src_nrm=nP, tgt_nrm=nQ, fixed=(fq, fm))
+        assert abs(out.n_corr - n_list) <= 2, (use_rej, out.n_corr, n_list)      # a normal product within rounding of the threshold
+        assert np.abs(out.T.astype(np.float64) - final).max() < 2e-5
+        assert out.last_mse == pytest.approx(mse, rel=2e-3 if use_rej else 1e-4)
+        assert n_list > len(P) if not use_rej else True
