@@ -212,6 +212,8 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     // (round 3: letting a group-walked chunk report an estimate of its per-lane cost instead — the duration of one of its
     // slots over kOctSlotShare — did away with these launches and with a good schedule: steady state 172-186 us against
     // 152-157; a slot lasts 51-60 us whatever its chunk costs per lane.  Measured, not kept.)
+    // (round 3, later: plans every 4 or 2 launches between 8 and 32 from the costs at hand, with and without the measuring launch
+    // in front of plan 16 — the driver's window stayed at 176-180 us per step in every combination: measured, not kept)
     const bool measuring = !no_plan && nch > 1 && ((((nx & (nx - 1)) == 0 && nx <= plan_every) || nx % plan_every == 0 || nx == ctx->force_plan_at));
     ctx->measuring_flag = measuring;   // handed to the launch as a kernel argument (round 2 kept it in device memory: two memset dispatches per plan step on the critical path)
   }
