@@ -16,6 +16,8 @@
 // move the oracle's status off "parity unpinned" (DESIGN.md §2).  Modes:
 //   nn   IterativeClosestPoint<PointXYZ>: 1-NN correspondences + TransformationEstimationSVD — the bench's metric
 //        (icp_mod.hpp:119-272, correspondence_estimation_mod.hpp:127-213)
+//   nnfix  `nn` with eight given pairs injected through setFixedCorrespondences (icp_mod.h:268: pair i = source point i * ns / 8,
+//        model point i * nt / 8) — the reference's vendored classes and the facade have it, stock PCL does not
 //   ns   estimateFinePose's configuration (poseestimator.cpp:161-379): normals k = 30, IterativeClosestPointWithNormals with
 //        CorrespondenceEstimationNormalShooting(k = 20) + CorrespondenceRejectorSurfaceNormal(0.7) + SVD
 #include <chrono>
@@ -78,7 +80,7 @@ template <class Icp> static void disable_convergence_tests(Icp &icp, int iterati
   icp.getConvergeCriteria()->setAbsoluteMSE(-1.0);   // PCL's default 1e-12 would end a run that has settled
 }
 
-static int run_nn(const std::string &scene_path, const std::string &model_path, const Mat4 &guess, int iterations) {
+static int run_nn(const std::string &scene_path, const std::string &model_path, const Mat4 &guess, int iterations, bool fixed_pairs) {
   typedef pcl::PointXYZ P;
   pcl::PointCloud<P>::Ptr scene(new pcl::PointCloud<P>), model(new pcl::PointCloud<P>);
   if (pcl::io::loadPCDFile(scene_path, *scene) < 0 || pcl::io::loadPCDFile(model_path, *model) < 0) return 2;
@@ -86,11 +88,26 @@ static int run_nn(const std::string &scene_path, const std::string &model_path, 
   icp.setInputSource(scene);   // the scene is registered onto the model (BASELINE.json: 1 M scene points vs 100 k model points)
   icp.setInputTarget(model);
   disable_convergence_tests(icp, iterations);
+  pcl::Correspondences given;
+  if (fixed_pairs) {
+#if defined(OPE_FACADE) || defined(OPE_REF_VENDORED)
+    for (int i = 0; i < 8; ++i) {
+      pcl::Correspondence c;
+      c.index_query = (int)((size_t)i * scene->size() / 8);
+      c.index_match = (int)((size_t)i * model->size() / 8);
+      given.push_back(c);
+    }
+    icp.setFixedCorrespondences(&given);
+#else
+    std::fprintf(stderr, "mode nnfix needs the reference's vendored icp_mod.h (make pcl REF=...): stock PCL has no setFixedCorrespondences\n");
+    return 1;
+#endif
+  }
   pcl::PointCloud<P> out;
   const auto t0 = std::chrono::steady_clock::now();
   icp.align(out, guess);
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  print_line("nn", iterations, ms / iterations, icp.getFinalTransformation(), icp.getFitnessScore(), icp.hasConverged(), scene->size(), model->size());
+  print_line(fixed_pairs ? "nnfix" : "nn", iterations, ms / iterations, icp.getFinalTransformation(), icp.getFitnessScore(), icp.hasConverged(), scene->size(), model->size());
   return 0;
 }
 
@@ -144,14 +161,14 @@ static int run_ns(const std::string &scene_path, const std::string &model_path, 
 
 int main(int argc, char **argv) {
   if (argc < 5) {
-    std::fprintf(stderr, "usage: %s <scene.pcd> <model.pcd> <guess.txt: 16 numbers, row-major, or '-'> <iterations> [nn|ns]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <scene.pcd> <model.pcd> <guess.txt: 16 numbers, row-major, or '-'> <iterations> [nn|nnfix|ns]\n", argv[0]);
     return 1;
   }
   Mat4 guess = Mat4::Identity();
   if (std::strcmp(argv[3], "-") != 0 && !read_guess(argv[3], guess)) { std::fprintf(stderr, "cannot read the guess '%s'\n", argv[3]); return 1; }
   const int iterations = std::max(1, std::atoi(argv[4]));
   const std::string mode = argc > 5 ? argv[5] : "nn";
-  if (mode == "nn") return run_nn(argv[1], argv[2], guess, iterations);
+  if (mode == "nn" || mode == "nnfix") return run_nn(argv[1], argv[2], guess, iterations, mode == "nnfix");
   if (mode == "ns") return run_ns(argv[1], argv[2], guess, iterations);
   std::fprintf(stderr, "unknown mode '%s'\n", mode.c_str());
   return 1;

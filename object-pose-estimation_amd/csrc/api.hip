@@ -1298,7 +1298,8 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
     if (rc != OPE_OK) return rc;
     TraceRange r_red(ctx, "reduce");
     if (chained) {
-      launch_icp_update_chained(ctx->upd_stream, ctx->d_state, run_nsums(ctx), chain_ptr(ctx), ctx->chain_seq, (uint32_t)ctx->acc_blocks);
+      // (the ticket word counts up through the run: acc_blocks is the same for every launch of a run)
+      launch_icp_update_chained(ctx->upd_stream, ctx->d_state, run_nsums(ctx), chain_ptr(ctx), ctx->chain_seq, (ctx->chain_seq + 1u) * (uint32_t)ctx->acc_blocks);
       ++ctx->chain_seq;
       continue;
     }

@@ -49,10 +49,11 @@ __device__ __forceinline__ uint32_t chain_load(const uint32_t *p) { return __hip
 __device__ __forceinline__ void chain_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void chain_wait_own_memory_ops() { __builtin_amdgcn_s_waitcnt(0); }   // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's stores and atomics have been acknowledged
 // Head of an accumulate launch: in-line runs (chain == nullptr) early-out on the "done" flag; overlapped runs first wait for
-// update chain_seq - 1.  Returns false (for the whole block) if the launch has nothing to do.
-__device__ __forceinline__ bool acc_launch_begin(const IcpState *st, uint32_t *chain, uint32_t chain_seq) {
+// update chain_seq - 1 and then fetch the transform rows (s_const[0..11]) and "done" together, one round trip behind the word.
+// Returns false (for the whole block) if the launch has nothing to do.
+__device__ __forceinline__ bool acc_launch_begin(const IcpState *st, uint32_t *chain, uint32_t chain_seq, float *s_const) {
   if (chain == nullptr) return st->done == 0;
-  __shared__ uint32_t s_go[1];
+  __shared__ uint32_t s_go[2];
   if (threadIdx.x == 0) {
     uint32_t go = 1u;
     const unsigned long long t0 = wall_clock64();
@@ -60,11 +61,13 @@ __device__ __forceinline__ bool acc_launch_begin(const IcpState *st, uint32_t *c
       if (wall_clock64() - t0 > kChainTimeoutTicks) { go = 0u; atomicOr(chain + 2, 1u); break; }
       __builtin_amdgcn_s_sleep(2);
     }
-    if (go != 0u && __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) go = 0u;   // (issued after the word above has arrived)
-    *s_go = go;
+    s_go[0] = go;
   }
+  __syncthreads();   // (the loads below are issued after the word has arrived)
+  if (threadIdx.x < 12) s_const[threadIdx.x] = __hip_atomic_load(&st->Ff[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if (threadIdx.x == 12) s_go[1] = (uint32_t)__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  return *s_go != 0u;
+  return s_go[0] != 0u && s_go[1] == 0u;
 }
 // Tail of an accumulate launch: the block's sums are in (fp64 atomics) -> one ticket.
 __device__ __forceinline__ void acc_launch_end(uint32_t *chain) {
@@ -151,7 +154,10 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list,
     float *__restrict__ knn_rk, const uint32_t *__restrict__ plan_out, uint32_t measuring_launch, uint32_t *chain_arg, uint32_t chain_seq) {
   uint32_t *const chain = (MODE == 0 && !RECIP) ? chain_arg : nullptr;   // overlapped update launches exist for the plain 1-NN run only (api.hip)
-  if (!acc_launch_begin(st, chain, chain_seq)) return;
+  // Per-run constants live in LDS and are re-read where they are used (through a pointer the optimiser cannot see
+  // through): held in registers across the walk they were spilled to scratch, 13 dwords per lane and launch.
+  __shared__ __attribute__((aligned(16))) float s_const[16];   // F rows [0..11], pivot [12..14], best0 [15]
+  if (!acc_launch_begin(st, chain, chain_seq, s_const)) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
   __shared__ double s_red[BLOCK / 64][kNumSumsMax];
@@ -159,9 +165,6 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   float *stk = &s_stk[0][threadIdx.x];
   extern __shared__ unsigned char s_dyn[];  // MODE 1: k-NN lists
 
-  // Per-run constants live in LDS and are re-read where they are used (through a pointer the optimiser cannot see
-  // through): held in registers across the walk they were spilled to scratch, 13 dwords per lane and launch.
-  __shared__ __attribute__((aligned(16))) float s_const[16];   // F rows [0..11], pivot [12..14], best0 [15]
   const double max_d2 = st->max_d2;
   // With a finite setMaxCorrespondenceDistance the 1-NN search only has to see points that can survive the
   // threshold test (correspondence_estimation_mod.hpp:171 rejects d2 > max_d2 afterwards anyway): start from the
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     if ((double)f < max_d2) f = nextafterf(f, INFINITY);
     best0 = nextafterf(f, INFINITY);
   }
-  if (threadIdx.x < 12) s_const[threadIdx.x] = chain != nullptr ? __hip_atomic_load(&st->Ff[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st->Ff[threadIdx.x];   // (an overlapped update wrote it while this launch was already resident)
+  if (threadIdx.x < 12) { if (chain == nullptr) s_const[threadIdx.x] = st->Ff[threadIdx.x]; }   // (overlapped: fetched by acc_launch_begin)
   else if (threadIdx.x < 15) s_const[threadIdx.x] = (float)st->pivot[threadIdx.x - 12];
   else if (threadIdx.x == 15) s_const[15] = best0;
   __syncthreads();
@@ -527,12 +530,12 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     const uint32_t *__restrict__ qorder, unsigned char *__restrict__ qclass, const uint32_t *__restrict__ chunk_order,
     uint32_t *__restrict__ chunk_cost, const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, uint32_t measuring_launch,
     uint32_t *chain, uint32_t chain_seq) {
-  if (!acc_launch_begin(st, chain, chain_seq)) return;
+  __shared__ __attribute__((aligned(16))) float s_const[16];   // F rows [0..11], pivot [12..14], best0 [15]
+  if (!acc_launch_begin(st, chain, chain_seq, s_const)) return;
   constexpr int BLOCK = kAccBlock;
   __shared__ double s_red[BLOCK / 64][kNumSumsMax];
   __shared__ float s_stk[kMaxDepth + 1][BLOCK];
   float *stk = &s_stk[0][threadIdx.x];
-  __shared__ __attribute__((aligned(16))) float s_const[16];   // F rows [0..11], pivot [12..14], best0 [15]
   const double max_d2 = st->max_d2;
   float best0 = INFINITY;
   if (max_d2 < 3.0e38) {
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     if ((double)f < max_d2) f = nextafterf(f, INFINITY);
     best0 = nextafterf(f, INFINITY);
   }
-  if (threadIdx.x < 12) s_const[threadIdx.x] = chain != nullptr ? __hip_atomic_load(&st->Ff[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st->Ff[threadIdx.x];   // (an overlapped update wrote it while this launch was already resident)
+  if (threadIdx.x < 12) { if (chain == nullptr) s_const[threadIdx.x] = st->Ff[threadIdx.x]; }   // (overlapped: fetched by acc_launch_begin)
   else if (threadIdx.x < 15) s_const[threadIdx.x] = (float)st->pivot[threadIdx.x - 12];
   else if (threadIdx.x == 15) s_const[15] = best0;
   __syncthreads();
@@ -1135,13 +1138,13 @@ __global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, double *S,
 
 // The update launch of an overlapped run (see acc_launch_begin): on its own stream, resident while accumulate launch `seq`
 // still runs.  The state is fetched first (nothing writes it during an accumulate launch), then lane 0 waits for the
-// launch's `nblocks` tickets, the sums are read and consumed as in icp_update_kernel, the ticket word is left at zero and
-// the update is published (chain[1] = seq + 1) to the blocks of launch seq + 1, which are waiting or about to start.
+// launch's tickets (the word counts up through the run: `tickets` = blocks of every overlapped launch so far, this one
+// included), the sums are read and consumed as in icp_update_kernel and the update is published (chain[1] = seq + 1) to the blocks of launch seq + 1, which are waiting or about to start.
 // A run that is over ("done") had no tickets to wait for: the word is published all the same, so that the launches still
 // enqueued behind it drain.  192 VGPRs (it needs 96): the wave must fit into the block slot that api.hip leaves free on every
 // XCD beside an accumulate launch (two of its waves per SIMD).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(192))) void icp_update_chained_kernel(IcpState *st, int nsums, uint32_t *chain,
-                                                                                                uint32_t seq, uint32_t nblocks) {
+                                                                                                uint32_t seq, uint32_t tickets) {
   __shared__ double s_S[kNumSumsMax];
   __shared__ IcpState s_st;
   __shared__ uint32_t s_mode;   // 0: the run is over, 1: update, 2: the accumulate launch did not report in time
@@ -1152,7 +1155,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(192))) void icp_
     if (__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) mode = 0u;
     else {
       const unsigned long long t0 = wall_clock64();
-      while (chain_load(chain) < nblocks) {
+      while ((int32_t)(chain_load(chain) - tickets) < 0) {
         if (wall_clock64() - t0 > kChainTimeoutTicks) { mode = 2u; break; }
         __builtin_amdgcn_s_sleep(1);
       }
@@ -1184,11 +1187,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(192))) void icp_
   }
   chain_wait_own_memory_ops();
   __syncthreads();
-  if (t == 0) {
-    chain_store(chain, 0u);
-    chain_wait_own_memory_ops();
-    chain_store(chain + 1, seq + 1u);
-  }
+  if (t == 0) chain_store(chain + 1, seq + 1u);
 }
 
 // OPE_EST_POINT_TO_PLANE_LM: the Levenberg-Marquardt minimisation on the 91 sums of lm_stats_kernel (lm.hip, lm_solve.hpp)
@@ -1612,8 +1611,8 @@ void launch_icp_lm_update(hipStream_t stream, IcpState *st, double *S, double *s
   hipLaunchKernelGGL(icp_lm_update_kernel, dim3(1), dim3(64), 0, stream, st, S, stats);
 }
 
-void launch_icp_update_chained(hipStream_t stream, IcpState *st, int nsums, uint32_t *chain, uint32_t seq, uint32_t nblocks) {
-  hipLaunchKernelGGL(icp_update_chained_kernel, dim3(1), dim3(64), 0, stream, st, nsums, chain, seq, nblocks);
+void launch_icp_update_chained(hipStream_t stream, IcpState *st, int nsums, uint32_t *chain, uint32_t seq, uint32_t tickets) {
+  hipLaunchKernelGGL(icp_update_chained_kernel, dim3(1), dim3(64), 0, stream, st, nsums, chain, seq, tickets);
 }
 
 void launch_icp_update(hipStream_t stream, IcpState *st, double *S, int nsums, const float *Tk_ext) {

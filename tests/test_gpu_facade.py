@@ -49,7 +49,7 @@ def test_rigid_transform_svd_entry_point():
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["nn", "ns"])
+@pytest.mark.parametrize("mode", ["nn", "nnfix", "ns"])
 def test_pcl_ab_harness_facade_build_matches_the_oracle(tmp_path, mode):
     """bench/pcl_baseline.cpp — the LIVE A/B harness against the Point Cloud Library — in the one build this image can make
     (against the facade): same .pcd inputs and guess as a PCL build would read, fixed iterations, one JSON line; its transform
@@ -79,10 +79,14 @@ def test_pcl_ab_harness_facade_build_matches_the_oracle(tmp_path, mode):
     p = oracle.default_icp_params()
     p.max_iterations = K; p.transformation_epsilon = 0.0; p.euclidean_fitness_epsilon = 0.0; p.mse_threshold_absolute = -1.0
     p.acc_mode = 1; p.transform_mode = 1
-    if mode == "nn":
-        ref = oracle.icp(src, tgt, p, guess=guess)
+    if mode in ("nn", "nnfix"):
+        # nnfix: eight given pairs through the facade's setFixedCorrespondences (icp_mod.h:268), the same eight to the oracle
+        fixed = (np.arange(8) * len(src) // 8, np.arange(8) * len(tgt) // 8) if mode == "nnfix" else None
+        ref = oracle.icp(src, tgt, p, guess=guess, fixed=fixed)
         assert ref.iterations == K
         assert float(np.linalg.norm(T - ref.T.astype(np.float64))) < 1e-4
+        if fixed is not None:
+            assert float(np.linalg.norm(T - oracle.icp(src, tgt, p, guess=guess).T.astype(np.float64))) > 1e-4   # (they do move the result)
     else:
         ns_, nt_ = oracle.normals_knn(src, 30)[0], oracle.normals_knn(tgt, 30)[0]
         ok_s, ok_t = np.isfinite(ns_).all(1), np.isfinite(nt_).all(1)
