@@ -198,8 +198,11 @@ typedef struct {
    * ope_icp_iterate.  OPE_UPDATE_OVERLAPPED (0, default): on a stream of its own next to the accumulate launch it follows,
    * waiting on the device for that launch's blocks, while the next accumulate launch is already being dispatched and its
    * blocks wait for the update's word: one kernel boundary per iteration instead of two around a 64-thread launch.  Taken by
-   * plain 1-NN runs of one rank (not: normal shooting, reciprocal, deterministic_sums, the LM estimator, sharded runs, batches
-   * of one iteration), the others launch in line whatever this says.  Every device-side wait is bounded (2 s: OPE_EHIP).
+   * plain 1-NN runs of one rank (not: normal shooting, reciprocal, deterministic_sums, the LM estimator, fixed correspondences,
+   * sharded runs), the others launch in line whatever this says.  Every device-side wait is bounded (2 s); a run that hits
+   * the bound (the GPU's block slots held by other work, a tool that serialises dispatches) resumes in line at the next
+   * ope_icp_poll / ope_icp_end with nothing lost but the time, and the context stays in line from then on; a process under a
+   * counter-collecting profiler (rocprofv3 --pmc: ROCPROF_COUNTER_COLLECTION in the environment) launches in line from the start.
    * OPE_UPDATE_IN_LINE (1): accumulate -> update -> accumulate on the one stream, as in rounds 1-2 (a profiler that
    * serialises dispatches, e.g. rocprofv3 --pmc, wants this).  Same arithmetic either way. */
   int update_launch;

@@ -385,6 +385,10 @@ int ope_ctx_create(ope_ctx **out, int device_ordinal) {
     return set_err(nullptr, OPE_EHIP, "hipSetDevice/hipStreamCreate failed");
   }
   ctx->stream = ctx->own_stream;
+  // A profiler that collects hardware counters serialises dispatches (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION), and a
+  // serialised update launch would wait its 2 s for an accumulate launch that cannot start beside it: such processes launch their
+  // updates in line from the start.  The one environment variable the product library looks at.
+  if (const char *e = getenv("ROCPROF_COUNTER_COLLECTION"); e != nullptr && *e != 0 && *e != '0' && !dev_env("OPE_CHAIN_UNDER_COUNTERS")) ctx->chain_broken = true;
   if (hipMalloc(&ctx->d_state, sizeof(IcpState)) != hipSuccess ||
       hipMalloc(&ctx->d_partials, sizeof(double) * kNumSumsMax * kAccMaxBlocks) != hipSuccess ||
       hipMalloc((void **)&ctx->d_work_counter, 256) != hipSuccess ||
@@ -1434,8 +1438,27 @@ int ope_icp_poll(ope_ctx *ctx, ope_icp_result *result) {
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (result) fill_result(ctx, result);
   if (ctx->h_state->chain_error) {
+    // An overlapped update launch waited its 2 s for an accumulate launch that could not run beside it (the GPU's block slots
+    // held by other work, or a tool that serialises dispatches).  Nothing is lost but time: the update that gave up changed
+    // nothing but the two flags, every launch behind it found "done" and left the sums alone, and the state still holds the
+    // last completed iteration.  The iterations that did not happen are enqueued again, in line, and so are all later runs of
+    // this context.
     ctx->chain_broken = true;
-    return set_err(ctx, OPE_EHIP, "an overlapped update launch waited 2 s for its accumulate launch (GPU shared with other work, or serialised by a profiler?): the run was ended; later runs on this context launch their updates in line (ope_icp_params.update_launch = OPE_UPDATE_IN_LINE does so from the start)");
+    ctx->chained = false;
+    const int applied = ctx->h_state->iterations, lost = ctx->iters_enqueued - applied;
+    if (lost <= 0 || lost > ctx->iters_enqueued || ctx->chain_recovering)
+      return set_err(ctx, OPE_EHIP, "an overlapped update launch waited 2 s for its accumulate launch and the run could not be resumed in line (ope_icp_params.update_launch = OPE_UPDATE_IN_LINE avoids the overlapped launches from the start)");
+    ctx->chain_recovering = true;
+    unsigned char *st8 = reinterpret_cast<unsigned char *>(ctx->d_state);
+    hipError_t e = hipMemsetAsync(st8 + offsetof(IcpState, S), 0, sizeof(double) * kNumSumsMax, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(st8 + offsetof(IcpState, done), 0, sizeof(int), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(st8 + offsetof(IcpState, chain_error), 0, sizeof(int), ctx->stream);
+    int rc = e == hipSuccess ? OPE_OK : set_err(ctx, OPE_EHIP, std::string("ope_icp_poll: ") + hipGetErrorString(e));
+    ctx->iters_enqueued = applied;
+    if (rc == OPE_OK) rc = ope_icp_iterate(ctx, lost);
+    if (rc == OPE_OK) rc = ope_icp_poll(ctx, result);
+    ctx->chain_recovering = false;
+    return rc;
   }
   if (ctx->h_state->comm_error) {
     // the ranks' sequence numbers no longer agree and the slots hold the words of the aborted exchange: a later run could

@@ -168,7 +168,8 @@ struct ope_ctx {
   bool chain_on = false;         // the batch being enqueued does overlap
   bool chain_open = false;       // the update stream holds launches the launch stream has not waited for yet
   bool chain_u_synced = false;   // the update stream has waited for the launch stream since the state was last written there
-  bool chain_broken = false;     // a bounded wait ran out in an earlier run: later runs launch their updates in line
+  bool chain_broken = false;     // a bounded wait ran out in an earlier run (or a counter-collecting profiler is attached): runs launch their updates in line
+  bool chain_recovering = false; // ope_icp_poll is re-enqueueing, in line, the iterations an overlapped run lost to a bounded wait
   uint32_t chain_seq = 0;        // overlapped accumulate launches of this run so far (= updates published once they are done)
   int64_t kernel_launches[OPE_KERNEL_KINDS] = {0, 0, 0, 0};   // per search kernel, this run (ope_icp_kernel_launches)
   uint32_t *d_hint = nullptr;       // per sorted query: leaf (heap id) of the previous iteration's match, 0 = none
