@@ -64,7 +64,8 @@ constexpr float kHeavyLoadFactor = 1.5f;   // launches that fill the GPU: group 
 constexpr float kHeavyMaxChunksPerWave = 1.8f;   // beyond this the launch is throughput-bound: no 8-lane group walks
 
 // Developer A/B switches and sweeps (tools/*.py) read the environment only in builds made with -DOPE_DEVELOPER
-// (`make DEVELOPER=1`); the product library has no environment-dependent behaviour on its launch path.
+// (`make DEVELOPER=1`); the product library's launch path depends on one environment variable only (ROCPROF_COUNTER_COLLECTION,
+// ope_ctx_create: a counter-collecting profiler serialises dispatches, so updates are launched in line).
 #ifdef OPE_DEVELOPER
 static const char *dev_env(const char *name) { return getenv(name); }
 #else
@@ -457,6 +458,7 @@ int ope_ctx_set_stream(ope_ctx *ctx, void *hip_stream) {
 int ope_ctx_sync(ope_ctx *ctx) {
   if (!ctx) return OPE_EINVAL;
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->chain_open) OPE_HIP(ctx, hipStreamSynchronize(ctx->upd_stream));   // the last overlapped update ends a few microseconds after the last accumulate launch
   return OPE_OK;
 }
 
