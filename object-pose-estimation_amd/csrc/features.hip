@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "bvh_traverse.hpp"
+#include "libm_f32.hpp"
 
 namespace ope {
 
@@ -203,7 +204,7 @@ __device__ __forceinline__ bool pair_features(float p1x, float p1y, float p1z, f
   float ax = n1x, ay = n1y, az = n1z, bx = n2x, by = n2y, bz = n2z;
   const float angle1 = (ax * dx + ay * dy + az * dz) / f4;
   const float angle2 = (bx * dx + by * dy + bz * dz) / f4;
-  if (acosf(fabsf(angle1)) > acosf(fabsf(angle2))) {
+  if (lmf_acosf(fabsf(angle1)) > lmf_acosf(fabsf(angle2))) {   // (libm_f32.hpp: the same bits as the C library of the CPU path)
     ax = n2x; ay = n2y; az = n2z;
     bx = n1x; by = n1y; bz = n1z;
     dx *= -1.f; dy *= -1.f; dz *= -1.f;
@@ -217,7 +218,7 @@ __device__ __forceinline__ bool pair_features(float p1x, float p1y, float p1z, f
   vx /= vn; vy /= vn; vz /= vn;
   const float wx = ay * vz - az * vy, wy = az * vx - ax * vz, wz = ax * vy - ay * vx;
   f2 = vx * bx + vy * by + vz * bz;
-  f1 = atan2f(wx * bx + wy * by + wz * bz, ax * bx + ay * by + az * bz);
+  f1 = lmf_atan2f(wx * bx + wy * by + wz * bz, ax * bx + ay * by + az * bz);
   return true;
 }
 

@@ -1,0 +1,147 @@
+// libm_f32.hpp — atanf / atan2f / acosf in float with bits that do not depend on the machine: the fdlibm float algorithms
+// (Sun Microsystems' freely distributable routines, as glibc's flt-32 directory carries them) written out in IEEE float operations
+// in a fixed order (this translation unit is compiled with -ffp-contract=off; divisions and square roots are the correctly rounded
+// ones).  pcl::computePairFeatures takes acos / atan2 of floats (uPCL features/src/pfh.cpp); with the device math library's own
+// atan2f a few results per million round differently from glibc's, which is enough to move a pair feature across an FPFH bin
+// edge (round 2: up to 10 % of the FPFH rows of a 50 k-key-point frame differed from the CPU path by whole bin flips).
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+namespace ope {
+__device__ __forceinline__ uint32_t lmf_bits(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float lmf_from(uint32_t u) { return __uint_as_float(u); }
+
+__device__ __forceinline__ float lmf_atanf(float x) {
+  const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+  const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+  const float aT[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                               6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+  const float one = 1.0f, huge = 1.0e30f;
+  float w, s1, s2, z;
+  int32_t ix, hx, id;
+  hx = (int32_t)lmf_bits(x);
+  ix = hx & 0x7fffffff;
+  if (ix >= 0x4c000000) { /* |x| >= 2^25 */
+    if (ix > 0x7f800000) return x + x; /* NaN */
+    if (hx > 0) return atanhi[3] + atanlo[3];
+    else return -atanhi[3] - atanlo[3];
+  }
+  if (ix < 0x3ee00000) {    /* |x| < 0.4375 */
+    if (ix < 0x31000000) {  /* |x| < 2^-29 */
+      if (huge + x > one) return x;
+    }
+    id = -1;
+  } else {
+    x = lmf_from((uint32_t)ix);   /* fabsf */
+    if (ix < 0x3f980000) {        /* |x| < 1.1875 */
+      if (ix < 0x3f300000) { id = 0; x = __fdiv_rn((float)2.0 * x - one, (float)2.0 + x); }
+      else { id = 1; x = __fdiv_rn(x - one, x + one); }
+    } else {
+      if (ix < 0x401c0000) { id = 2; x = __fdiv_rn(x - (float)1.5, one + (float)1.5 * x); }
+      else { id = 3; x = __fdiv_rn(-(float)1.0, x); }
+    }
+  }
+  z = x * x;
+  w = z * z;
+  s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+  s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+  if (id < 0) return x - x * (s1 + s2);
+  const float hi = id == 0 ? atanhi[0] : id == 1 ? atanhi[1] : id == 2 ? atanhi[2] : atanhi[3];   // (selects, not an indexed local array)
+  const float lo = id == 0 ? atanlo[0] : id == 1 ? atanlo[1] : id == 2 ? atanlo[2] : atanlo[3];
+  z = hi - ((x * (s1 + s2) - lo) - x);
+  return (hx < 0) ? -z : z;
+}
+
+__device__ __forceinline__ float lmf_atan2f(float y, float x) {
+  const float tiny = 1.0e-30f, zero = 0.0f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  float z;
+  int32_t k, m, hx, hy, ix, iy;
+  hx = (int32_t)lmf_bits(x); ix = hx & 0x7fffffff;
+  hy = (int32_t)lmf_bits(y); iy = hy & 0x7fffffff;
+  if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;   /* NaN */
+  if (hx == 0x3f800000) return lmf_atanf(y);              /* x = 1.0 */
+  m = ((hy >> 31) & 1) | ((hx >> 30) & 2);                /* 2*sign(x) + sign(y) */
+  if (iy == 0) {
+    switch (m) {
+      case 0: case 1: return y;
+      case 2: return pi + tiny;
+      case 3: return -pi - tiny;
+    }
+  }
+  if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  if (ix == 0x7f800000) {
+    if (iy == 0x7f800000) {
+      switch (m) {
+        case 0: return pi_o_4 + tiny;
+        case 1: return -pi_o_4 - tiny;
+        case 2: return (float)3.0 * pi_o_4 + tiny;
+        case 3: return (float)-3.0 * pi_o_4 - tiny;
+      }
+    } else {
+      switch (m) {
+        case 0: return zero;
+        case 1: return -zero;
+        case 2: return pi + tiny;
+        case 3: return -pi - tiny;
+      }
+    }
+  }
+  if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  k = (iy - ix) >> 23;
+  if (k > 60) z = pi_o_2 + (float)0.5 * pi_lo;       /* |y/x| > 2^60 */
+  else if (hx < 0 && k < -60) z = 0.0f;              /* |y|/x < -2^60 */
+  else { float q = __fdiv_rn(y, x); z = lmf_atanf(lmf_from(lmf_bits(q) & 0x7fffffffu)); }
+  switch (m) {
+    case 0: return z;
+    case 1: return lmf_from(lmf_bits(z) ^ 0x80000000u);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+  }
+}
+
+__device__ __forceinline__ float lmf_sqrtf(float x) { return __fsqrt_rn(x); }   // IEEE square root
+
+__device__ __forceinline__ float lmf_acosf(float x) {
+  const float one = 1.0f, pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+  const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f, pS4 = 7.9153501429e-04f,
+              pS5 = 3.4793309169e-05f, qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+  float z, p, q, r, w, s, c, df;
+  int32_t hx, ix;
+  hx = (int32_t)lmf_bits(x);
+  ix = hx & 0x7fffffff;
+  if (ix == 0x3f800000) {            /* |x| == 1 */
+    if (hx > 0) return 0.0f;
+    else return pi + (float)2.0 * pio2_lo;
+  } else if (ix > 0x3f800000) {
+    return __fdiv_rn(x - x, x - x);   /* NaN */
+  }
+  if (ix < 0x3f000000) {             /* |x| < 0.5 */
+    if (ix <= 0x23000000) return pio2_hi + pio2_lo;   /* |x| < 2^-57 */
+    z = x * x;
+    p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    r = __fdiv_rn(p, q);
+    return pio2_hi - (x - (pio2_lo - x * r));
+  } else if (hx < 0) {               /* x < -0.5 */
+    z = (one + x) * (float)0.5;
+    p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    s = lmf_sqrtf(z);
+    r = __fdiv_rn(p, q);
+    w = r * s - pio2_lo;
+    return pi - (float)2.0 * (s + w);
+  } else {                           /* x > 0.5 */
+    z = (one - x) * (float)0.5;
+    s = lmf_sqrtf(z);
+    df = lmf_from(lmf_bits(s) & 0xfffff000u);
+    c = __fdiv_rn(z - df * df, s + df);
+    p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    r = __fdiv_rn(p, q);
+    w = r * s + c;
+    return (float)2.0 * (df + w);
+  }
+}
+
+}  // namespace ope

@@ -11,6 +11,7 @@
  *   pcl::UniformSampling::compute               :141-145  (uniform_sampling.hpp, PCL<=1.7 keypoints API)
  *   pcl::SampleConsensusInitialAlignment::align :50-64    (ia_ransac.hpp)
  */
+#include "libm_f32.h"
 #include "ope_oracle.h"
 
 #include <float.h>
@@ -149,7 +150,7 @@ int orc_pair_features(const float p1[3], const float n1[3], const float p2[3], c
   float a[3] = {n1[0], n1[1], n1[2]}, b[3] = {n2[0], n2[1], n2[2]};
   float angle1 = (a[0] * dp[0] + a[1] * dp[1] + a[2] * dp[2]) / *f4;
   float angle2 = (b[0] * dp[0] + b[1] * dp[1] + b[2] * dp[2]) / *f4;
-  if (acosf(fabsf(angle1)) > acosf(fabsf(angle2))) {
+  if (lmf_acosf(fabsf(angle1)) > lmf_acosf(fabsf(angle2))) {   /* (libm_f32.h: glibc's bits, on any machine) */
     for (int d = 0; d < 3; ++d) { a[d] = n2[d]; b[d] = n1[d]; dp[d] *= -1.f; }
     *f3 = -angle2;
   } else
@@ -162,7 +163,7 @@ int orc_pair_features(const float p1[3], const float n1[3], const float p2[3], c
   float w[3];
   cross3f(a, v, w);
   *f2 = v[0] * b[0] + v[1] * b[1] + v[2] * b[2];
-  *f1 = atan2f(w[0] * b[0] + w[1] * b[1] + w[2] * b[2], a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
+  *f1 = lmf_atan2f(w[0] * b[0] + w[1] * b[1] + w[2] * b[2], a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
   return 1;
 }
 

@@ -67,17 +67,15 @@ def test_c3_uniform_sampling_of_the_frame_bit_exact(c3):
 
 
 def _fpfh_compare(out, ref, m_mean):
-    """FPFH rows against the oracle's.  A pair feature that lands within rounding of a bin edge may fall on the other side
-    (libm of the device vs glibc): that moves 100/(m-1) between two adjacent bins of one SPFH row, and a fraction of it
-    into the rows of the neighbours.  Rows are therefore either equal to ~1e-3 of 300 or differ by whole
-    flips; both populations are bounded."""
+    """FPFH rows against the oracle's.  Rounds 1-2 had to allow whole bin flips in up to 10 % of the rows: a pair feature within
+    rounding of a bin edge fell on the other side because the device's atan2f / acosf and glibc's round a few results per
+    million differently.  Both sides now compute those two functions with the same float operations (csrc/libm_f32.hpp,
+    oracle/libm_f32.h = glibc's bits), and every row agrees to the order of the float additions: L1 < 1e-3 of 300, the bound
+    SURVEY section 7 asked for, on every row (8e-5 at most on the C3 frame's 49.6 k key points)."""
     l1 = np.abs(out.astype(np.float64) - ref.astype(np.float64)).sum(1)
-    clean = l1 < 1e-2
-    flip_unit = 2.0 * 100.0 / max(m_mean - 1.0, 1.0)      # one flip in the point's own SPFH row, L1
-    assert np.median(l1) < 2e-3
-    assert clean.mean() > 0.90, clean.mean()
-    assert l1.max() < 6.0 * flip_unit, (l1.max(), flip_unit)   # a handful of flips at most in any one neighbourhood
-    return clean.mean(), l1.max()
+    assert np.median(l1) < 2e-4
+    assert l1.max() < 1e-3, l1.max()
+    return 1.0, l1.max()
 
 
 def test_c3_normals_and_fpfh_on_all_frame_keypoints(c3):

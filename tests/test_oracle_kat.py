@@ -466,3 +466,38 @@ def test_voxel_grid_known_answers():
     # PCL refuses leaves whose voxel index would overflow 32 bits and hands back its input
     assert oracle.voxel_grid(z, 1e-5) is None
     assert len(oracle.voxel_grid(np.full((4, 3), np.nan, np.float32), 0.1)) == 0
+
+
+def test_libm_f32_restatement_returns_the_c_librarys_bits(tmp_path):
+    """oracle/libm_f32.h (and its device twin csrc/libm_f32.hpp) restate atanf / atan2f / acosf so that CPU and GPU agree bit
+    for bit; the restatement is the C library's own algorithm: on this box every result equals libm's, so the oracle computes
+    what it computed with libm (2e6 atan2f arguments over both quadrant pairs and small operands, every 97th float of [-1, 1]
+    for acosf)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text(r'''
+#include <math.h>
+#include <stdio.h>
+#include "libm_f32.h"
+int main(void) {
+  unsigned long long s = 88172645463325252ull; long bad = 0;
+  for (long i = 0; i < 2000000; ++i) {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17; float a = (float)((double)(s & 0xffffff) / 8388608.0 - 1.0);
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17; float b = (float)((double)(s & 0xffffff) / 8388608.0 - 1.0);
+    if (i % 3 == 0) a *= 1e-3f; else if (i % 7 == 0) b *= 1e-4f;
+    if (lmf_bits(atan2f(a, b)) != lmf_bits(lmf_atan2f(a, b))) ++bad;
+    if (lmf_bits(atanf(8.0f * a)) != lmf_bits(lmf_atanf(8.0f * a))) ++bad;
+  }
+  for (uint32_t u = 0; u <= 0x3f800000u; u += 97) {
+    float x = lmf_from(u);
+    if (lmf_bits(acosf(x)) != lmf_bits(lmf_acosf(x)) || lmf_bits(acosf(-x)) != lmf_bits(lmf_acosf(-x))) ++bad;
+  }
+  printf("%ld\n", bad);
+  return 0;
+}
+''')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(root, "oracle"), str(src), "-o", str(exe), "-lm"])
+    assert int(subprocess.check_output([str(exe)]).decode().strip()) == 0
