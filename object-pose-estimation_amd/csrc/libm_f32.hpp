@@ -144,4 +144,20 @@ __device__ __forceinline__ float lmf_acosf(float x) {
   }
 }
 
+// cos and sin of an angle in [0, pi/3] — all eigen33 asks for (theta = atan2(...) / 3): the Taylor series in double (terms to
+// x^22 / x^23: below 1e-21 at pi/3), rounded to float once.  IEEE double operations in a fixed order: the same bits anywhere.
+ // (The C library's cosf / sinf of this box are a different, equally valid rounding of the same values in a few arguments per
+ // thousand; PCL's Scalar = float eigen33 gets whatever its platform's libm returns.)
+__device__ __forceinline__ void lmf_cos_sin_small(float xf, float *c, float *s) {
+  const double x = (double)xf, z = x * x;
+  const double pc = 1.0 + z * (-1.0 / 2.0 + z * (1.0 / 24.0 + z * (-1.0 / 720.0 + z * (1.0 / 40320.0 + z * (-1.0 / 3628800.0 + z * (1.0 / 479001600.0 +
+                    z * (-1.0 / 87178291200.0 + z * (1.0 / 20922789888000.0 + z * (-1.0 / 6402373705728000.0 + z * (1.0 / 2432902008176640000.0 +
+                    z * (-1.0 / 1124000727777607680000.0)))))))))));
+  const double ps = 1.0 + z * (-1.0 / 6.0 + z * (1.0 / 120.0 + z * (-1.0 / 5040.0 + z * (1.0 / 362880.0 + z * (-1.0 / 39916800.0 + z * (1.0 / 6227020800.0 +
+                    z * (-1.0 / 1307674368000.0 + z * (1.0 / 355687428096000.0 + z * (-1.0 / 121645100408832000.0 + z * (1.0 / 51090942171709440000.0 +
+                    z * (-1.0 / 25852016738884976640000.0)))))))))));
+  *c = (float)pc;
+  *s = (float)(x * ps);
+}
+
 }  // namespace ope

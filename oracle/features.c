@@ -48,8 +48,9 @@ static void compute_roots(const float m[9], float roots[3]) {
   float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
   if (q > 0.f) q = 0.f;
   float rho = sqrtf(-a_over_3);
-  float theta = atan2f(sqrtf(-q), half_b) * s_inv3;
-  float cos_theta = cosf(theta), sin_theta = sinf(theta);
+  float theta = lmf_atan2f(sqrtf(-q), half_b) * s_inv3;   /* libm_f32.h: the same bits on the CPU and on the GPU */
+  float cos_theta, sin_theta;
+  lmf_cos_sin_small(theta, &cos_theta, &sin_theta);
   roots[0] = c2_over_3 + 2.f * rho * cos_theta;
   roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
   roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);

@@ -119,6 +119,8 @@ def _check(frames, model, scenes, seed, tol_coarse=2e-5, tol=1e-4, band=3e-2, se
         if k == 0:
             T, fit, strength, src, info = pe.estimate_final_pose(src, scene)
             assert fr["coarse_calls"] == info["coarse_calls"]
+            print(f"[end to end, frame 0] |final - oracle| = {_frob(fr['final'], T):.3e}  |fine - oracle| = {_frob(fr['fine'], info['fine']):.3e}  "
+                  f"|coarse - oracle| = {_frob(fr['coarse'], info['coarse']) if 'coarse' in info else float('nan'):.3e}")
             assert _frob(fr["final"], T) < band and _frob(fr["fine"], info["fine"]) < band
             assert fr["fitness"] == pytest.approx(fit, rel=0.15) and fr["strength"] == pytest.approx(strength, abs=0.03)
         aligned_dev = _transform_f32(fr["fine"], aligned_dev)         # :358-360
