@@ -278,8 +278,12 @@ __global__ __launch_bounds__(kFeatBlock) void spfh_kernel(CloudView q, BvhView t
       float *row = spfh + (size_t)v.self_pos * kSpfhStride;
 #pragma unroll
       for (int b = 0; b < 33; ++b) {
+        // PCL adds hist_incr to the bin once per pair, in float (fpfh.hpp computePointSPFHSignature): c additions of the same
+        // value, whatever their order — not c * hist_incr rounded once
         const uint32_t c = hist[b * kFeatBlock];
-        row[b] = c ? (float)c * hist_incr : 0.f;
+        float h = 0.f;
+        for (uint32_t a = 0; a < c; ++a) h = __fadd_rn(h, hist_incr);
+        row[b] = h;
       }
       row[33] = row[34] = row[35] = 0.f;
     }
