@@ -231,7 +231,8 @@ void ope_icp_default_params(ope_icp_params *p);
  * 134-162); normal shooting lists none (…normal_shooting_weighted.hpp:81-101); listed pairs pass the rejectors like any
  * other; then the FIRST rejector alone is applied to the given pairs and the survivors are appended, a second time for those
  * already listed (icp_mod.hpp:210-224; only when a rejector is installed).  SVD estimator only; not with reciprocal
- * correspondences; sharded runs add them on rank 0.  ope_icp_correspondences lists the searched pairs only.  Runs with fixed
+ * correspondences; in a sharded run set them on exactly ONE rank (indices into that rank's shard): every rank that holds
+ * pairs adds them to the sums that are then summed over the ranks.  ope_icp_correspondences lists the searched pairs only.  Runs with fixed
  * correspondences launch their update in line. */
 int ope_icp_set_fixed_correspondences(ope_ctx *ctx, const ope_cloud *src, const ope_cloud *tgt_cloud, const int32_t *index_query,
                                       const int32_t *index_match, size_t n);

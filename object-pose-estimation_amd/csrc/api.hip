@@ -1224,9 +1224,10 @@ int ope_icp_set_fixed_correspondences(ope_ctx *ctx, const ope_cloud *src, const 
   return OPE_OK;
 }
 
-// the given pairs' share of the sums, after an accumulate launch (rank 0 of a sharded run: they are added once)
+// the given pairs' share of the sums, after an accumulate launch (sharded runs: the caller sets them on exactly one rank, with
+// indices into that rank's shard, so that they are added once)
 static void enqueue_fixed_pairs(ope_ctx *ctx) {
-  if (ctx->n_fixed_run == 0 || ctx->comm_rank != 0) return;
+  if (ctx->n_fixed_run == 0) return;
   launch_icp_fixed_pairs(ctx->stream, ctx->d_state, ctx->d_fixed, (uint32_t)ctx->n_fixed_run, sums_ptr(ctx));
 }
 
