@@ -176,6 +176,9 @@ void orc_fpfh(const float *xyz, const float *nrm, int n, float radius, float *ou
   int64_t total = orc_kdtree_radius(tree, xyz, n, radius, 0, offs, NULL, NULL, 0);
   int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));
   float *d2 = (float *)malloc(sizeof(float) * (size_t)(total > 0 ? total : 1));
+  /* UNSORTED neighbour lists: the reference sets no search method on its FPFHEstimation (poseestimator.cpp:121-125), so
+   * Feature::initCompute makes a pcl::search::KdTree(sorted = false) [uPCL-recall] and pass 2 adds the weighted rows in the
+   * kd-tree's own order */
   orc_kdtree_radius(tree, xyz, n, radius, 0, offs, idx, d2, total);
   float *spfh = (float *)calloc((size_t)n * 33, sizeof(float));
   const float d_pi = 1.0f / (2.0f * (float)M_PI);
