@@ -20,6 +20,7 @@
 //        model point i * nt / 8) — the reference's vendored classes and the facade have it, stock PCL does not
 //   ns   estimateFinePose's configuration (poseestimator.cpp:161-379): normals k = 30, IterativeClosestPointWithNormals with
 //        CorrespondenceEstimationNormalShooting(k = 20) + CorrespondenceRejectorSurfaceNormal(0.7) + SVD
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
