@@ -396,7 +396,8 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
   template <class TE> void setTransformationEstimation(const std::shared_ptr<TE> &) { params_.estimator = TE::ope_estimator; }
   std::shared_ptr<registration::DefaultConvergenceCriteria> getConvergeCriteria() { return criteria_; }
   // vPCL icp_mod.h:268-281 — the reference's injection of given pairs into every iteration (unused by its own programs).
-  // The pointer is kept, as in the reference; the pairs are read at align().
+  // The pointer is kept, as in the reference; the pairs are read at align().  (The reference's correspondence estimation also
+  // writes each pair's `distance` field back through the pointer, every iteration; the façade leaves the caller's list untouched.)
   void setFixedCorrespondences(Correspondences *correspondences) { corres_fixed_ = correspondences; }
   Correspondences getFixedCorrespondences() { return *corres_fixed_; }
   void clearCorrespondences() { if (corres_fixed_) corres_fixed_->clear(); }
