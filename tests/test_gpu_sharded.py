@@ -127,7 +127,7 @@ def test_four_ranks_on_one_gpu_at_full_c4_size_match_the_single_rank(tmp_path):
         mp.spawn(_worker, args=(world, _free_port(), ns, nt, max_it, str(tmp_path)), nprocs=world, join=True)
     T1 = np.load(tmp_path / "T_w1.npy"); T4 = np.load(tmp_path / "T_w4.npy")
     m1 = np.load(tmp_path / "meta_w1.npy"); m4 = np.load(tmp_path / "meta_w4.npy")
-    assert np.linalg.norm(T1.astype(np.float64) - T4.astype(np.float64)) < 5e-6
+    assert np.linalg.norm(T1.astype(np.float64) - T4.astype(np.float64)) < 2e-5      # (0.8e-6 to 5.1e-6 seen: see the docstring)
     assert m1[0] == m4[0] == max_it and m1[1] == m4[1] == ns
     assert m4[3] == pytest.approx(ns / (ns + nt))
 
@@ -316,7 +316,9 @@ def test_peer_to_peer_slots_carry_the_sums_between_ranks_on_one_gpu(tmp_path, wo
     ctx.close()
     assert meta[0] == ref.iterations and meta[1] == ref.n_corr and meta[2] == ref.state
     assert meta[3] == pytest.approx(ns / (ns + nt))
-    assert np.linalg.norm(T.astype(np.float64) - ref.T.astype(np.float64)) < 5e-6
+    # (the grouping of the fp64 additions differs between one rank and four: a last-bit difference of a sum, rounded into the float
+    # increment and amplified by twelve iterations of the fast early phase — 0.8e-6 to 5.1e-6 seen over the rounds; north_star's bound is 1e-4)
+    assert np.linalg.norm(T.astype(np.float64) - ref.T.astype(np.float64)) < 2e-5
     print(f"peer-to-peer, {world} ranks on one GPU, {ns} x {nt}: {meta[4] * 1e6:.0f} us per iteration")
 
 
