@@ -48,7 +48,7 @@ void launch_icp_lm_update(hipStream_t, IcpState *, double *, double *);
 void launch_lm_pos_to_orig(hipStream_t, const BvhView &, int32_t *, uint32_t);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
 void launch_knn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int, int32_t *, float *);
-void launch_fitness(hipStream_t, int, const CloudView &, const BvhView &, const float *, double, double *);
+void launch_fitness(hipStream_t, int, const CloudView &, const BvhView &, const float *, double, double *, const uint32_t *);
 void launch_pairs_svd(hipStream_t, const float *, const float *, uint32_t, double *, int, float *);
 // comm.cpp
 int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count);
@@ -1582,7 +1582,9 @@ int ope_fitness(ope_ctx *ctx, const ope_cloud *src, const ope_index *tgt, const 
   float *d_T = static_cast<float *>(ctx->d_scratch);
   double *d_part = reinterpret_cast<double *>(static_cast<unsigned char *>(ctx->d_scratch) + 256);
   OPE_HIP(ctx, h2d_copy(ctx->stream, d_T, rows, sizeof rows));
-  launch_fitness(ctx->stream, nblocks, src->view(), tgt->view(), d_T, max_range, d_part);
+  // getFitnessScore right after align (poseestimator.cpp:354-356): the run's start leaves are still there for this very pair
+  const uint32_t *hint = (ctx->run_src == src && ctx->run_tgt == tgt && ctx->d_hint && ctx->corr_cap >= src->n && !ctx->run_active) ? ctx->d_hint : nullptr;
+  launch_fitness(ctx->stream, nblocks, src->view(), tgt->view(), d_T, max_range, d_part, hint);
   std::vector<double> hp(2 * (size_t)nblocks);
   OPE_HIP(ctx, hipMemcpyAsync(hp.data(), d_part, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, ctx->stream));
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));

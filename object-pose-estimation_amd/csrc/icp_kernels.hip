@@ -1478,8 +1478,10 @@ __global__ __launch_bounds__(kKnnBlock) void knn_search_kernel(CloudView q, BvhV
 }
 
 // Registration::getFitnessScore: partial sums {Σ d2 (d2 <= max_range), count} per block.
+// hint (optional): per query the leaf that held its match in the ICP run that has just ended over the same pair — the walk
+// starts there, as the run's own walks did (a start leaf never changes what a walk finds)
 __global__ __launch_bounds__(256) void fitness_kernel(CloudView q, BvhView tgt, const float *__restrict__ T,
-                                                       double max_range, double *__restrict__ partials) {
+                                                       double max_range, double *__restrict__ partials, const uint32_t *__restrict__ hint) {
   __shared__ double s_red[4][2];
   __shared__ float s_stk[kMaxDepth + 1][256];
   float *stk = &s_stk[0][threadIdx.x];
@@ -1496,7 +1498,7 @@ __global__ __launch_bounds__(256) void fitness_kernel(CloudView q, BvhView tgt, 
     const float y = xform_row(F + 4, s.x, s.y, s.z);
     const float z = xform_row(F + 8, s.x, s.y, s.z);
     NearestVisitor v{active ? INFINITY : -INFINITY, kNoPos, 0};
-    if (active) bvh_traverse(tgt, x, y, z, v, stk, 256);
+    if (active) bvh_traverse(tgt, x, y, z, v, stk, 256, hint ? hint[i] : 0u);
     if (active && v.pos != kNoPos && (double)v.best <= max_range) { sum += (double)v.best; cnt += 1.0; }
   }
   sum = wave_sum(sum);
@@ -1635,8 +1637,8 @@ void launch_knn_search(hipStream_t stream, const CloudView &q, const BvhView &tg
 }
 
 void launch_fitness(hipStream_t stream, int nblocks, const CloudView &q, const BvhView &tgt, const float *d_T,
-                    double max_range, double *partials) {
-  hipLaunchKernelGGL(fitness_kernel, dim3(nblocks), dim3(256), 0, stream, q, tgt, d_T, max_range, partials);
+                    double max_range, double *partials, const uint32_t *hint) {
+  hipLaunchKernelGGL(fitness_kernel, dim3(nblocks), dim3(256), 0, stream, q, tgt, d_T, max_range, partials, hint);
 }
 
 }  // namespace ope
