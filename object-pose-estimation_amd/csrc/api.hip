@@ -49,6 +49,7 @@ void launch_lm_pos_to_orig(hipStream_t, const BvhView &, int32_t *, uint32_t);
 void launch_nn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int32_t *, float *);
 void launch_knn_search(hipStream_t, const CloudView &, const BvhView &, const float *, int, int32_t *, float *);
 void launch_fitness(hipStream_t, int, const CloudView &, const BvhView &, const float *, double, double *, const uint32_t *);
+void launch_seed_hints(hipStream_t, const CloudView &, const BvhView &, const IcpState *, uint32_t *);
 void launch_pairs_svd(hipStream_t, const float *, const float *, uint32_t, double *, int, float *);
 // comm.cpp
 int comm_allreduce_sums(ope_ctx *ctx, double *d_sums, int count);
@@ -1101,6 +1102,9 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     if (rc != OPE_OK) return rc;
   }
   OPE_HIP(ctx, hipMemcpyAsync(ctx->d_state, h, sizeof *h, hipMemcpyHostToDevice, ctx->stream));
+  // k-NN runs of more than one pass: start leaves for the first launch (icp_kernels.hip: seed_hints_kernel)
+  if (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && p.max_iterations > 1 && src->n_valid > 0 && !dev_env("OPE_NO_SEED"))
+    launch_seed_hints(ctx->stream, src->view(), tgt->view(), ctx->d_state, ctx->d_hint);
   if (ctx->d_sums_ext)
     OPE_HIP(ctx, hipMemsetAsync(ctx->d_sums_ext, 0, sizeof(double) * (p.estimator == OPE_EST_POINT_TO_PLANE_LLS ? kNumSumsMax : kNumSums), ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter, 0, 256, ctx->stream));

@@ -1636,6 +1636,30 @@ void launch_knn_search(hipStream_t stream, const CloudView &q, const BvhView &tg
                      d_T ? 1 : 0, k, out_idx, out_d2);
 }
 
+// Start leaves for the FIRST launch of a k-NN run (normal shooting): a k-NN walk from the root has no bound until its list is full
+// and opens far more of the tree than it needs (the first launch of a BuildModel pair took 1.7-2x a later one).  One lane per
+// sixteen Morton-adjacent queries walks the tree for the first of them — a 1-NN walk, pruned from the first box on — and hands
+// the leaf it ends in to all sixteen: their neighbours are in or next to it.  A start leaf never changes what a walk finds.
+__global__ __launch_bounds__(256) void seed_hints_kernel(CloudView src, BvhView tgt, const IcpState *__restrict__ st, uint32_t *__restrict__ hint) {
+  __shared__ float s_stk[kMaxDepth + 1][256];
+  float *stk = &s_stk[0][threadIdx.x];
+  const uint32_t n_groups = (src.n_valid + 15u) / 16u;
+  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < n_groups; g += gridDim.x * 256u) {
+    const uint32_t i0 = g * 16u;
+    const float4 s = src.xyzw[i0];
+    const float x = xform_row(st->Ff + 0, s.x, s.y, s.z), y = xform_row(st->Ff + 4, s.x, s.y, s.z), z = xform_row(st->Ff + 8, s.x, s.y, s.z);
+    NearestVisitor v{INFINITY, kNoPos, 0};
+    bvh_traverse(tgt, x, y, z, v, stk, 256);
+    if (v.leaf != 0u)
+      for (uint32_t i = i0; i < min(i0 + 16u, src.n_valid); ++i) hint[i] = v.leaf;
+  }
+}
+void launch_seed_hints(hipStream_t stream, const CloudView &src, const BvhView &tgt, const IcpState *st, uint32_t *hint) {
+  const uint32_t n_groups = (src.n_valid + 15u) / 16u;
+  if (n_groups == 0) return;
+  hipLaunchKernelGGL(seed_hints_kernel, dim3(std::min<uint32_t>((n_groups + 255u) / 256u, 4096u)), dim3(256), 0, stream, src, tgt, st, hint);
+}
+
 void launch_fitness(hipStream_t stream, int nblocks, const CloudView &q, const BvhView &tgt, const float *d_T,
                     double max_range, double *partials, const uint32_t *hint) {
   hipLaunchKernelGGL(fitness_kernel, dim3(nblocks), dim3(256), 0, stream, q, tgt, d_T, max_range, partials, hint);
