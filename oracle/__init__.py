@@ -145,6 +145,7 @@ def _declare(L):
     L.orc_icp_fixed.restype = C.c_int
     L.orc_icp_fixed.argtypes = [_fp, _fp, C.c_int, _fp, _fp, C.c_int, _fp, C.POINTER(IcpParams), _ip, _ip, C.c_int, _fp,
                                 C.POINTER(IcpResult), _fp, _ip, _ip, _fp]
+    L.orc_icp_set_threads.argtypes = [C.c_int]
     L.orc_fitness.restype = C.c_double
     L.orc_fitness.argtypes = [_fp, C.c_int, _fp, C.c_int, _fp, C.c_double, C.POINTER(C.c_int)]
     L.orc_icp_partial_sums.argtypes = [_fp, C.c_int, C.c_void_p, _fp, _fp, C.c_double, _dp, _dp]
@@ -306,8 +307,9 @@ class IcpOut:
     corr_d2: np.ndarray
 
 
-def icp(src, tgt, params: IcpParams | None = None, guess=None, src_nrm=None, tgt_nrm=None, fixed=None) -> IcpOut:
-    """fixed: optional (index_query[], index_match[]) — the reference's setFixedCorrespondences (icp_mod.h:268), see icp.c."""
+def icp(src, tgt, params: IcpParams | None = None, guess=None, src_nrm=None, tgt_nrm=None, fixed=None, n_threads: int = 1) -> IcpOut:
+    """fixed: optional (index_query[], index_match[]) — the reference's setFixedCorrespondences (icp_mod.h:268), see icp.c.
+    n_threads: threads of the per-query searches only (orc_icp_set_threads); the result does not depend on it."""
     src, tgt = _f32(src, 3), _f32(tgt, 3)
     p = params or default_icp_params()
     sn = _f32(src_nrm, 3) if src_nrm is not None else None
@@ -321,9 +323,13 @@ def icp(src, tgt, params: IcpParams | None = None, guess=None, src_nrm=None, tgt
     assert len(fq) == len(fm)
     cap = len(src) + 2 * len(fq)
     cq = np.empty(cap, np.int32); cm = np.empty(cap, np.int32); cd = np.empty(cap, np.float32)
-    rc = lib().orc_icp_fixed(_p(src, _fp), _p(sn, _fp), len(src), _p(tgt, _fp), _p(tn, _fp), len(tgt), _p(g, _fp),
-                             C.byref(p), _p(fq, _ip) if len(fq) else None, _p(fm, _ip) if len(fm) else None, len(fq), _p(T, _fp),
-                             C.byref(res), _p(hist, _fp), _p(cq, _ip), _p(cm, _ip), _p(cd, _fp))
+    lib().orc_icp_set_threads(int(n_threads))
+    try:
+        rc = lib().orc_icp_fixed(_p(src, _fp), _p(sn, _fp), len(src), _p(tgt, _fp), _p(tn, _fp), len(tgt), _p(g, _fp),
+                                 C.byref(p), _p(fq, _ip) if len(fq) else None, _p(fm, _ip) if len(fm) else None, len(fq), _p(T, _fp),
+                                 C.byref(res), _p(hist, _fp), _p(cq, _ip), _p(cm, _ip), _p(cd, _fp))
+    finally:
+        lib().orc_icp_set_threads(1)
     if rc != 0:
         raise ValueError(f"orc_icp rc={rc}")
     n = res.n_corr

@@ -474,6 +474,49 @@ void orc_icp_partial_sums_mt(const float *src_xyz, int ns, const orc_kdtree *tgt
   free(jobs); free(th); free(started);
 }
 
+/* Search threads of orc_icp / orc_icp_fixed (tests that follow a whole 1 M-point run).  Only the per-query searches run in
+ * parallel — each query's result lands in its own slot —; the list is then put together, rejected, summed and transformed by one
+ * thread in query order, so the loop returns exactly what it returns with one thread. */
+static int g_icp_threads = 1;
+void orc_icp_set_threads(int n) { g_icp_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
+
+typedef struct {
+  const orc_kdtree *tree; const float *work; const float *wnrm; const float *tgt; int lo, hi; int corr_mode, kk;
+  int32_t *id; float *d; uint8_t *ok; double *line;
+} nn_job;
+static void *nn_worker(void *arg) {
+  nn_job *j = (nn_job *)arg;
+  int32_t *nn_i = (int32_t *)malloc(sizeof(int32_t) * (size_t)j->kk);
+  float *nn_d = (float *)malloc(sizeof(float) * (size_t)j->kk);
+  for (int i = j->lo; i < j->hi; ++i) {
+    const float *q = j->work + 3 * i;
+    j->ok[i] = 0;
+    if (!finite3(q)) continue;
+    if (j->corr_mode == 0) {
+      int32_t f;
+      orc_kdtree_knn(j->tree, q, 1, 1, &j->id[i], &j->d[i], &f);
+      j->ok[i] = f ? 1 : 0;
+    } else {
+      int32_t f;
+      orc_kdtree_knn(j->tree, q, 1, j->kk, nn_i, nn_d, &f);
+      if (f <= 0) continue;
+      double min_dist = DBL_MAX;
+      int min_index = 0;
+      const float *nq = j->wnrm + 3 * i;
+      for (int m = 0; m < f; ++m) {
+        float vx = j->tgt[3 * nn_i[m]] - q[0], vy = j->tgt[3 * nn_i[m] + 1] - q[1], vz = j->tgt[3 * nn_i[m] + 2] - q[2];
+        double N[3] = {nq[0], nq[1], nq[2]}, V[3] = {vx, vy, vz};
+        double C[3] = {N[1] * V[2] - N[2] * V[1], N[2] * V[0] - N[0] * V[2], N[0] * V[1] - N[1] * V[0]};
+        double dist = C[0] * C[0] + C[1] * C[1] + C[2] * C[2];
+        if (dist < min_dist) { min_dist = dist; min_index = m; }
+      }
+      j->id[i] = nn_i[min_index]; j->d[i] = nn_d[min_index]; j->line[i] = min_dist; j->ok[i] = 1;
+    }
+  }
+  free(nn_i); free(nn_d);
+  return NULL;
+}
+
 int orc_icp(const float *src_xyz, const float *src_nrm, int ns, const float *tgt_xyz, const float *tgt_nrm, int nt,
             const float guess[16], const orc_icp_params *p, float out_T[16], orc_icp_result *res, float *T_hist,
             int32_t *corr_q_out, int32_t *corr_m_out, float *corr_d2_out) {
@@ -524,6 +567,16 @@ int orc_icp_fixed(const float *src_xyz, const float *src_nrm, int ns, const floa
   int32_t *nn_i = (int32_t *)malloc(sizeof(int32_t) * (size_t)kk);
   float *nn_d = (float *)malloc(sizeof(float) * (size_t)kk);
 
+  /* threaded search (orc_icp_set_threads): per-query slots; reciprocal search stays on one thread (its tree is rebuilt per iteration) */
+  const int n_thr = (g_icp_threads > 1 && !p->use_reciprocal) ? g_icp_threads : 1;
+  int32_t *sl_id = NULL; float *sl_d = NULL; uint8_t *sl_ok = NULL; double *sl_line = NULL;
+  if (n_thr > 1) {
+    sl_id = (int32_t *)malloc(sizeof(int32_t) * (size_t)ns);
+    sl_d = (float *)malloc(sizeof(float) * (size_t)ns);
+    sl_ok = (uint8_t *)malloc((size_t)ns);
+    sl_line = (double *)malloc(sizeof(double) * (size_t)ns);
+  }
+
   float final_T[16], Tk[16];
   double final_Td[16];
   memcpy(final_T, guess, sizeof final_T);
@@ -569,6 +622,26 @@ int orc_icp_fixed(const float *src_xyz, const float *src_nrm, int ns, const floa
         fixed_d[f] = (float)(Cx * Cx + Cy * Cy + Cz * Cz);
       }
     }
+    if (n_thr > 1) {
+      nn_job jobs[256];
+      pthread_t th[256];
+      char started[256];
+      for (int t = 0; t < n_thr; ++t) {
+        const long long a = (long long)ns * t / n_thr, b = (long long)ns * (t + 1) / n_thr;
+        jobs[t] = (nn_job){tree, work, wnrm, tgt_xyz, (int)a, (int)b, p->corr_mode, kk, sl_id, sl_d, sl_ok, sl_line};
+        started[t] = pthread_create(&th[t], NULL, nn_worker, &jobs[t]) == 0;
+        if (!started[t]) nn_worker(&jobs[t]);
+      }
+      for (int t = 0; t < n_thr; ++t)
+        if (started[t]) pthread_join(th[t], NULL);
+      /* the list in query order, with the tests of the one-thread loop below */
+      for (int i = 0; i < ns; ++i) {
+        if (!sl_ok[i]) continue;
+        if (p->corr_mode == 0) { if ((double)sl_d[i] > max_d2) continue; }
+        else if (sl_line[i] > p->max_corr_dist) continue;      /* quirk Q2, as below */
+        cq[ncorr] = i; cm[ncorr] = sl_id[i]; cd[ncorr] = sl_d[i]; ++ncorr;
+      }
+    } else
     for (int i = 0; i < ns; ++i) {
       const float *q = work + 3 * i;
       if (!finite3(q)) continue;
@@ -687,6 +760,7 @@ int orc_icp_fixed(const float *src_xyz, const float *src_nrm, int ns, const floa
   if (corr_d2_out) memcpy(corr_d2_out, cd, sizeof(float) * (size_t)ncorr);
 
   free(fixed_d);
+  free(sl_id); free(sl_d); free(sl_ok); free(sl_line);
   free(work); free(wnrm); free(cq); free(cm); free(cd); free(ps); free(pt); free(pn); free(nn_i); free(nn_d);
   orc_kdtree_free(tree);
   if (rtree) orc_kdtree_free(rtree);

@@ -184,6 +184,10 @@ int orc_icp_fixed(const float *src_xyz, const float *src_nrm, int ns, const floa
                   const float guess[16], const orc_icp_params *p, const int32_t *fixed_q, const int32_t *fixed_m, int n_fixed,
                   float out_T[16], orc_icp_result *res, float *T_hist, int32_t *corr_q, int32_t *corr_m, float *corr_d2);
 
+/* Number of threads the per-query searches of orc_icp / orc_icp_fixed run on (default 1).  Lists, rejectors, sums and
+ * transforms stay on one thread in query order: results do not depend on the setting. */
+void orc_icp_set_threads(int n);
+
 /* Registration::getFitnessScore(max_range) for an arbitrary transform. */
 double orc_fitness(const float *src_xyz, int ns, const float *tgt_xyz, int nt,
                    const float T[16], double max_range, int *n_used);

@@ -1,6 +1,6 @@
-"""world_size-2 `gloo` tests of the sharded ICP driver (KAT-9): the same run_sharded_icp loop that the
-GPU ranks execute, with a checker engine (CPU oracle) standing in for the kernels.  Asserts that the
-sharded result is independent of the number of ranks and equals the unsharded oracle."""
+"""`gloo` tests of the sharded ICP driver at world sizes 1, 2, 4 and 8 (R in {1, 2, 4, 8}): the same
+run_sharded_icp loop that the GPU ranks execute, with a checker engine (CPU oracle) standing in for the kernels.  Asserts that
+the sharded result is independent of the number of ranks and equals the unsharded oracle."""
 import importlib
 import os
 import socket
@@ -111,18 +111,40 @@ def test_shard_range_partitions_exactly():
         sharded.shard_range(10, 2, 2)
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_gloo_equals_one_rank_and_oracle(tmp_path):
-    ns, nt, max_it = 6000, 1500, 12
-    for world in (1, 2):
-        mp.spawn(_worker, args=(world, _free_port(), ns, nt, max_it, str(tmp_path)), nprocs=world, join=True)
-    T1 = np.load(tmp_path / "T_w1.npy"); T2 = np.load(tmp_path / "T_w2.npy")
-    m1 = np.load(tmp_path / "meta_w1.npy"); m2 = np.load(tmp_path / "meta_w2.npy")
-    assert np.linalg.norm(T1.astype(np.float64) - T2.astype(np.float64)) < 1e-6      # rank-count invariance
-    assert (m1 == m2).all() and m1[1] == ns
+def _run_world(world, ns, nt, max_it, tmp_path):
+    mp.spawn(_worker, args=(world, _free_port(), ns, nt, max_it, str(tmp_path)), nprocs=world, join=True)
+    return np.load(tmp_path / f"T_w{world}.npy"), np.load(tmp_path / f"meta_w{world}.npy")
+
+
+def _oracle_run(ns, nt, max_it):
     p = oracle.default_icp_params()
     p.max_iterations = max_it; p.transformation_epsilon = 1e-10; p.euclidean_fitness_epsilon = 1e-10
     p.acc_mode = 1; p.transform_mode = 1
-    ref = oracle.icp(synth.scene_cloud(ns), synth.model_surface(nt, 1), p)
+    return oracle.icp(synth.scene_cloud(ns), synth.model_surface(nt, 1), p)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_equals_one_rank_and_oracle(tmp_path):
+    ns, nt, max_it = 6000, 1500, 12
+    T1, m1 = _run_world(1, ns, nt, max_it, tmp_path)
+    T2, m2 = _run_world(2, ns, nt, max_it, tmp_path)
+    assert np.linalg.norm(T1.astype(np.float64) - T2.astype(np.float64)) < 1e-6      # rank-count invariance
+    assert (m1 == m2).all() and m1[1] == ns
+    ref = _oracle_run(ns, nt, max_it)
     assert np.linalg.norm(T2.astype(np.float64) - ref.T.astype(np.float64)) < 2e-5
     assert m2[0] == ref.iterations
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [4, 8])
+def test_four_and_eight_rank_gloo_equal_one_rank_and_oracle(tmp_path, world):
+    """KAT-9 at the rank counts BASELINE's C4 names (the 8-GPU node is one process per GPU = world 8): the shards are ragged
+    (6001 is prime: no two world sizes cut it alike), every rank reports the all-reduced count and bit-identical transforms."""
+    ns, nt, max_it = 6001, 1500, 10
+    T1, m1 = _run_world(1, ns, nt, max_it, tmp_path)
+    Tw, mw = _run_world(world, ns, nt, max_it, tmp_path)
+    assert np.linalg.norm(T1.astype(np.float64) - Tw.astype(np.float64)) < 1e-6
+    assert (m1 == mw).all() and mw[1] == ns
+    ref = _oracle_run(ns, nt, max_it)
+    assert np.linalg.norm(Tw.astype(np.float64) - ref.T.astype(np.float64)) < 2e-5
+    assert mw[0] == ref.iterations
