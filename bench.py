@@ -62,6 +62,8 @@ def main() -> int:
     ap.add_argument("--update-launch", default="overlapped", choices=["overlapped", "in-line"],
                     help="ope_icp_params.update_launch (include/ope.h): the library's default, or accumulate -> update -> accumulate "
                          "on one stream as in rounds 1-2 (A/B; and what a profiler that serialises dispatches, rocprofv3 --pmc, wants)")
+    ap.add_argument("--certificates", default="auto", choices=["auto", "off", "always"],
+                    help="ope_icp_params.skip_certificates (include/ope.h): the library's default, never, or from the first launch (A/B)")
     ap.add_argument("--no-ns", action="store_true", help="skip the normal-shooting leg (the correspondence estimation the reference's "
                                                           "estimateFinePose really installs), reported beside `value` at N = 1")
     ap.add_argument("--no-coarse", action="store_true", help="skip the FPFH + SAC-IA initial alignment (identity start)")
@@ -243,7 +245,8 @@ def main() -> int:
     S = args.steady
     params = ope.default_icp_params(max_iterations=W + K + S + 1, transformation_epsilon=0.0,
                                     euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0, check_every=0,
-                                    update_launch=0 if args.update_launch == "overlapped" else 1)
+                                    update_launch=0 if args.update_launch == "overlapped" else 1,
+                                    skip_certificates={"auto": ope.CERT_AUTO, "off": ope.CERT_OFF, "always": ope.CERT_ALWAYS}[args.certificates])
     ctx.icp_set_global_sizes(n_scene, n_model)
     ctx.icp_begin(cs, ix, params, guess)
 

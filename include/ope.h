@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OPE_ABI_VERSION 4
+#define OPE_ABI_VERSION 5
 
 enum {
   OPE_OK = 0,
@@ -206,9 +206,22 @@ typedef struct {
    * OPE_UPDATE_IN_LINE (1): accumulate -> update -> accumulate on the one stream, as in rounds 1-2 (a profiler that
    * serialises dispatches, e.g. rocprofv3 --pmc, wants this).  Same arithmetic either way. */
   int update_launch;
+  /* Skip certificates of the plain 1-NN search (what CorrespondenceEstimation::determineCorrespondences,
+   * impl/correspondence_estimation_mod.hpp:165-177, recomputes from scratch every iteration).  Late in a run a query's nearest
+   * neighbour rarely changes, and that can be PROVEN without a search: a search also yields a lower bound L on the query's
+   * distance to every OTHER target point (the runner-up among the points it saw, the smallest bound among the boxes it pruned);
+   * each later launch takes the query's own displacement off L and, while the previous match re-measured from where the query
+   * is now stays strictly below what is left — past every fp32 rounding —, that match is the unique nearest neighbour: same
+   * index, same d2, bit for bit, and no walk.  Every launch still writes every correspondence and adds every term of the sums.
+   * OPE_CERT_AUTO (0, default): certificates are kept from the iteration on whose update moves no scene point by more than a
+   * quarter of the target's point spacing (decided on the device, no host round trip; earlier they would expire at once).
+   * OPE_CERT_OFF (1): never.  OPE_CERT_ALWAYS (2): from the first launch (tests).  Plain 1-NN runs only (not: reciprocal,
+   * normal shooting, deterministic_sums); exact in every mode — the choice moves time only. */
+  int skip_certificates;
 } ope_icp_params;
 enum { OPE_WALK_AUTO = 0, OPE_WALK_LANE = 1, OPE_WALK_PACKET = 2 };
 enum { OPE_UPDATE_OVERLAPPED = 0, OPE_UPDATE_IN_LINE = 1 };
+enum { OPE_CERT_AUTO = 0, OPE_CERT_OFF = 1, OPE_CERT_ALWAYS = 2 };
 
 typedef struct {
   int iterations;        /* nr_iterations_ */
@@ -244,6 +257,11 @@ enum { OPE_KERNEL_GRID = 0, OPE_KERNEL_TREE_LANE = 1, OPE_KERNEL_TREE_PACKET = 2
 int ope_icp_kernel_launches(const ope_ctx *ctx, int64_t counts[OPE_KERNEL_KINDS]);
 /* How many update steps of the current (or last) run were launched overlapped (ope_icp_params.update_launch). */
 int64_t ope_icp_overlapped_updates(const ope_ctx *ctx);
+/* Skip certificates of the run in progress (ope_icp_params.skip_certificates; synchronises the stream): out[0] = queries answered
+ * from their certificate, summed over the run's launches; out[1] = accumulate launches that kept certificates; out[2] = 1 if the
+ * run has reached the stage where it keeps them; out[3] = the last update's largest scene displacement in nanometres (what the
+ * automatic mode compares with a quarter of the target's point spacing). */
+int ope_icp_certificate_stats(ope_ctx *ctx, int64_t out[4]);
 
 /* Registration::align(output, guess) -> IterativeClosestPoint::computeTransformation
  * (registration_mod.hpp:176-219, icp_mod.hpp:119-272).  guess may be NULL (identity).

@@ -25,6 +25,7 @@ CONV_NAMES = ["NOT_CONVERGED", "ITERATIONS", "TRANSFORM", "ABS_MSE", "REL_MSE", 
 CORR_NEAREST, CORR_NORMAL_SHOOTING = 0, 1
 EST_SVD, EST_POINT_TO_PLANE_LLS, EST_POINT_TO_PLANE_LM = 0, 1, 2
 COMM_AUTO, COMM_RCCL, COMM_P2P = 0, 1, 2
+CERT_AUTO, CERT_OFF, CERT_ALWAYS = 0, 1, 2   # ope_icp_params.skip_certificates
 NUM_SUMS, NUM_SUMS_MAX = 17, 44
 COMM_ID_BYTES = 128
 
@@ -69,6 +70,7 @@ class IcpParams(C.Structure):
         ("deterministic_sums", C.c_int),
         ("tree_walk", C.c_int),
         ("update_launch", C.c_int),
+        ("skip_certificates", C.c_int),
     ]
 
 
@@ -147,6 +149,7 @@ ABI = [
     ("ope_icp_set_global_sizes", C.c_int, [_vp, C.c_int64, C.c_int64]),
     ("ope_icp_kernel_launches", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("ope_icp_overlapped_updates", C.c_int64, [_vp]),
+    ("ope_icp_certificate_stats", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("ope_icp_set_fixed_correspondences", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t]),
     ("ope_icp_profile_launches", C.c_int, [_vp, _fp, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ope_cloud_select", C.c_int, [_vp, _vp, _ip, C.c_size_t, C.POINTER(_vp)]),
@@ -471,6 +474,14 @@ class Context:
     def icp_overlapped_updates(self) -> int:
         """Update steps of the current / last run that were launched overlapped (ope_icp_params.update_launch)."""
         return int(lib().ope_icp_overlapped_updates(self.h))
+
+    def icp_certificate_stats(self) -> dict:
+        """Skip certificates of the run in progress (ope_icp_params.skip_certificates): queries answered from their certificate
+        (summed over the launches), launches that kept certificates, whether the run keeps them now, the last update's largest
+        scene displacement in metres."""
+        c = (C.c_int64 * 4)()
+        self._chk(lib().ope_icp_certificate_stats(self.h, c))
+        return {"certified": int(c[0]), "launches": int(c[1]), "on": bool(c[2]), "last_move": c[3] * 1e-9}
 
     def icp_set_global_sizes(self, n_src_total: int, n_tgt_total: int):
         self._chk(lib().ope_icp_set_global_sizes(self.h, n_src_total, n_tgt_total))

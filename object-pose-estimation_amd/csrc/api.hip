@@ -16,7 +16,7 @@ namespace ope {
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
                            uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *, const uint32_t *, hipEvent_t, hipEvent_t, bool,
-                           uint32_t *, uint32_t);
+                           uint32_t *, uint32_t, uint2 *);
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
 void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
@@ -179,6 +179,8 @@ static int grid_probe_poll(ope_ctx *ctx, int it_done) {
 static int switch_kernel(ope_ctx *ctx, bool to_grid, int it_done, uint32_t nch) {
   ctx->use_grid = to_grid;
   ctx->plan_valid = false;   // chunk ids mean something else to the other kernel
+  // skip certificates are kept up to date by the tree kernel's launches only: none survives a change of kernel
+  if (ctx->d_cert && ctx->run_src) OPE_HIP(ctx, hipMemsetAsync(ctx->d_cert, 0, sizeof(uint2) * std::max<size_t>(ctx->run_src->n, 1), ctx->stream));
   if (ctx->plan_pending) { OPE_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_plan_done, 0)); ctx->plan_pending = false; }
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * (size_t)(nch + 1), ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 8, 0, 8, ctx->stream));
@@ -350,7 +352,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
                         (ctx->plan_valid && ctx->plan_cur_slots) ? ctx->d_plan_slots[ctx->plan_cur] : nullptr,
                         (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && !dev_env("OPE_NO_KNN_BOUND")) ? ctx->d_knn_rk : nullptr, ctx->d_plan_out + 8 * ctx->plan_cur,
                         timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr,
-                        ctx->measuring_flag, ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq);
+                        ctx->measuring_flag, ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, ctx->cert_run ? ctx->d_cert : nullptr);
   if (timed) ++ctx->prof_used;
   return OPE_OK;
 }
@@ -436,6 +438,7 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
   if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
   if (ctx->d_hint) (void)hipFree(ctx->d_hint);
+  if (ctx->d_cert) (void)hipFree(ctx->d_cert);
   if (ctx->d_knn_rk) (void)hipFree(ctx->d_knn_rk);
   for (void *p : {(void *)ctx->d_ghint, (void *)ctx->d_qorder, (void *)ctx->d_qclass, ctx->d_part_tmp, (void *)ctx->d_chunk_keys})
     if (p) (void)hipFree(p);
@@ -848,9 +851,31 @@ void ope_icp_default_params(ope_icp_params *p) {
   p->deterministic_sums = 0;
   p->tree_walk = OPE_WALK_AUTO;
   p->update_launch = OPE_UPDATE_OVERLAPPED;
+  p->skip_certificates = OPE_CERT_AUTO;
 }
 
 int64_t ope_icp_overlapped_updates(const ope_ctx *ctx) { return ctx ? (int64_t)ctx->chain_seq : 0; }
+
+int ope_icp_certificate_stats(ope_ctx *ctx, int64_t out[4]) {
+  if (!ctx || !out) return OPE_EINVAL;
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!ctx->d_work_counter || !ctx->d_state) return OPE_OK;
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  const int rcj = chain_join(ctx);
+  if (rcj != OPE_OK) return rcj;
+  uint32_t w[4] = {0, 0, 0, 0};
+  int mode = 0;
+  float move = 0.f;
+  OPE_HIP(ctx, hipMemcpyAsync(w, ctx->d_work_counter + 40, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
+  OPE_HIP(ctx, hipMemcpyAsync(&mode, reinterpret_cast<unsigned char *>(ctx->d_state) + offsetof(IcpState, cert_mode), sizeof mode, hipMemcpyDeviceToHost, ctx->stream));
+  OPE_HIP(ctx, hipMemcpyAsync(&move, reinterpret_cast<unsigned char *>(ctx->d_state) + offsetof(IcpState, last_move), sizeof move, hipMemcpyDeviceToHost, ctx->stream));
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  out[0] = (int64_t)(((uint64_t)w[1] << 32) | w[0]);
+  out[1] = (int64_t)w[2];
+  out[2] = mode;
+  out[3] = (int64_t)((double)move * 1e9);
+  return OPE_OK;
+}
 
 int ope_icp_kernel_launches(const ope_ctx *ctx, int64_t counts[OPE_KERNEL_KINDS]) {
   if (!ctx || !counts) return OPE_EINVAL;
@@ -912,6 +937,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown estimator");
   if (p.tree_walk < OPE_WALK_AUTO || p.tree_walk > OPE_WALK_PACKET) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown tree_walk");
   if (p.update_launch != OPE_UPDATE_OVERLAPPED && p.update_launch != OPE_UPDATE_IN_LINE) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown update_launch");
+  if (p.skip_certificates < OPE_CERT_AUTO || p.skip_certificates > OPE_CERT_ALWAYS) return set_err(ctx, OPE_EINVAL, "ope_icp_begin: unknown skip_certificates");
   if (ctx->n_fixed > 0) {
     if (ctx->fixed_src != src || ctx->fixed_tgt_n != tgt->n_total)
       return set_err(ctx, OPE_EINVAL, "ope_icp_begin: the fixed correspondences were set for another pair of clouds (ope_icp_set_fixed_correspondences with n = 0 clears them)");
@@ -946,10 +972,12 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
     if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
     if (ctx->d_hint) (void)hipFree(ctx->d_hint);
-    ctx->d_corr_match = nullptr; ctx->d_corr_d2 = nullptr; ctx->d_hint = nullptr; ctx->corr_cap = 0;
+    if (ctx->d_cert) (void)hipFree(ctx->d_cert);
+    ctx->d_corr_match = nullptr; ctx->d_corr_d2 = nullptr; ctx->d_hint = nullptr; ctx->d_cert = nullptr; ctx->corr_cap = 0;
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_corr_match, sizeof(int32_t) * std::max<size_t>(src->n, 1)));
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_corr_d2, sizeof(float) * std::max<size_t>(src->n, 1)));
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_hint, sizeof(uint32_t) * std::max<size_t>(src->n, 1)));
+    OPE_HIP(ctx, hipMalloc((void **)&ctx->d_cert, sizeof(uint2) * std::max<size_t>(src->n, 1)));
     ctx->corr_cap = std::max<size_t>(src->n, 1);
   }
   ctx->use_grid = false;
@@ -1083,6 +1111,27 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   h->use_self_occluded_rej = p.use_self_occluded_rej;
   h->use_reciprocal = p.use_reciprocal;
   h->estimator = p.estimator;
+  {
+    // Skip certificates (ope.h: skip_certificates): plain 1-NN runs.  Automatic: kept once an update moves no scene point by
+    // more than a quarter of the target's point spacing, estimated from the surface of its bounding box over its size (a
+    // closed surface sampled by n points inside that box: spacing ~ sqrt(area / n); the factor matters little — a run that starts keeping them
+    // early pays a few percent per launch for walks that report their bounds, one that starts late walks a little longer).
+    ctx->cert_run = p.corr_mode == OPE_CORR_NEAREST && !p.use_reciprocal && p.deterministic_sums == 0 && p.skip_certificates != OPE_CERT_OFF &&
+                    !dev_env("OPE_NO_CERT");
+    const double ex = (double)tgt->bb_hi[0] - tgt->bb_lo[0], ey = (double)tgt->bb_hi[1] - tgt->bb_lo[1], ez = (double)tgt->bb_hi[2] - tgt->bb_lo[2];
+    const double spacing = std::sqrt(2.0 * (ex * ey + ey * ez + ez * ex) / (double)std::max<size_t>(tgt->n, 1));
+    h->cert_thr = !ctx->cert_run ? -1.0f : p.skip_certificates == OPE_CERT_ALWAYS ? std::numeric_limits<float>::infinity() : (float)(0.25 * spacing);
+    if (const char *e = dev_env("OPE_CERT_THR")) h->cert_thr = (float)atof(e);   // developer sweep (metres)
+    h->cert_mode = (ctx->cert_run && p.skip_certificates == OPE_CERT_ALWAYS) ? 1 : 0;
+    double r2 = 0;
+    for (int d = 0; d < 3; ++d) {
+      h->src_c[d] = 0.5f * (src->bb_lo[d] + src->bb_hi[d]);
+      const double hd = 0.5 * ((double)src->bb_hi[d] - (double)src->bb_lo[d]);
+      r2 += hd * hd;
+    }
+    h->src_r = (float)std::sqrt(r2);
+    if (ctx->cert_run) OPE_HIP(ctx, hipMemsetAsync(ctx->d_cert, 0, sizeof(uint2) * std::max<size_t>(src->n, 1), ctx->stream));
+  }
   {
     // inverse of the guess (adjugate), rows layout
     const double a = g[0], b = g[4], c = g[8], d = g[1], e = g[5], f = g[9], gg = g[2], hh = g[6], ii = g[10];

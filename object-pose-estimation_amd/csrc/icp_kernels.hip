@@ -66,6 +66,9 @@ __device__ __forceinline__ bool acc_launch_begin(const IcpState *st, uint32_t *c
   __syncthreads();   // (the loads below are issued after the word has arrived)
   if (threadIdx.x < 12) s_const[threadIdx.x] = __hip_atomic_load(&st->Ff[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else if (threadIdx.x == 12) s_go[1] = (uint32_t)__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if (threadIdx.x >= 16 && threadIdx.x < 28) s_const[threadIdx.x] = __hip_atomic_load(&st->Fprev[threadIdx.x - 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if (threadIdx.x == 28) s_const[28] = __int_as_float(__hip_atomic_load(&st->cert_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else if (threadIdx.x == 29) s_const[29] = __int_as_float(__hip_atomic_load(&st->cert_prev_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   __syncthreads();
   return s_go[0] != 0u && s_go[1] == 0u;
 }
@@ -152,11 +155,14 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
     const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list,
-    float *__restrict__ knn_rk, const uint32_t *__restrict__ plan_out, uint32_t measuring_launch, uint32_t *chain_arg, uint32_t chain_seq) {
+    float *__restrict__ knn_rk, const uint32_t *__restrict__ plan_out, uint32_t measuring_launch, uint32_t *chain_arg, uint32_t chain_seq,
+    uint2 *__restrict__ cert_arg) {
   uint32_t *const chain = (MODE == 0 && !RECIP) ? chain_arg : nullptr;   // overlapped update launches exist for the plain 1-NN run only (api.hip)
+  uint2 *const cert = (MODE == 0 && !RECIP) ? cert_arg : nullptr;        // and so do skip certificates
   // Per-run constants live in LDS and are re-read where they are used (through a pointer the optimiser cannot see
   // through): held in registers across the walk they were spilled to scratch, 13 dwords per lane and launch.
-  __shared__ __attribute__((aligned(16))) float s_const[16];   // F rows [0..11], pivot [12..14], best0 [15]
+  __shared__ __attribute__((aligned(16))) float s_const[32];   // F rows [0..11], pivot [12..14], best0 [15], previous launch's F rows [16..27], cert_mode [28], cert_prev_ok [29] (int bits)
+  __shared__ uint32_t s_ncert;
   if (!acc_launch_begin(st, chain, chain_seq, s_const)) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
@@ -178,8 +184,27 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   if (threadIdx.x < 12) { if (chain == nullptr) s_const[threadIdx.x] = st->Ff[threadIdx.x]; }   // (overlapped: fetched by acc_launch_begin)
   else if (threadIdx.x < 15) s_const[threadIdx.x] = (float)st->pivot[threadIdx.x - 12];
   else if (threadIdx.x == 15) s_const[15] = best0;
+  else if (threadIdx.x < 28) { if (chain == nullptr) s_const[threadIdx.x] = st->Fprev[threadIdx.x - 16]; }
+  else if (threadIdx.x == 28) { if (chain == nullptr) s_const[28] = __int_as_float(st->cert_mode); }
+  else if (threadIdx.x == 29) { if (chain == nullptr) s_const[29] = __int_as_float(st->cert_prev_ok); }
+  else if (threadIdx.x == 30) s_ncert = 0u;
   __syncthreads();
   if (MODE == 2 && knn_rk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) const_cast<IcpState *>(st)->knn_acc_flag = 1;
+  // ---- skip certificates (plain 1-NN; ope.h: ope_icp_params.skip_certificates).  A launch in cert mode brings every query's
+  // certificate up to the transform it searches with — by answering from it or by a certifying walk — so the next launch only
+  // has to take one launch's displacement off it.  cert_on is launch-uniform; the walks below exist once per visitor type.
+#ifdef OPE_NO_CERT_KERNEL   // (A/B build: the kernel as it was without the certified branch)
+  const bool cert_on = false;
+#else
+  const bool cert_on = cert != nullptr && __float_as_int(s_const[28]) != 0;
+#endif
+  const bool cert_prev_ok = cert_on && __float_as_int(s_const[29]) != 0;
+  if (cert_on && blockIdx.x == 0 && threadIdx.x == 0) {
+    // in line: the update that follows learns that the certificates are of this launch's transform (overlapped runs alternate
+    // accumulate and update launches by construction: icp_update_chained_kernel says so itself)
+    if (chain == nullptr) const_cast<IcpState *>(st)->cert_acc_flag = 1;
+    atomicAdd(work_counter + 42, 1u);
+  }
   const bool rej_sn = NRM && st->use_surface_normal_rej;
   const bool rej_so = NRM && st->use_self_occluded_rej;
   // the LM estimator (lm.hip) re-reads the matched target points: corr_match then holds their POSITION in the index
@@ -275,7 +300,73 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     float d2;
     uint32_t pos = 0;
     int match = -1;
-    if (MODE == 0) {
+    if (MODE == 0 && OCT_OK && cert_on) {
+      // ---- certified search.  c = {1 + position of the previous match, L}: at the previous launch every OTHER target point
+      // was at least L away from this query.  The query has moved by dl since (recomputed from the previous launch's transform),
+      // so every other point is at least L - dl away now; if the previous match, re-measured with the search's own arithmetic,
+      // is strictly nearer than that — past the rounding of every quantity involved (u = 2^-24: a computed d2 is within 5u of
+      // the true one, v_sqrt_f32 within 1 ulp; the factors below leave 16u) — it is the unique nearest neighbour: what a walk
+      // would return, bit for bit.  Otherwise the query walks, with the visitor that reports the next L.
+      const uint32_t h = active ? hint[i] : 0u;
+      const float best_init = active ? cst[15] : -INFINITY;
+      bool need = active;
+      float c_best = INFINITY, c_L = 0.f;
+      uint32_t c_pos1 = 0u;
+      bool c_moved = false;
+      if (active && cert_prev_ok) {
+        const uint2 c = cert[i];
+        if (c.x != 0u) {
+          const v4f tp = ld16(tgt.pts + (c.x - 1u));
+          const float dn = sq_dist3(__fsub_rn(x, tp.x), __fsub_rn(y, tp.y), __fsub_rn(z, tp.z));
+          float G[12];
+#pragma unroll
+          for (int k = 0; k < 12; ++k) G[k] = cst[16 + k];
+          const float ox = xform_row(G + 0, s.x, s.y, s.z), oy = xform_row(G + 4, s.x, s.y, s.z), oz = xform_row(G + 8, s.x, s.y, s.z);
+          const float dl = __builtin_amdgcn_sqrtf(sq_dist3(__fsub_rn(x, ox), __fsub_rn(y, oy), __fsub_rn(z, oz)));
+          const float L0 = __uint_as_float(c.y);
+          // L0 - dl rounded DOWN (one float below the rounded difference); a query that has not moved keeps its L
+          const float L1 = dl == 0.f ? L0 : __uint_as_float(__float_as_uint(__fsub_rn(L0, __fmaf_rn(dl, 1.000001f, 1e-30f))) - 1u);
+          const float T = __fmul_rn(__fmul_rn(L1, L1), 0.999999f);
+          if (L1 > 0.f && dn < T && dn < best_init) { need = false; c_best = dn; c_L = L1; c_pos1 = c.x; c_moved = dl != 0.f; }
+        }
+      }
+      NearestCertVisitor w{need ? best_init : -INFINITY, kNoPos, 0, INFINITY, INFINITY};
+      if (__ballot(need) != 0ull) {
+        if (oct) {
+          if (need) bvh_traverse_oct(tgt, x, y, z, w, &s_stk[0][threadIdx.x & ~7u], BLOCK, h);
+        } else {
+          const bool done = PACKET && bvh_traverse_packet(tgt, x, y, z, need, w, h, stk, BLOCK);
+          if (!done && need) {
+            // (a packet that gave up has shown this lane some leaves already: start over, so that no point is shown twice)
+            if (PACKET) w = NearestCertVisitor{best_init, kNoPos, 0, INFINITY, INFINITY};
+            bvh_traverse_deferred(tgt, x, y, z, w, stk, BLOCK, h, min(8, kMaxDepth + 1 - tgt.depth));
+          }
+        }
+      }
+      const bool wfound = need && w.pos != kNoPos;
+      if (owner) {
+        if (need) {
+          // the next launch's L: every other point's computed d2 is at least min(second, lb) -> its true distance at least
+          // sqrt of that less 2.5u, and the square root itself is good to 1 ulp
+          const float Lw = __fmul_rn(__builtin_amdgcn_sqrtf(fminf(w.second, w.lb)), 0.9999995f);
+          cert[i] = wfound ? make_uint2(w.pos + 1u, __float_as_uint(Lw)) : make_uint2(0u, 0u);
+        } else if (c_moved) {
+          cert[i] = make_uint2(c_pos1, __float_as_uint(c_L));
+        }
+      }
+      {
+        const uint32_t nc = (uint32_t)__popcll(__ballot(owner && !need));
+        if (lane_id == 0 && nc != 0u) atomicAdd(&s_ncert, nc);
+      }
+      const uint32_t r_leaf = need ? w.leaf : h;
+      if (owner && r_leaf != h) hint[i] = r_leaf;
+      const bool found = active && (need ? wfound : true);
+      const float r_best = need ? w.best : c_best;
+      pos = found ? (need ? w.pos : c_pos1 - 1u) : 0;
+      ok = found && !((double)r_best > max_d2);
+      d2 = found ? r_best : INFINITY;
+      match = found ? (store_pos ? (int)pos : __float_as_int(tgt.pts[pos].w)) : -1;
+    } else if (MODE == 0) {
       NearestVisitor v{active ? cst[15] : -INFINITY, kNoPos, 0};
       // start at the leaf that held this query's nearest neighbour one iteration ago (0 = none yet)
       const uint32_t h = active ? hint[i] : 0u;
@@ -441,6 +532,8 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     if (S_atomic != nullptr) unsafeAtomicAdd(S_atomic + threadIdx.x, v);
     else partials[threadIdx.x * kAccMaxBlocks + blockIdx.x] = v;
   }
+  if (MODE == 0 && !RECIP && cert_on && threadIdx.x == 64 && s_ncert != 0u)
+    atomicAdd(reinterpret_cast<unsigned long long *>(work_counter + 40), (unsigned long long)s_ncert);   // ope_icp_certificate_stats
   acc_launch_end(chain);
 }
 
@@ -530,7 +623,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     const uint32_t *__restrict__ qorder, unsigned char *__restrict__ qclass, const uint32_t *__restrict__ chunk_order,
     uint32_t *__restrict__ chunk_cost, const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, uint32_t measuring_launch,
     uint32_t *chain, uint32_t chain_seq) {
-  __shared__ __attribute__((aligned(16))) float s_const[16];   // F rows [0..11], pivot [12..14], best0 [15]
+  __shared__ __attribute__((aligned(16))) float s_const[32];   // F rows [0..11], pivot [12..14], best0 [15]; [16..29]: see icp_accumulate_kernel
   if (!acc_launch_begin(st, chain, chain_seq, s_const)) return;
   constexpr int BLOCK = kAccBlock;
   __shared__ double s_red[BLOCK / 64][kNumSumsMax];
@@ -1007,6 +1100,27 @@ __device__ __forceinline__ void icp_update_lane(IcpState *st, const double *S, c
       for (int k = 0; k < 4; ++k) a += (double)Tf[4 * k + r] * st->F[4 * c + k];
       Fn[4 * c + r] = a;
     }
+  {
+    // Skip certificates (ope.h: skip_certificates): from the update on that moves no scene point by more than cert_thr the
+    // accumulate launches keep per-query certificates.  The largest displacement over the scene's bounding sphere, centre c and
+    // radius r in the scene's own frame: |Fn c - F c| + ||Rn - R||_F r (a trigger only: exactness never rests on it).  Sticky.
+    const double cx = (double)st->src_c[0], cy = (double)st->src_c[1], cz = (double)st->src_c[2];
+    double mv2 = 0.0, dr2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double d0 = Fn[r] - st->F[r], d1 = Fn[4 + r] - st->F[4 + r], d2 = Fn[8 + r] - st->F[8 + r], d3 = Fn[12 + r] - st->F[12 + r];
+      const double m = d0 * cx + d1 * cy + d2 * cz + d3;
+      mv2 += m * m;
+      dr2 += d0 * d0 + d1 * d1 + d2 * d2;
+    }
+    const float move = (float)(fast_sqrt(mv2) + fast_sqrt(dr2) * (double)st->src_r);
+    st->last_move = move;
+    if (move < st->cert_thr) st->cert_mode = 1;
+    // in line: certificates are of the transform this update replaces iff an accumulate launch in cert mode has run since the
+    // last update (two updates in a row, or a transform set from outside, leave them behind: every query then walks once)
+    st->cert_prev_ok = st->cert_acc_flag;
+    st->cert_acc_flag = 0;
+  }
 #pragma unroll
   for (int i = 0; i < 16; ++i) st->F[i] = Fn[i];
 #pragma unroll
@@ -1169,7 +1283,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(192))) void icp_
     // the sums as the blocks' atomics left them (the state's own array: overlapped runs have no caller-owned sums buffer)
     if (t < kNumSumsMax) s_S[t] = t < nsums ? __hip_atomic_load(&st->S[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     __syncthreads();
-    if (t == 0) icp_update_lane(&s_st, s_S, nullptr);
+    if (t == 0) {
+      icp_update_lane(&s_st, s_S, nullptr);
+      s_st.cert_prev_ok = 1;   // this update follows accumulate launch `seq` by construction (see acc_launch_begin)
+    }
     __syncthreads();
     // The state goes back with plain stores — the next update and the host read it after this kernel has ended — EXCEPT the
     // sums: a zero left dirty in this XCD's L2 would be written back at the end of this kernel, over what the next launch's
@@ -1180,6 +1297,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(192))) void icp_
     if (t < nsums) __hip_atomic_store(&st->S[t], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t < 12) __hip_atomic_store(&st->Ff[t], s_st.Ff[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == 12) __hip_atomic_store(&st->done, s_st.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t >= 16 && t < 28) __hip_atomic_store(&st->Fprev[t - 16], s_st.Fprev[t - 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 28) __hip_atomic_store(&st->cert_mode, s_st.cert_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 29) __hip_atomic_store(&st->cert_prev_ok, s_st.cert_prev_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else if (mode == 2u && t == 0) {
     __hip_atomic_store(&st->chain_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&st->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1519,7 +1639,7 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
                            const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
                            int k_normal_shooting, double *S_atomic, const uint32_t *slot_list, float *knn_rk, const uint32_t *plan_out,
-                           hipEvent_t e0, hipEvent_t e1, bool measuring, uint32_t *chain, uint32_t chain_seq) {
+                           hipEvent_t e0, hipEvent_t e1, bool measuring, uint32_t *chain, uint32_t chain_seq, uint2 *cert) {
   const uint32_t mflag = measuring ? 1u : 0u;
   // e0 / e1 (ope_icp_profile): the launch's own start and stop time stamps, taken by the dispatch itself (hipExtLaunchKernelGGL).
   // Round 3 measured what a hipEventRecord before and after every launch costs the loop it times: 7-11 us per iteration (two
@@ -1528,10 +1648,10 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
   do {                                                                                                                        \
     if (e0 != nullptr)                                                                                                        \
       hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, e0, e1, 0, src, tgt, srcix, st, partials, corr_match, \
-                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq); \
+                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert); \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, partials, corr_match, corr_d2,   \
-                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq); \
+                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert); \
   } while (0)
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS) OPE_KLAUNCH((icp_accumulate_kernel<M, N, R>), BLK, LDS)
   if (mode == 0 && !recip && packet) {

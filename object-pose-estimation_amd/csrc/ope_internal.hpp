@@ -91,7 +91,17 @@ struct IcpState {
   float Fprev[12];
   int have_prev;       // Fprev and the stored k-th distances belong together (set by the update that follows an accumulate launch)
   int knn_acc_flag;    // written by a k-NN accumulate launch: "the stored k-th distances are of the current transform"
+  // Skip certificates of the plain 1-NN search (icp_kernels.hip, "skip certificates"; round 4).
+  int cert_mode;       // accumulate launches keep and use per-query certificates (sticky: set by the update step once an iteration moves the scene by less than cert_thr)
+  int cert_prev_ok;    // Fprev is the transform of the launch the stored certificates were last brought up to (the update before this launch followed an accumulate launch)
+  int cert_acc_flag;   // written by an in-line accumulate launch in cert mode: "the certificates are of the current transform"
+  float cert_thr;      // metres; < 0: never, +inf: from the first launch on
+  float src_c[3];      // centre of the source cloud's bounding box (its own frame)
+  float src_r;         // half its diagonal
+  float last_move;     // the estimate cert_thr was last compared with: largest displacement of a source point by the last update
+  int pad2_;
 };
+static_assert(sizeof(IcpState) % 8 == 0, "IcpState holds doubles");
 
 // Peer-to-peer exchange of the sums (comm.cpp, icp_p2p_update_kernel): every rank owns one slot per parity in every
 // rank's buffer; a slot is 2 * kP2pMaxSums 8-byte words {low: 32 data bits, high: sequence number of the exchange}.
@@ -173,6 +183,8 @@ struct ope_ctx {
   uint32_t chain_seq = 0;        // overlapped accumulate launches of this run so far (= updates published once they are done)
   int64_t kernel_launches[OPE_KERNEL_KINDS] = {0, 0, 0, 0};   // per search kernel, this run (ope_icp_kernel_launches)
   uint32_t *d_hint = nullptr;       // per sorted query: leaf (heap id) of the previous iteration's match, 0 = none
+  bool cert_run = false;            // the run in progress keeps skip certificates (ope_icp_begin)
+  uint2 *d_cert = nullptr;          // per sorted query: {1 + position of its match in the index's point order (0: no certificate), bits of the lower bound L (float, metres) on its distance to every OTHER target point}
   float *d_knn_rk = nullptr;        // k-NN runs: per sorted query the squared distance of the last list entry of the previous launch (+inf: none)
   size_t knn_rk_cap = 0;
   // grid path of the 1-NN search (icp_accumulate_grid_kernel)

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(ope):
     lib = ctypes.CDLL(ope.LIB_PATH)
     missing = [n for n in declared_symbols() if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.ope_abi_version() == 4
+    assert lib.ope_abi_version() == 5
 
 
 def test_python_binding_table_covers_the_header(ope):
