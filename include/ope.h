@@ -208,15 +208,17 @@ typedef struct {
   int update_launch;
   /* Skip certificates of the plain 1-NN search (what CorrespondenceEstimation::determineCorrespondences,
    * impl/correspondence_estimation_mod.hpp:165-177, recomputes from scratch every iteration).  Late in a run a query's nearest
-   * neighbour rarely changes, and that can be PROVEN without a search: a search also yields a lower bound L on the query's
-   * distance to every OTHER target point (the runner-up among the points it saw, the smallest bound among the boxes it pruned);
-   * each later launch takes the query's own displacement off L and, while the previous match re-measured from where the query
-   * is now stays strictly below what is left — past every fp32 rounding —, that match is the unique nearest neighbour: same
-   * index, same d2, bit for bit, and no walk.  Every launch still writes every correspondence and adds every term of the sums.
-   * OPE_CERT_AUTO (0, default): certificates are kept from the iteration on whose update moves no scene point by more than a
-   * quarter of the target's point spacing (decided on the device, no host round trip; earlier they would expire at once).
-   * OPE_CERT_OFF (1): never.  OPE_CERT_ALWAYS (2): from the first launch (tests).  Plain 1-NN runs only (not: reciprocal,
-   * normal shooting, deterministic_sums); exact in every mode — the choice moves time only. */
+   * neighbour rarely changes, and that can be PROVEN without a search.  A certificate is the outcome of one 6-nearest walk from
+   * where the query was then (q_ref): its five nearest target points and a lower bound L — the sixth's distance — on its distance
+   * to every other one.  Wherever the query is later, every non-candidate is at least L - |q - q_ref| away; while the nearest of
+   * the five candidates, re-measured from where the query is now, stays strictly below that (past every fp32 rounding) and
+   * strictly below the other four, it is the unique nearest neighbour: same index, same d2, bit for bit, and no walk.  Every
+   * launch still writes every correspondence and adds every term of the sums.
+   * OPE_CERT_AUTO (0, default): launches keep certificates from the iteration on whose update moves no scene point by more than
+   * an eighth of the target's point spacing (decided on the device, no host round trip), and a query builds one when the slack it
+   * can expect — read off its previous distance — is worth eight launches of the scene's current displacement.
+   * OPE_CERT_OFF (1): never.  OPE_CERT_ALWAYS (2): from the first launch (tests).  Plain 1-NN runs on the OBB-tree kernel only
+   * (not: reciprocal, normal shooting, deterministic_sums, the grid kernel); exact in every mode — the choice moves time only. */
   int skip_certificates;
 } ope_icp_params;
 enum { OPE_WALK_AUTO = 0, OPE_WALK_LANE = 1, OPE_WALK_PACKET = 2 };
@@ -260,7 +262,7 @@ int64_t ope_icp_overlapped_updates(const ope_ctx *ctx);
 /* Skip certificates of the run in progress (ope_icp_params.skip_certificates; synchronises the stream): out[0] = queries answered
  * from their certificate, summed over the run's launches; out[1] = accumulate launches that kept certificates; out[2] = 1 if the
  * run has reached the stage where it keeps them; out[3] = the last update's largest scene displacement in nanometres (what the
- * automatic mode compares with a quarter of the target's point spacing). */
+ * automatic mode compares with an eighth of the target's point spacing). */
 int ope_icp_certificate_stats(ope_ctx *ctx, int64_t out[4]);
 
 /* Registration::align(output, guess) -> IterativeClosestPoint::computeTransformation

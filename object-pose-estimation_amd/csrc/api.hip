@@ -6,6 +6,7 @@
 #include <limits>
 #include <numeric>
 
+#include <chrono>
 #include <thread>
 
 #include "ope_internal.hpp"
@@ -16,7 +17,7 @@ namespace ope {
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
                            uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *, const uint32_t *, hipEvent_t, hipEvent_t, bool,
-                           uint32_t *, uint32_t, uint2 *);
+                           uint32_t *, uint32_t, float4 *, uint32_t *, uint32_t *, uint32_t);
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
 void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
@@ -29,7 +30,7 @@ hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t,
                             float4 **, float4 **, float4 **);
 void launch_icp_accumulate_grid(hipStream_t, int, bool, const CloudView &, const BvhView &, const GridView &, const IcpState *, double *, int32_t *,
                                 float *, uint32_t *, uint32_t *, const uint32_t *, unsigned char *, const uint32_t *, uint32_t *, const uint32_t *,
-                                double *, hipEvent_t, hipEvent_t, bool, uint32_t *, uint32_t);
+                                double *, hipEvent_t, hipEvent_t, bool, uint32_t *, uint32_t, uint32_t *, uint32_t);
 int grid_plan(hipStream_t, bool, const unsigned char *, uint32_t, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, const uint32_t *,
               uint32_t *, uint32_t, uint32_t, float, float, void *, size_t);
 size_t grid_plan_tmp_bytes(uint32_t, uint32_t);
@@ -179,8 +180,7 @@ static int grid_probe_poll(ope_ctx *ctx, int it_done) {
 static int switch_kernel(ope_ctx *ctx, bool to_grid, int it_done, uint32_t nch) {
   ctx->use_grid = to_grid;
   ctx->plan_valid = false;   // chunk ids mean something else to the other kernel
-  // skip certificates are kept up to date by the tree kernel's launches only: none survives a change of kernel
-  if (ctx->d_cert && ctx->run_src) OPE_HIP(ctx, hipMemsetAsync(ctx->d_cert, 0, sizeof(uint2) * std::max<size_t>(ctx->run_src->n, 1), ctx->stream));
+
   if (ctx->plan_pending) { OPE_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_plan_done, 0)); ctx->plan_pending = false; }
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * (size_t)(nch + 1), ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 8, 0, 8, ctx->stream));
@@ -202,7 +202,27 @@ static int switch_kernel(ope_ctx *ctx, bool to_grid, int it_done, uint32_t nch) 
   return OPE_OK;
 }
 
+// The host stays at most kPaceLead accumulate launches ahead of the GPU: it reads, without a HIP call, the word every launch
+// stores its number into when it starts (pinned memory).  What that buys: a bounded queue, and a device-side decision — the
+// update step asking for certifying launches — reaches the launches that are enqueued no more than that many launches late
+// (bench.py and ope_icp_run with check_every = 0 enqueue a whole run in one go: a hundred launches in the time the GPU
+// takes for ten).  The GPU never waits for the host: kPaceLead launches are a millisecond and more of work.  A wait is bounded
+// (a caller's stream may be held up by something the caller does after this call returns): two seconds, then no pacing.
+constexpr uint32_t kPaceLead = 16;
+static void pace_wait(ope_ctx *ctx) {
+  if (ctx->h_pace == nullptr || ctx->pace_off || ctx->launch_no < kPaceLead) return;
+  volatile uint32_t *seen = ctx->h_pace;
+  if ((int32_t)(ctx->launch_no - *seen) < (int32_t)kPaceLead) return;
+  const auto t0 = std::chrono::steady_clock::now();
+  while ((int32_t)(ctx->launch_no - *seen) >= (int32_t)kPaceLead) {
+    std::this_thread::yield();
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { ctx->pace_off = true; return; }
+  }
+}
+
 static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
+  pace_wait(ctx);
+  if (ctx->cert_run && !ctx->cert_seen && ctx->h_pace != nullptr && *(volatile uint32_t *)(ctx->h_pace + 1) != 0u) ctx->cert_seen = true;
   // re-sort the chunks by the cost they measured: after launches 1, 2, 4, ..., 32 and then every 32
   static const bool no_plan_env = dev_env("OPE_NO_PLAN") != nullptr;  // developer A/B switch
   const bool no_plan = no_plan_env || ctx->run_params.deterministic_sums != 0;
@@ -254,7 +274,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
                                ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8,
                                atomic_sums ? sums_ptr(ctx) : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr,
                                timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr, ctx->measuring_flag,
-                               ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq);
+                               ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, ctx->d_pace, ++ctx->launch_no);
     if (timed) ++ctx->prof_used;
     return OPE_OK;
   }
@@ -352,7 +372,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
                         (ctx->plan_valid && ctx->plan_cur_slots) ? ctx->d_plan_slots[ctx->plan_cur] : nullptr,
                         (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && !dev_env("OPE_NO_KNN_BOUND")) ? ctx->d_knn_rk : nullptr, ctx->d_plan_out + 8 * ctx->plan_cur,
                         timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr,
-                        ctx->measuring_flag, ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, ctx->cert_run ? ctx->d_cert : nullptr);
+                        ctx->measuring_flag, ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, (ctx->cert_run && ctx->cert_seen) ? ctx->d_cert_q : nullptr, ctx->d_cert_pos, ctx->d_pace, ++ctx->launch_no);
   if (timed) ++ctx->prof_used;
   return OPE_OK;
 }
@@ -404,6 +424,8 @@ int ope_ctx_create(ope_ctx **out, int device_ordinal) {
       hipEventCreateWithFlags(&ctx->ev_chain_u, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_acc_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_plan_done, hipEventDisableTiming) != hipSuccess ||
+      hipHostMalloc((void **)&ctx->h_pace, 64, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&ctx->d_pace, ctx->h_pace, 0) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState)) != hipSuccess) {
     ope_ctx_destroy(ctx);
     return set_err(nullptr, OPE_ENOMEM, "context allocation failed");
@@ -438,7 +460,8 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
   if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
   if (ctx->d_hint) (void)hipFree(ctx->d_hint);
-  if (ctx->d_cert) (void)hipFree(ctx->d_cert);
+  if (ctx->d_cert_q) (void)hipFree(ctx->d_cert_q);
+  if (ctx->d_cert_pos) (void)hipFree(ctx->d_cert_pos);
   if (ctx->d_knn_rk) (void)hipFree(ctx->d_knn_rk);
   for (void *p : {(void *)ctx->d_ghint, (void *)ctx->d_qorder, (void *)ctx->d_qclass, ctx->d_part_tmp, (void *)ctx->d_chunk_keys})
     if (p) (void)hipFree(p);
@@ -449,6 +472,7 @@ void ope_ctx_destroy(ope_ctx *ctx) {
     if (p) (void)hipFree(p);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->h_state) (void)hipHostFree(ctx->h_state);
+  if (ctx->h_pace) (void)hipHostFree(ctx->h_pace);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -972,12 +996,14 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     if (ctx->d_corr_match) (void)hipFree(ctx->d_corr_match);
     if (ctx->d_corr_d2) (void)hipFree(ctx->d_corr_d2);
     if (ctx->d_hint) (void)hipFree(ctx->d_hint);
-    if (ctx->d_cert) (void)hipFree(ctx->d_cert);
-    ctx->d_corr_match = nullptr; ctx->d_corr_d2 = nullptr; ctx->d_hint = nullptr; ctx->d_cert = nullptr; ctx->corr_cap = 0;
+    if (ctx->d_cert_q) (void)hipFree(ctx->d_cert_q);
+    if (ctx->d_cert_pos) (void)hipFree(ctx->d_cert_pos);
+    ctx->d_corr_match = nullptr; ctx->d_corr_d2 = nullptr; ctx->d_hint = nullptr; ctx->d_cert_q = nullptr; ctx->d_cert_pos = nullptr; ctx->corr_cap = 0;
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_corr_match, sizeof(int32_t) * std::max<size_t>(src->n, 1)));
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_corr_d2, sizeof(float) * std::max<size_t>(src->n, 1)));
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_hint, sizeof(uint32_t) * std::max<size_t>(src->n, 1)));
-    OPE_HIP(ctx, hipMalloc((void **)&ctx->d_cert, sizeof(uint2) * std::max<size_t>(src->n, 1)));
+    OPE_HIP(ctx, hipMalloc((void **)&ctx->d_cert_q, sizeof(float4) * std::max<size_t>(src->n, 1)));
+    OPE_HIP(ctx, hipMalloc((void **)&ctx->d_cert_pos, sizeof(uint32_t) * kCertCand * std::max<size_t>(src->n, 1)));
     ctx->corr_cap = std::max<size_t>(src->n, 1);
   }
   ctx->use_grid = false;
@@ -1120,9 +1146,16 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
                     !dev_env("OPE_NO_CERT");
     const double ex = (double)tgt->bb_hi[0] - tgt->bb_lo[0], ey = (double)tgt->bb_hi[1] - tgt->bb_lo[1], ez = (double)tgt->bb_hi[2] - tgt->bb_lo[2];
     const double spacing = std::sqrt(2.0 * (ex * ey + ey * ez + ez * ex) / (double)std::max<size_t>(tgt->n, 1));
-    h->cert_thr = !ctx->cert_run ? -1.0f : p.skip_certificates == OPE_CERT_ALWAYS ? std::numeric_limits<float>::infinity() : (float)(0.25 * spacing);
+    h->cert_thr = !ctx->cert_run ? -1.0f : p.skip_certificates == OPE_CERT_ALWAYS ? std::numeric_limits<float>::infinity() : (float)(0.125 * spacing);
     if (const char *e = dev_env("OPE_CERT_THR")) h->cert_thr = (float)atof(e);   // developer sweep (metres)
     h->cert_mode = (ctx->cert_run && p.skip_certificates == OPE_CERT_ALWAYS) ? 1 : 0;
+    ctx->cert_seen = h->cert_mode != 0;
+    h->host_cert = (ctx->cert_run && !ctx->cert_seen) ? ctx->d_pace + 1 : nullptr;
+    // what a certificate is worth (icp_accumulate_kernel): the (kCertCand + 1)-th neighbour of a query D from a surface sampled at
+    // `spacing` lies ~ kCertCand spacing^2 / (2 pi D) further out than the nearest one, never more than about the spacing itself
+    h->cert_cap = (float)spacing;
+    h->cert_k = (float)((double)kCertCand * spacing * spacing / (2.0 * 3.14159265358979323846));
+    if (const char *e = dev_env("OPE_CERT_CAP")) h->cert_cap = (float)atof(e);   // developer sweep (metres)
     double r2 = 0;
     for (int d = 0; d < 3; ++d) {
       h->src_c[d] = 0.5f * (src->bb_lo[d] + src->bb_hi[d]);
@@ -1130,7 +1163,12 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
       r2 += hd * hd;
     }
     h->src_r = (float)std::sqrt(r2);
-    if (ctx->cert_run) OPE_HIP(ctx, hipMemsetAsync(ctx->d_cert, 0, sizeof(uint2) * std::max<size_t>(src->n, 1), ctx->stream));
+    // positions index THIS target's point order: certificates never outlive the pairing ("no candidate 0" = no certificate);
+    // the per-query worth of a certificate is read off the previous launch's distance: none yet
+    if (ctx->cert_run) {
+      OPE_HIP(ctx, hipMemsetAsync(ctx->d_cert_pos, 0, sizeof(uint32_t) * std::max<size_t>(src->n, 1), ctx->stream));
+      OPE_HIP(ctx, hipMemsetAsync(ctx->d_corr_d2, 0x7f, sizeof(float) * std::max<size_t>(src->n, 1), ctx->stream));   // 0x7f7f7f7f = 3.4e38
+    }
   }
   {
     // inverse of the guess (adjugate), rows layout
@@ -1163,6 +1201,10 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_partials, 0, sizeof(double) * kNumSumsMax * kAccMaxBlocks, ctx->stream));
   // the pinned block is reused for read-back: make sure the upload is finished with it first
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // (every launch of the previous run is over: nothing writes the pace words any more)
+  ctx->h_pace[0] = 0u; ctx->h_pace[1] = 0u;
+  ctx->launch_no = 0;
+  ctx->pace_off = dev_env("OPE_NO_PACE") != nullptr;
 
 #ifdef OPE_DEVELOPER
   if (dev_env("OPE_DUMP_HASH")) {   // developer probe: checksums of everything the run reads, to stderr

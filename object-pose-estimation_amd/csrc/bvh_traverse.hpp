@@ -69,8 +69,6 @@ __device__ __forceinline__ void load_node(const BvhView &t, uint32_t node, v4f &
 // Visitors for which presenting a point a second time changes nothing (1-NN with a strict comparison) take a leaf scan
 // without per-point range checks; see the leaf branch of bvh_walk.
 template <class Visitor> struct leaf_rescan_is_harmless { static constexpr bool value = false; };
-// Visitors that certify their result (NearestCertVisitor below): a walker must tell them about every subtree it skips.
-template <class Visitor> struct visitor_certifies { static constexpr bool value = false; };
 
 template <class Visitor>
 __device__ __forceinline__ void bvh_walk(const BvhView &t, float qx, float qy, float qz, Visitor &v, float *stk, int stk_stride,
@@ -210,11 +208,7 @@ __device__ __forceinline__ void bvh_walk(const BvhView &t, float qx, float qy, f
     }
     // back up to the deepest pending sibling whose parked bound still beats the current best (LDS only);
     // most queries end here without touching LDS: no parked bound is below `minb`
-    if constexpr (visitor_certifies<Visitor>::value) {
-      if (v.prune_peek(minb)) { fold_pending(v, node, trail, stk, stk_stride); return; }
-    } else {
-      if (v.prune(minb)) return;
-    }
+    if (v.prune(minb)) return;
     for (;;) {
       if (trail == 0) return;
       const int k = __builtin_ctz(trail);
@@ -228,13 +222,10 @@ __device__ __forceinline__ void bvh_walk(const BvhView &t, float qx, float qy, f
 constexpr uint32_t kNoPos = 0xffffffffu;
 
 struct NearestVisitor {
-  static constexpr bool kCert = false;
   float best;
   uint32_t pos;   // reordered target position of the best point, kNoPos if none
   uint32_t leaf;  // heap id of the leaf that holds it (next iteration's start hint)
   __device__ __forceinline__ bool prune(float bound) const { return !(bound < best); }
-  __device__ __forceinline__ bool prune_peek(float bound) const { return !(bound < best); }
-  __device__ __forceinline__ void fold(float) {}
   __device__ __forceinline__ float bound() const { return best; }   // a subtree is worth entering iff its lower bound is below this
   __device__ __forceinline__ void point(float d, const v4f &, uint32_t i, uint32_t lf) {
     if (d < best) { best = d; pos = i; leaf = lf; }
@@ -243,48 +234,6 @@ struct NearestVisitor {
 };
 
 template <> struct leaf_rescan_is_harmless<NearestVisitor> { static constexpr bool value = true; };
-
-// The same search, CERTIFIED (round 4): besides the nearest point the walk reports a lower bound on the computed squared
-// distance of EVERY OTHER target point, min(second, lb):
-//   second — the smallest d2 among the points the walk was shown other than the current best.  Every point is shown exactly
-//            once (no moved-back batches: a best point shown twice would be its own runner-up), and with best <= second the
-//            update is one v_med3_f32: new second = median(best, d, second);
-//   lb     — the smallest box bound among the subtrees the walk did NOT enter: every prune() that says "skip" records its
-//            bound, and a walk that stops while siblings are still parked folds their bounds in (fold) — the walkers below
-//            spell out each place.  A box bound never exceeds the computed d2 of a point inside the box (see the header).
-// With that, a later launch can prove the match unchanged without walking: icp_kernels.hip, "skip certificates".
-struct NearestCertVisitor {
-  static constexpr bool kCert = true;
-  float best;
-  uint32_t pos, leaf;
-  float second, lb;
-  __device__ __forceinline__ bool prune(float bound) {
-    const bool p = !(bound < best);
-    lb = p ? fminf(lb, bound) : lb;
-    return p;
-  }
-  __device__ __forceinline__ bool prune_peek(float bound) const { return !(bound < best); }   // a test that skips nothing by itself
-  __device__ __forceinline__ void fold(float bound) { lb = fminf(lb, bound); }
-  __device__ __forceinline__ float bound() const { return best; }
-  __device__ __forceinline__ void point(float d, const v4f &, uint32_t i, uint32_t lf) {
-    second = __builtin_amdgcn_fmed3f(best, d, second);
-    if (d < best) { best = d; pos = i; leaf = lf; }
-  }
-  __device__ __forceinline__ void on_node() {}
-};
-// the parked bounds of the siblings still pending when a walk stops at {node, trail}: subtrees it never entered
-template <> struct visitor_certifies<NearestCertVisitor> { static constexpr bool value = true; };
-template <class Visitor>
-__device__ __forceinline__ void fold_pending(Visitor &v, uint32_t node, uint32_t trail, const float *stk, int stk_stride) {
-  if constexpr (Visitor::kCert) {
-    while (trail != 0u) {
-      const int k = __builtin_ctz(trail);
-      node = (node >> k) ^ 1u;
-      trail = (trail >> k) & ~1u;
-      v.fold(stk[(31 - __clz(node)) * stk_stride]);
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // Per-lane 1-NN walk with DEFERRED leaf scans (round 3).  In the flat loop of bvh_walk a trip costs the wave a node step AND a
@@ -299,33 +248,6 @@ __device__ __forceinline__ void fold_pending(Visitor &v, uint32_t node, uint32_t
 #ifndef OPE_SCAN_BATCH
 #define OPE_SCAN_BATCH 8u
 #endif
-// every point of a leaf shown exactly once (certifying visitors): guarded batches of eight from one base address
-template <class Visitor>
-__device__ __forceinline__ void scan_leaf_once(const BvhView &t, uint32_t node, float qx, float qy, float qz, Visitor &v) {
-  const uint32_t j = node - (1u << t.depth);
-  const uint32_t s = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
-  const uint32_t e = (uint32_t)(((unsigned long long)(j + 1) * t.n) >> t.depth);
-#define OPE_LEAF_POINT(P, IDX) v.point(sq_dist3(__fsub_rn(qx, P.x), __fsub_rn(qy, P.y), __fsub_rn(qz, P.z)), P, IDX, node)
-  for (uint32_t i = s; i < e; i += 8) {
-    // (a batch may run past the leaf — guarded — and, at the last leaf, into the kPtsPad zeroed entries)
-    const float4 *pb = t.pts + i;
-    const v4f p0 = ld16(pb), p1 = ld16(pb + 1), p2 = ld16(pb + 2), p3 = ld16(pb + 3), p4 = ld16(pb + 4), p5 = ld16(pb + 5),
-              p6 = ld16(pb + 6), p7 = ld16(pb + 7);
-    OPE_LEAF_POINT(p0, i);
-    if (i + 1 < e) OPE_LEAF_POINT(p1, i + 1);
-    if (i + 2 < e) OPE_LEAF_POINT(p2, i + 2);
-    if (i + 3 < e) OPE_LEAF_POINT(p3, i + 3);
-    if (i + 4 < e) OPE_LEAF_POINT(p4, i + 4);
-    if (i + 5 < e) OPE_LEAF_POINT(p5, i + 5);
-    if (i + 6 < e) OPE_LEAF_POINT(p6, i + 6);
-    if (i + 7 < e) OPE_LEAF_POINT(p7, i + 7);
-  }
-#undef OPE_LEAF_POINT
-}
-
-__device__ __forceinline__ void scan_leaf_nearest(const BvhView &t, uint32_t node, float qx, float qy, float qz, NearestCertVisitor &v) {
-  scan_leaf_once(t, node, qx, qy, qz, v);
-}
 __device__ __forceinline__ void scan_leaf_nearest(const BvhView &t, uint32_t node, float qx, float qy, float qz, NearestVisitor &v) {
   const uint32_t j = node - (1u << t.depth);
   const uint32_t s = (uint32_t)(((unsigned long long)j * t.n) >> t.depth);
@@ -371,8 +293,7 @@ __device__ __forceinline__ void scan_leaf_nearest(const BvhView &t, uint32_t nod
   v.leaf = (v.pos != pos0) ? node : v.leaf;
 }
 
-template <class Visitor>
-__device__ __forceinline__ void bvh_traverse_deferred(const BvhView &t, float qx, float qy, float qz, Visitor &v, float *stk,
+__device__ __forceinline__ void bvh_traverse_deferred(const BvhView &t, float qx, float qy, float qz, NearestVisitor &v, float *stk,
                                                       int stk_stride, uint32_t start_leaf, int qcap) {
   const uint32_t leaf0 = 1u << t.depth;
   const int D = t.depth;
@@ -442,8 +363,7 @@ __device__ __forceinline__ void bvh_traverse_deferred(const BvhView &t, float qx
         node_done = false;
         if (!descend) {
           // back up to the deepest pending sibling whose parked bound still beats the current best
-          // (a certifying visitor is told about the siblings left parked when the walk is over, below)
-          if (v.prune_peek(minb)) walking = false;
+          if (v.prune(minb)) walking = false;
           else {
             for (;;) {
               if (trail == 0) { walking = false; break; }
@@ -461,9 +381,8 @@ __device__ __forceinline__ void bvh_traverse_deferred(const BvhView &t, float qx
       if (r < nq) scan_leaf_nearest(t, lq[r * stk_stride], qx, qy, qz, v);
     nq = 0;
     stall = false;
-    if (__ballot(walking) == 0ull) break;
+    if (__ballot(walking) == 0ull) return;
   }
-  fold_pending(v, node, trail, stk, stk_stride);   // (a walk that ran out of siblings comes here with trail == 0)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -626,18 +545,15 @@ __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, 
     if (k + 1 < D) stk[(D - k - 1) * stk_stride] = e1;
     minb = fminf(minb, fminf(e0, e1));
   }
-  // (a certifying visitor is told, lane by lane, the bound of every subtree the WAVE does not enter: fold)
   for (;;) {
     // back up to the deepest pending sibling that ANY lane can still improve in (inactive lanes carry best = -inf)
-    if (__ballot(minb < v.bound()) == 0ull) { fold_pending(v, node, trail, stk, stk_stride); return true; }
+    if (__ballot(minb < v.bound()) == 0ull) return true;
     bool more = false;
     while (trail != 0u) {
       const int k = __builtin_ctz(trail);
       node = (node >> k) ^ 1u;
       trail = (trail >> k) & ~1u;
-      const float pb = stk[(31 - __clz(node)) * stk_stride];
-      if (__ballot(pb < v.bound()) != 0ull) { more = true; break; }
-      if constexpr (Visitor::kCert) v.fold(pb);
+      if (__ballot(stk[(31 - __clz(node)) * stk_stride] < v.bound()) != 0ull) { more = true; break; }
     }
     if (!more) return true;
     OPE_PKT_COUNT(ps, backups);
@@ -654,10 +570,7 @@ __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, 
       OPE_PKT_COUNT(ps, steps);
       const float d0 = packet_node_bound(cl, qx, qy, qz), d1 = packet_node_bound(cr, qx, qy, qz);
       const unsigned long long n0 = __ballot(d0 < v.bound()), n1 = __ballot(d1 < v.bound());
-      if ((n0 | n1) == 0ull) {
-        if constexpr (Visitor::kCert) v.fold(fminf(d0, d1));
-        break;
-      }
+      if ((n0 | n1) == 0ull) break;
       // nearer child first by majority; the other one is parked if any lane wants it
       const bool right = (n0 == 0ull) || (n1 != 0ull && 2 * __popcll(__ballot(d1 < d0) & act) > __popcll(act));
       const bool pend = right ? (n0 != 0ull) : (n1 != 0ull);
@@ -665,7 +578,6 @@ __device__ __forceinline__ bool bvh_traverse_packet(const BvhView &t, float qx, 
       node = 2 * node + (right ? 1u : 0u);
       trail = (trail << 1) | (pend ? 1u : 0u);
       if (pend) { stk[(31 - __clz(node)) * stk_stride] = df; minb = fminf(minb, df); }
-      else if constexpr (Visitor::kCert) v.fold(df);
     }
   }
 }
@@ -685,8 +597,7 @@ __device__ __forceinline__ float group8_min(float v) {
   return v;
 }
 
-template <class Visitor>
-__device__ __forceinline__ void bvh_traverse_oct(const BvhView &t, float qx, float qy, float qz, Visitor &v, float *stk,
+__device__ __forceinline__ void bvh_traverse_oct(const BvhView &t, float qx, float qy, float qz, NearestVisitor &v, float *stk,
                                                  int stk_stride, uint32_t start_leaf) {
   const uint32_t g = threadIdx.x & 7u;
   const uint32_t leaf0 = 1u << t.depth;
@@ -755,17 +666,8 @@ __device__ __forceinline__ void bvh_traverse_oct(const BvhView &t, float qx, flo
         float d0 = (i0 < e) ? sq_dist3(__fsub_rn(qx, p0.x), __fsub_rn(qy, p0.y), __fsub_rn(qz, p0.z)) : INFINITY;
         const float d1 = (i1 < e) ? sq_dist3(__fsub_rn(qx, p1.x), __fsub_rn(qy, p1.y), __fsub_rn(qz, p1.z)) : INFINITY;
         uint32_t ip = i0;
-        float dhi = d1;   // the lane's other point
-        if (d1 < d0) { dhi = d0; d0 = d1; ip = i1; }
+        if (d1 < d0) { d0 = d1; ip = i1; }
         const float dm = group8_min(d0);
-        if constexpr (Visitor::kCert) {
-          // runner-up of these (up to) sixteen points: the winner lane's other point or another lane's nearer one; then
-          // {best, second} of the walk merged with {dm, d2nd}
-          const unsigned long long mw = __ballot(d0 == dm) >> ((threadIdx.x & 63u) & ~7u);
-          const uint32_t ww = (uint32_t)__builtin_ctz((uint32_t)(mw & 0xffu));
-          const float d2nd = group8_min(g == ww ? dhi : d0);
-          v.second = fminf(fminf(v.second, d2nd), fmaxf(v.best, dm));
-        }
         if (dm < v.best) {
           const unsigned long long m = __ballot(d0 == dm) >> ((threadIdx.x & 63u) & ~7u);
           const uint32_t w = (uint32_t)__builtin_ctz((uint32_t)(m & 0xffu));
@@ -775,7 +677,7 @@ __device__ __forceinline__ void bvh_traverse_oct(const BvhView &t, float qx, flo
         }
       }
     }
-    if (v.prune_peek(minb)) { fold_pending(v, node, trail, stk, stk_stride); return; }
+    if (v.prune(minb)) return;
     for (;;) {
       if (trail == 0) return;
       const int k = __builtin_ctz(trail);

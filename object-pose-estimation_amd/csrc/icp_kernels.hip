@@ -29,6 +29,7 @@ __device__ uint32_t *g_chunk_stats = nullptr;
 #endif
 
 typedef const __attribute__((address_space(3))) float *lds_cfloat_ptr;   // a pointer that stays an LDS pointer
+static_assert(kCertCand >= 1 && kCertCand <= 8, "skip certificates: candidates per query");
 
 // ---- update launches overlapped with the accumulate launches (round 3; host side: api.hip, ope_icp_iterate) -------------
 // In line, an iteration is accumulate -> update -> accumulate on one stream, and the two kernel boundaries around the
@@ -66,9 +67,7 @@ __device__ __forceinline__ bool acc_launch_begin(const IcpState *st, uint32_t *c
   __syncthreads();   // (the loads below are issued after the word has arrived)
   if (threadIdx.x < 12) s_const[threadIdx.x] = __hip_atomic_load(&st->Ff[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else if (threadIdx.x == 12) s_go[1] = (uint32_t)__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else if (threadIdx.x >= 16 && threadIdx.x < 28) s_const[threadIdx.x] = __hip_atomic_load(&st->Fprev[threadIdx.x - 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else if (threadIdx.x == 28) s_const[28] = __int_as_float(__hip_atomic_load(&st->cert_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  else if (threadIdx.x == 29) s_const[29] = __int_as_float(__hip_atomic_load(&st->cert_prev_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else if (threadIdx.x == 17) s_const[17] = __hip_atomic_load(&st->last_move, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   return s_go[0] != 0u && s_go[1] == 0u;
 }
@@ -149,19 +148,23 @@ __device__ __forceinline__ void add_query_sums(double *acc, lds_cfloat_ptr cs2, 
 #ifdef OPE_KNN_STATS
 __device__ unsigned long long g_knn_stats[8];
 #endif
-template <int MODE, bool NRM, bool RECIP = false, bool PACKET = false, int KREG = 20>
+template <int MODE, bool NRM, bool RECIP = false, bool PACKET = false, int KREG = 20, bool CERT = false>
 __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !RECIP) ? kAccWavesPerSimd : 4) void icp_accumulate_kernel(
     CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
     const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list,
     float *__restrict__ knn_rk, const uint32_t *__restrict__ plan_out, uint32_t measuring_launch, uint32_t *chain_arg, uint32_t chain_seq,
-    uint2 *__restrict__ cert_arg) {
+    float4 *__restrict__ cert_q, uint32_t *__restrict__ cert_pos, uint32_t *pace, uint32_t launch_no) {
+  // pace (host-visible): "launch launch_no has started", i.e. every launch before it is over — the host keeps a bounded lead
+  // over the GPU by it (api.hip: pace_wait), which is what lets it notice, a few launches late at most, that the update step
+  // has asked for certifying launches (IcpState::cert_mode -> host_cert)
+  if (pace != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(pace, launch_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   uint32_t *const chain = (MODE == 0 && !RECIP) ? chain_arg : nullptr;   // overlapped update launches exist for the plain 1-NN run only (api.hip)
-  uint2 *const cert = (MODE == 0 && !RECIP) ? cert_arg : nullptr;        // and so do skip certificates
+  static_assert(!CERT || (MODE == 0 && !RECIP), "skip certificates: plain 1-NN only");
   // Per-run constants live in LDS and are re-read where they are used (through a pointer the optimiser cannot see
   // through): held in registers across the walk they were spilled to scratch, 13 dwords per lane and launch.
-  __shared__ __attribute__((aligned(16))) float s_const[32];   // F rows [0..11], pivot [12..14], best0 [15], previous launch's F rows [16..27], cert_mode [28], cert_prev_ok [29] (int bits)
+  __shared__ __attribute__((aligned(16))) float s_const[20];   // F rows [0..11], pivot [12..14], best0 [15], last_move [17], cert_k [18], cert_cap [19] (CERT)
   __shared__ uint32_t s_ncert;
   if (!acc_launch_begin(st, chain, chain_seq, s_const)) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
@@ -184,27 +187,23 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   if (threadIdx.x < 12) { if (chain == nullptr) s_const[threadIdx.x] = st->Ff[threadIdx.x]; }   // (overlapped: fetched by acc_launch_begin)
   else if (threadIdx.x < 15) s_const[threadIdx.x] = (float)st->pivot[threadIdx.x - 12];
   else if (threadIdx.x == 15) s_const[15] = best0;
-  else if (threadIdx.x < 28) { if (chain == nullptr) s_const[threadIdx.x] = st->Fprev[threadIdx.x - 16]; }
-  else if (threadIdx.x == 28) { if (chain == nullptr) s_const[28] = __int_as_float(st->cert_mode); }
-  else if (threadIdx.x == 29) { if (chain == nullptr) s_const[29] = __int_as_float(st->cert_prev_ok); }
+  else if (threadIdx.x == 17) { if (chain == nullptr) s_const[17] = st->last_move; }
   else if (threadIdx.x == 30) s_ncert = 0u;
   __syncthreads();
   if (MODE == 2 && knn_rk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) const_cast<IcpState *>(st)->knn_acc_flag = 1;
-  // ---- skip certificates (plain 1-NN; ope.h: ope_icp_params.skip_certificates).  A launch in cert mode brings every query's
-  // certificate up to the transform it searches with — by answering from it or by a certifying walk — so the next launch only
-  // has to take one launch's displacement off it.  cert_on is launch-uniform; the walks below exist once per visitor type.
-#ifdef OPE_NO_CERT_KERNEL   // (A/B build: the kernel as it was without the certified branch)
-  const bool cert_on = false;
-#else
-  const bool cert_on = cert != nullptr && __float_as_int(s_const[28]) != 0;
-#endif
-  const bool cert_prev_ok = cert_on && __float_as_int(s_const[29]) != 0;
-  if (cert_on && blockIdx.x == 0 && threadIdx.x == 0) {
-    // in line: the update that follows learns that the certificates are of this launch's transform (overlapped runs alternate
-    // accumulate and update launches by construction: icp_update_chained_kernel says so itself)
-    if (chain == nullptr) const_cast<IcpState *>(st)->cert_acc_flag = 1;
-    atomicAdd(work_counter + 42, 1u);
+  // ---- skip certificates (plain 1-NN; ope.h: ope_icp_params.skip_certificates).  A certificate is a statement about the
+  // target alone: "from q_ref, the kCertCand points {c_j} are the nearest and every other target point is at least L away" — the
+  // outcome of ONE (kCertCand + 1)-nearest walk from q_ref.  It says nothing about transforms or launches, so whatever happened
+  // in between (updates, step-wise calls, a change of kernel and back) it proves what it proves about where the query is NOW.
+  // The CERT instantiation is launched once the update step has asked for it (IcpState::cert_mode, seen by the host through
+  // host_cert): the instantiation without carries none of this.
+  constexpr bool cert_on = CERT;
+  if (cert_on && threadIdx.x == 0) {
+    s_const[18] = st->cert_k;
+    s_const[19] = st->cert_cap;
+    if (blockIdx.x == 0) atomicAdd(work_counter + 42, 1u);
   }
+  if (cert_on) __syncthreads();
   const bool rej_sn = NRM && st->use_surface_normal_rej;
   const bool rej_so = NRM && st->use_self_occluded_rej;
   // the LM estimator (lm.hip) re-reads the matched target points: corr_match then holds their POSITION in the index
@@ -300,73 +299,131 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     float d2;
     uint32_t pos = 0;
     int match = -1;
-    if (MODE == 0 && OCT_OK && cert_on) {
-      // ---- certified search.  c = {1 + position of the previous match, L}: at the previous launch every OTHER target point
-      // was at least L away from this query.  The query has moved by dl since (recomputed from the previous launch's transform),
-      // so every other point is at least L - dl away now; if the previous match, re-measured with the search's own arithmetic,
-      // is strictly nearer than that — past the rounding of every quantity involved (u = 2^-24: a computed d2 is within 5u of
-      // the true one, v_sqrt_f32 within 1 ulp; the factors below leave 16u) — it is the unique nearest neighbour: what a walk
-      // would return, bit for bit.  Otherwise the query walks, with the visitor that reports the next L.
+    if constexpr (CERT) {
+      // ---- certified search.  {q_ref, L} and the candidates c_j: when this query last built a certificate, from q_ref, every
+      // target point but the candidates was at least L away.  The query is dl from q_ref now, so every non-candidate is at least
+      // L - dl away; if the nearest candidate, re-measured with the search's own arithmetic, is strictly nearer than that — past
+      // the rounding of every quantity involved (u = 2^-24: a computed d2 is within 5u of the true one, v_sqrt_f32 within 1 ulp;
+      // the factors below leave 16u) — and strictly nearer than every other candidate, it is the unique nearest neighbour: what
+      // a walk would return, bit for bit.  Nothing is written but the correspondence.
       const uint32_t h = active ? hint[i] : 0u;
       const float best_init = active ? cst[15] : -INFINITY;
+      const size_t cstride = src.n;
       bool need = active;
-      float c_best = INFINITY, c_L = 0.f;
-      uint32_t c_pos1 = 0u;
-      bool c_moved = false;
-      if (active && cert_prev_ok) {
-        const uint2 c = cert[i];
-        if (c.x != 0u) {
-          const v4f tp = ld16(tgt.pts + (c.x - 1u));
-          const float dn = sq_dist3(__fsub_rn(x, tp.x), __fsub_rn(y, tp.y), __fsub_rn(z, tp.z));
-          float G[12];
+      bool stuck = false;   // a certificate that fails where it was built: a new one from here would be no better
+      float c_best = INFINITY;
+      uint32_t c_pos = 0u;
+      if (active) {
+        const uint32_t p0 = cert_pos[i];
+        if (p0 != 0u) {
+          const v4f c = ld16(cert_q + i);
+          uint32_t pj[kCertCand];
+          pj[0] = p0;
 #pragma unroll
-          for (int k = 0; k < 12; ++k) G[k] = cst[16 + k];
-          const float ox = xform_row(G + 0, s.x, s.y, s.z), oy = xform_row(G + 4, s.x, s.y, s.z), oz = xform_row(G + 8, s.x, s.y, s.z);
-          const float dl = __builtin_amdgcn_sqrtf(sq_dist3(__fsub_rn(x, ox), __fsub_rn(y, oy), __fsub_rn(z, oz)));
-          const float L0 = __uint_as_float(c.y);
-          // L0 - dl rounded DOWN (one float below the rounded difference); a query that has not moved keeps its L
-          const float L1 = dl == 0.f ? L0 : __uint_as_float(__float_as_uint(__fsub_rn(L0, __fmaf_rn(dl, 1.000001f, 1e-30f))) - 1u);
-          const float T = __fmul_rn(__fmul_rn(L1, L1), 0.999999f);
-          if (L1 > 0.f && dn < T && dn < best_init) { need = false; c_best = dn; c_L = L1; c_pos1 = c.x; c_moved = dl != 0.f; }
-        }
-      }
-      NearestCertVisitor w{need ? best_init : -INFINITY, kNoPos, 0, INFINITY, INFINITY};
-      if (__ballot(need) != 0ull) {
-        if (oct) {
-          if (need) bvh_traverse_oct(tgt, x, y, z, w, &s_stk[0][threadIdx.x & ~7u], BLOCK, h);
-        } else {
-          const bool done = PACKET && bvh_traverse_packet(tgt, x, y, z, need, w, h, stk, BLOCK);
-          if (!done && need) {
-            // (a packet that gave up has shown this lane some leaves already: start over, so that no point is shown twice)
-            if (PACKET) w = NearestCertVisitor{best_init, kNoPos, 0, INFINITY, INFINITY};
-            bvh_traverse_deferred(tgt, x, y, z, w, stk, BLOCK, h, min(8, kMaxDepth + 1 - tgt.depth));
+          for (int j = 1; j < kCertCand; ++j) pj[j] = cert_pos[(size_t)j * cstride + i];
+          float b1 = INFINITY, b2 = INFINITY;   // nearest and runner-up among the candidates, from where the query is now
+          uint32_t bp = 0u;
+#pragma unroll
+          for (int j = 0; j < kCertCand; ++j) {
+            const v4f tp = ld16(tgt.pts + ((pj[j] != 0u ? pj[j] : p0) - 1u));
+            const float dj = pj[j] != 0u ? sq_dist3(__fsub_rn(x, tp.x), __fsub_rn(y, tp.y), __fsub_rn(z, tp.z)) : INFINITY;
+            const bool lt = dj < b1;
+            b2 = lt ? b1 : fminf(b2, dj);
+            bp = lt ? pj[j] - 1u : bp;
+            b1 = lt ? dj : b1;
           }
+          const float dl = __builtin_amdgcn_sqrtf(sq_dist3(__fsub_rn(x, c.x), __fsub_rn(y, c.y), __fsub_rn(z, c.z)));
+          // L - dl rounded DOWN (one float below the rounded difference); a query that sits where it walked keeps its L
+          const float L1 = dl == 0.f ? c.w : __uint_as_float(__float_as_uint(__fsub_rn(c.w, __fmaf_rn(dl, 1.000001f, 1e-30f))) - 1u);
+          const float T = __fmul_rn(__fmul_rn(L1, L1), 0.999999f);
+          // (b1 == b2: two candidates at the very same computed d2.  Which of them a search returns is a matter of its visiting
+          // order — the reference's kd-tree, the walks here and the oracle each have their own — and the distance is the same
+          // bit for bit: the certificate takes the first in its list, as the tests allow every search on exact ties.)
+          if (L1 > 0.f && b1 < T && b1 < best_init) { need = false; c_best = b1; c_pos = bp; }
+          else stuck = !(dl > 4.0f * cst[17]);
+#ifdef OPE_DEVELOPER   // tools/cert_probe.py: why certificates fail {expired: the bound, a tie among the candidates}
+          if (need && owner) atomicAdd(work_counter + (stuck ? 45 : 44), 1u);
+#endif
+        }
+#ifdef OPE_DEVELOPER
+        else if (owner) atomicAdd(work_counter + 46, 1u);   // no certificate
+#endif
+      }
+      // A query without a valid certificate walks.  Whether that walk BUILDS a certificate (a (kCertCand + 1)-nearest walk, dearer
+      // than the 1-NN walks) is decided per query from what a certificate would be worth: its slack — distance of the
+      // (kCertCand + 1)-th neighbour less the nearest's, ~ cert_k / D for a query D from the surface, at most cert_cap — against
+      // the scene's displacement per launch.  Surface points build soon after the launches start keeping certificates; a point
+      // 10 cm out, whose neighbours all lie within microns of each other in distance, once the scene moves by less than that.
+      bool build = false;
+      if (need) {
+        const float dprev = __builtin_amdgcn_sqrtf(corr_d2[i]);           // (+inf before the first match: no slack, no certificate yet)
+        const float slack = fminf(cst[19], cst[18] * __builtin_amdgcn_rcpf(dprev));
+        build = slack >= 8.0f * cst[17] && !stuck;
+      }
+#ifdef OPE_DEVELOPER
+      if (owner && build) atomicAdd(work_counter + 47, 1u);   // walks that build a certificate
+#endif
+      const bool fast = need && !build;
+      NearestVisitor v{fast ? best_init : -INFINITY, kNoPos, 0};
+      const unsigned long long fmask = __ballot(fast);
+      if (fmask != 0ull) {
+        if (oct) {
+          if (fast) bvh_traverse_oct(tgt, x, y, z, v, &s_stk[0][threadIdx.x & ~7u], BLOCK, h);
+        } else if (__popcll(fmask) <= 8) {
+          // a handful of walkers in a chunk that is otherwise answered from certificates: eight lanes walk for each of them
+          // (bvh_traverse_oct: a third of the dependent trips of a private walk — a launch in which next to nobody walks would
+          // otherwise last as long as its one longest private walk).  Group r serves the r-th walker.
+          const uint32_t r = lane_id >> 3;
+          const bool serve = r < (uint32_t)__popcll(fmask);
+          unsigned long long mm = fmask;
+          for (uint32_t k = 0; k < r && mm != 0ull; ++k) mm &= mm - 1ull;
+          const int from = mm != 0ull ? (int)__builtin_ctzll(mm) : 0;
+          const float gx = __shfl(x, from, 64), gy = __shfl(y, from, 64), gz = __shfl(z, from, 64);
+          const uint32_t gh = (uint32_t)__shfl((int)h, from, 64);
+          NearestVisitor gv{serve ? cst[15] : -INFINITY, kNoPos, 0};
+          if (serve) bvh_traverse_oct(tgt, gx, gy, gz, gv, &s_stk[0][threadIdx.x & ~7u], BLOCK, gh);
+          // the r-th walker takes its result from lane 8 r
+          const int back = 8 * (int)__popcll(fmask & ((1ull << lane_id) - 1ull));
+          const float rb = __shfl(gv.best, back, 64);
+          const uint32_t rp = (uint32_t)__shfl((int)gv.pos, back, 64), rl = (uint32_t)__shfl((int)gv.leaf, back, 64);
+          if (fast) { v.best = rb; v.pos = rp; v.leaf = rl; }
+        } else {
+          const bool done = PACKET && bvh_traverse_packet(tgt, x, y, z, fast, v, h, stk, BLOCK);
+          if (!done && fast) bvh_traverse_deferred(tgt, x, y, z, v, stk, BLOCK, h, min(8, kMaxDepth + 1 - tgt.depth));
         }
       }
-      const bool wfound = need && w.pos != kNoPos;
-      if (owner) {
-        if (need) {
-          // the next launch's L: every other point's computed d2 is at least min(second, lb) -> its true distance at least
-          // sqrt of that less 2.5u, and the square root itself is good to 1 ulp
-          const float Lw = __fmul_rn(__builtin_amdgcn_sqrtf(fminf(w.second, w.lb)), 0.9999995f);
-          cert[i] = wfound ? make_uint2(w.pos + 1u, __float_as_uint(Lw)) : make_uint2(0u, 0u);
-        } else if (c_moved) {
-          cert[i] = make_uint2(c_pos1, __float_as_uint(c_L));
+      float r_best = fast ? v.best : c_best;
+      uint32_t r_pos = fast ? v.pos : c_pos, r_leaf = fast ? v.leaf : h;
+      if (__ballot(build) != 0ull) {
+        constexpr int K = kCertCand + 1;
+        KnnRegVisitor<K> kv;
+        kv.init(build, best_init);
+        if (build) bvh_traverse(tgt, x, y, z, kv, stk, BLOCK, h);
+        if (build) {
+          r_best = kv.count > 0 ? kv.d[0] : best_init;
+          r_pos = kv.count > 0 ? kv.p[0] : kNoPos;
+          r_leaf = kv.count > 0 ? kv.leaf : h;
+          if (owner) {
+            // every point outside the list has a computed d2 of at least d[K-1] (a list that is not full still holds the walk's
+            // starting bound there) -> a true distance of at least its square root less 2.5u; the square root is good to 1 ulp
+            const float Lw = __fmul_rn(__builtin_amdgcn_sqrtf(kv.d[K - 1]), 0.9999995f);
+#pragma unroll
+            for (int j = 0; j < kCertCand; ++j) cert_pos[(size_t)j * cstride + i] = j < kv.count ? kv.p[j] + 1u : 0u;
+            cert_q[i] = make_float4(x, y, z, Lw);
+          }
         }
       }
       {
         const uint32_t nc = (uint32_t)__popcll(__ballot(owner && !need));
         if (lane_id == 0 && nc != 0u) atomicAdd(&s_ncert, nc);
       }
-      const uint32_t r_leaf = need ? w.leaf : h;
       if (owner && r_leaf != h) hint[i] = r_leaf;
-      const bool found = active && (need ? wfound : true);
-      const float r_best = need ? w.best : c_best;
-      pos = found ? (need ? w.pos : c_pos1 - 1u) : 0;
+      const bool found = active && r_pos != kNoPos;
+      pos = found ? r_pos : 0;
       ok = found && !((double)r_best > max_d2);
       d2 = found ? r_best : INFINITY;
       match = found ? (store_pos ? (int)pos : __float_as_int(tgt.pts[pos].w)) : -1;
-    } else if (MODE == 0) {
+    } else if constexpr (MODE == 0) {
       NearestVisitor v{active ? cst[15] : -INFINITY, kNoPos, 0};
       // start at the leaf that held this query's nearest neighbour one iteration ago (0 = none yet)
       const uint32_t h = active ? hint[i] : 0u;
@@ -412,7 +469,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
         ok = ok && r.pos != kNoPos && !((double)r.best > max_d2) &&
              __float_as_int(srcix.pts[r.pos].w) == __float_as_int(s.w);
       }
-    } else if (MODE == 2) {
+    } else if constexpr (MODE == 2) {
       // register list of KREG >= k entries: the k nearest are the first k of the KREG nearest
       constexpr int K = KREG;
       KnnRegVisitor<K> v;
@@ -532,7 +589,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     if (S_atomic != nullptr) unsafeAtomicAdd(S_atomic + threadIdx.x, v);
     else partials[threadIdx.x * kAccMaxBlocks + blockIdx.x] = v;
   }
-  if (MODE == 0 && !RECIP && cert_on && threadIdx.x == 64 && s_ncert != 0u)
+  if (CERT && threadIdx.x == 64 && s_ncert != 0u)
     atomicAdd(reinterpret_cast<unsigned long long *>(work_counter + 40), (unsigned long long)s_ncert);   // ope_icp_certificate_stats
   acc_launch_end(chain);
 }
@@ -622,8 +679,9 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ hint, uint32_t *__restrict__ ghint,
     const uint32_t *__restrict__ qorder, unsigned char *__restrict__ qclass, const uint32_t *__restrict__ chunk_order,
     uint32_t *__restrict__ chunk_cost, const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, uint32_t measuring_launch,
-    uint32_t *chain, uint32_t chain_seq) {
-  __shared__ __attribute__((aligned(16))) float s_const[32];   // F rows [0..11], pivot [12..14], best0 [15]; [16..29]: see icp_accumulate_kernel
+    uint32_t *chain, uint32_t chain_seq, uint32_t *pace, uint32_t launch_no) {
+  if (pace != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(pace, launch_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // see icp_accumulate_kernel
+  __shared__ __attribute__((aligned(16))) float s_const[20];   // F rows [0..11], pivot [12..14], best0 [15]; [16..19]: see icp_accumulate_kernel
   if (!acc_launch_begin(st, chain, chain_seq, s_const)) return;
   constexpr int BLOCK = kAccBlock;
   __shared__ double s_red[BLOCK / 64][kNumSumsMax];
@@ -1115,11 +1173,10 @@ __device__ __forceinline__ void icp_update_lane(IcpState *st, const double *S, c
     }
     const float move = (float)(fast_sqrt(mv2) + fast_sqrt(dr2) * (double)st->src_r);
     st->last_move = move;
-    if (move < st->cert_thr) st->cert_mode = 1;
-    // in line: certificates are of the transform this update replaces iff an accumulate launch in cert mode has run since the
-    // last update (two updates in a row, or a transform set from outside, leave them behind: every query then walks once)
-    st->cert_prev_ok = st->cert_acc_flag;
-    st->cert_acc_flag = 0;
+    if (move < st->cert_thr && st->cert_mode == 0) {
+      st->cert_mode = 1;
+      if (st->host_cert != nullptr) __hip_atomic_store(st->host_cert, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) st->F[i] = Fn[i];
@@ -1283,10 +1340,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(192))) void icp_
     // the sums as the blocks' atomics left them (the state's own array: overlapped runs have no caller-owned sums buffer)
     if (t < kNumSumsMax) s_S[t] = t < nsums ? __hip_atomic_load(&st->S[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     __syncthreads();
-    if (t == 0) {
-      icp_update_lane(&s_st, s_S, nullptr);
-      s_st.cert_prev_ok = 1;   // this update follows accumulate launch `seq` by construction (see acc_launch_begin)
-    }
+    if (t == 0) icp_update_lane(&s_st, s_S, nullptr);
     __syncthreads();
     // The state goes back with plain stores — the next update and the host read it after this kernel has ended — EXCEPT the
     // sums: a zero left dirty in this XCD's L2 would be written back at the end of this kernel, over what the next launch's
@@ -1297,9 +1351,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(192))) void icp_
     if (t < nsums) __hip_atomic_store(&st->S[t], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t < 12) __hip_atomic_store(&st->Ff[t], s_st.Ff[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == 12) __hip_atomic_store(&st->done, s_st.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t >= 16 && t < 28) __hip_atomic_store(&st->Fprev[t - 16], s_st.Fprev[t - 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == 28) __hip_atomic_store(&st->cert_mode, s_st.cert_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == 29) __hip_atomic_store(&st->cert_prev_ok, s_st.cert_prev_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 17) __hip_atomic_store(&st->last_move, s_st.last_move, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else if (mode == 2u && t == 0) {
     __hip_atomic_store(&st->chain_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&st->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1639,7 +1691,8 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
                            int32_t *corr_match, float *corr_d2, uint32_t *work_counter, uint32_t *hint,
                            const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
                            int k_normal_shooting, double *S_atomic, const uint32_t *slot_list, float *knn_rk, const uint32_t *plan_out,
-                           hipEvent_t e0, hipEvent_t e1, bool measuring, uint32_t *chain, uint32_t chain_seq, uint2 *cert) {
+                           hipEvent_t e0, hipEvent_t e1, bool measuring, uint32_t *chain, uint32_t chain_seq, float4 *cert_q, uint32_t *cert_pos,
+                           uint32_t *pace, uint32_t launch_no) {
   const uint32_t mflag = measuring ? 1u : 0u;
   // e0 / e1 (ope_icp_profile): the launch's own start and stop time stamps, taken by the dispatch itself (hipExtLaunchKernelGGL).
   // Round 3 measured what a hipEventRecord before and after every launch costs the loop it times: 7-11 us per iteration (two
@@ -1648,19 +1701,22 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
   do {                                                                                                                        \
     if (e0 != nullptr)                                                                                                        \
       hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, e0, e1, 0, src, tgt, srcix, st, partials, corr_match, \
-                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert); \
+                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert_q, cert_pos, pace, launch_no); \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, partials, corr_match, corr_d2,   \
-                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert); \
+                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert_q, cert_pos, pace, launch_no); \
   } while (0)
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS) OPE_KLAUNCH((icp_accumulate_kernel<M, N, R>), BLK, LDS)
+  const bool certify = cert_q != nullptr && mode == 0 && !recip;   // the certifying instantiation (api.hip decides when)
   if (mode == 0 && !recip && packet) {
-    if (nrm) OPE_KLAUNCH((icp_accumulate_kernel<0, true, false, true>), kAccBlock, 0);
+    if (certify) { if (nrm) OPE_KLAUNCH((icp_accumulate_kernel<0, true, false, true, 20, true>), kAccBlock, 0); else OPE_KLAUNCH((icp_accumulate_kernel<0, false, false, true, 20, true>), kAccBlock, 0); }
+    else if (nrm) OPE_KLAUNCH((icp_accumulate_kernel<0, true, false, true>), kAccBlock, 0);
     else OPE_KLAUNCH((icp_accumulate_kernel<0, false, false, true>), kAccBlock, 0);
     return;
   }
   if (mode == 0) {
     if (recip) { if (nrm) OPE_LAUNCH_ACC(0, true, true, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, true, kAccBlock, 0); }
+    else if (certify) { if (nrm) OPE_KLAUNCH((icp_accumulate_kernel<0, true, false, false, 20, true>), kAccBlock, 0); else OPE_KLAUNCH((icp_accumulate_kernel<0, false, false, false, 20, true>), kAccBlock, 0); }
     else       { if (nrm) OPE_LAUNCH_ACC(0, true, false, kAccBlock, 0); else OPE_LAUNCH_ACC(0, false, false, kAccBlock, 0); }
   } else {
     // normal shooting: the k-nearest list lives in registers for EVERY k <= 32 (instantiations at k rounded up to a
@@ -1695,6 +1751,15 @@ int icp_accumulate_blocks_per_cu(bool nrm, bool packet, bool grid) {
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, false, false, true>, kAccBlock, 0);
   else e = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, true, false, false>, kAccBlock, 0)
                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, false, false, false>, kAccBlock, 0);
+  if (e == hipSuccess && !grid) {   // a run may move to the certifying instantiation: the launch geometry must hold both
+    int nc = 0;
+    hipError_t ec;
+    if (packet) ec = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, true, false, true, 20, true>, kAccBlock, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, false, false, true, 20, true>, kAccBlock, 0);
+    else ec = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, true, false, false, 20, true>, kAccBlock, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, false, false, false, 20, true>, kAccBlock, 0);
+    if (ec == hipSuccess && nc > 0) nb = std::min(nb, nc);
+  }
   return (e == hipSuccess && nb > 0) ? nb : 0;
 }
 
@@ -1702,16 +1767,16 @@ void launch_icp_accumulate_grid(hipStream_t stream, int nblocks, bool nrm, const
                                 const IcpState *st, double *partials, int32_t *corr_match, float *corr_d2, uint32_t *hint, uint32_t *ghint,
                                 const uint32_t *qorder, unsigned char *qclass, const uint32_t *chunk_order, uint32_t *chunk_cost,
                                 const uint32_t *plan_info, double *S_atomic, hipEvent_t e0, hipEvent_t e1, bool measuring, uint32_t *chain,
-                                uint32_t chain_seq) {
+                                uint32_t chain_seq, uint32_t *pace, uint32_t launch_no) {
   const uint32_t mflag = measuring ? 1u : 0u;
 #define OPE_KLAUNCH(KERNEL)                                                                                                   \
   do {                                                                                                                        \
     if (e0 != nullptr)                                                                                                        \
       hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, e0, e1, 0, src, tgt, grid, st, partials, corr_match, \
-                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq); \
+                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no); \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, grid, st, partials, corr_match, corr_d2, \
-                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq); \
+                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no); \
   } while (0)
   if (nrm) OPE_KLAUNCH((icp_accumulate_grid_kernel<true>));
   else OPE_KLAUNCH((icp_accumulate_grid_kernel<false>));
@@ -1790,6 +1855,12 @@ void launch_fitness(hipStream_t stream, int nblocks, const CloudView &q, const B
 }  // namespace ope
 
 #ifdef OPE_DEVELOPER   // `make DEVELOPER=1`: instrumentation kernels are not part of the product library
+extern "C" int ope_debug_cert_reasons(ope_ctx *ctx, uint32_t out[4], int reset) {
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  OPE_HIP(ctx, hipMemcpy(out, ctx->d_work_counter + 44, 16, hipMemcpyDeviceToHost));
+  if (reset) OPE_HIP(ctx, hipMemset(ctx->d_work_counter + 44, 0, 16));
+  return OPE_OK;
+}
 // tools/chain_probe.py: switch the per-chunk path/packet counters of the tree kernel on (device buffer of 4 words per
 // chunk, handed back by ope_debug_chunk_stats_read) or off (nullptr)
 extern "C" int ope_debug_chunk_stats(ope_ctx *ctx, uint32_t n_chunks, uint32_t *read_into) {

@@ -93,13 +93,13 @@ struct IcpState {
   int knn_acc_flag;    // written by a k-NN accumulate launch: "the stored k-th distances are of the current transform"
   // Skip certificates of the plain 1-NN search (icp_kernels.hip, "skip certificates"; round 4).
   int cert_mode;       // accumulate launches keep and use per-query certificates (sticky: set by the update step once an iteration moves the scene by less than cert_thr)
-  int cert_prev_ok;    // Fprev is the transform of the launch the stored certificates were last brought up to (the update before this launch followed an accumulate launch)
-  int cert_acc_flag;   // written by an in-line accumulate launch in cert mode: "the certificates are of the current transform"
   float cert_thr;      // metres; < 0: never, +inf: from the first launch on
+  float cert_cap;      // metres: the slack a certificate is credited with at most (~ the target's point spacing)
+  float cert_k;        // square metres: slack of a certificate ~ cert_k / (distance of the query from the surface)
   float src_c[3];      // centre of the source cloud's bounding box (its own frame)
   float src_r;         // half its diagonal
-  float last_move;     // the estimate cert_thr was last compared with: largest displacement of a source point by the last update
-  int pad2_;
+  float last_move;     // largest displacement of a source point by the last update (estimate; what cert_thr is compared with and a certificate's worth is weighed against)
+  uint32_t *host_cert; // host-visible word (pinned) the update step sets when it sets cert_mode: from then on the host launches the certifying instantiation
 };
 static_assert(sizeof(IcpState) % 8 == 0, "IcpState holds doubles");
 
@@ -115,6 +115,7 @@ struct P2pView {
 };
 
 constexpr float kOctSlotShare = 0.42f;   // one of a group-walked chunk's eight slots lasts about this share of the chunk's per-lane duration (tools/chain_probe.py: 0.39-0.53)
+constexpr int kCertCand = 5;            // skip certificates: candidates kept per query (built by a (kCertCand + 1)-nearest walk)
 constexpr int kNumSums = 17;
 constexpr int kNumSumsMax = 44;  // + 21 (upper triangle of AᵀA) + 6 (Aᵀb) for the point-to-plane estimator
 constexpr int kAccBlock = 512;       // threads per block of the accumulate kernel
@@ -183,8 +184,18 @@ struct ope_ctx {
   uint32_t chain_seq = 0;        // overlapped accumulate launches of this run so far (= updates published once they are done)
   int64_t kernel_launches[OPE_KERNEL_KINDS] = {0, 0, 0, 0};   // per search kernel, this run (ope_icp_kernel_launches)
   uint32_t *d_hint = nullptr;       // per sorted query: leaf (heap id) of the previous iteration's match, 0 = none
-  bool cert_run = false;            // the run in progress keeps skip certificates (ope_icp_begin)
-  uint2 *d_cert = nullptr;          // per sorted query: {1 + position of its match in the index's point order (0: no certificate), bits of the lower bound L (float, metres) on its distance to every OTHER target point}
+  bool cert_run = false;            // the run in progress may keep skip certificates (ope_icp_begin)
+  bool cert_seen = false;           // ... and the device has asked for them (or they were forced): accumulate launches take the certifying instantiation
+  // host-visible words (pinned): [0] the number of the accumulate launch that last started (written by the launches), [1] "the update
+  // step has set cert_mode".  The host keeps at most kPaceLead launches between what it has enqueued and [0] (pace_wait): a bounded queue,
+  // and [1] is noticed a few launches late at most.
+  uint32_t *h_pace = nullptr, *d_pace = nullptr;
+  uint32_t launch_no = 0;           // accumulate launches enqueued in this run
+  bool pace_off = false;            // a wait ran into its limit (a stream held up from outside): no pacing for the rest of the run
+  // skip certificates, per sorted query: where the query was when it built its certificate and the lower bound L (metres) that walk
+  // proved on its distance to every target point but the candidates {x, y, z, L}; the candidates
+  float4 *d_cert_q = nullptr;
+  uint32_t *d_cert_pos = nullptr;   // [kCertCand][n]: 1 + position in the index's point order, nearest first; 0: none
   float *d_knn_rk = nullptr;        // k-NN runs: per sorted query the squared distance of the last list entry of the previous launch (+inf: none)
   size_t knn_rk_cap = 0;
   // grid path of the 1-NN search (icp_accumulate_grid_kernel)

@@ -24,10 +24,13 @@ for rep in range(2):
     ctx.icp_begin(cs, ix, p, guess)
     ctx.icp_profile(N)
     ctx.sync(); t0 = time.perf_counter()
-    cert = []
+    cert, reasons = [], []
     if os.environ.get("PROBE_STATS"):
+        import ctypes as C
         for k in range(N):
             ctx.icp_iterate(1); cert.append(ctx.icp_certificate_stats())
+            if os.environ.get("PROBE_LIB") == "dev":
+                r = (C.c_uint32 * 4)(); ope.lib().ope_debug_cert_reasons(ctx.h, r, 1); reasons.append(list(r))
     else:
         ctx.icp_iterate(N)
     ctx.sync(); dt = time.perf_counter() - t0
@@ -40,3 +43,5 @@ if cert:
     c = np.diff([0] + [x["certified"] for x in cert])
     print("certified per launch (every 5th):", [int(v) for v in c[::5]])
     print("last_move um (every 5th):", [round(x["last_move"] * 1e6, 1) for x in cert[::5]])
+if cert and reasons:
+    print("per launch {expired, tie among candidates, no certificate, walks that build} (every 10th):", reasons[::10])
