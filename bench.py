@@ -68,7 +68,9 @@ def main() -> int:
                                                           "estimateFinePose really installs), reported beside `value` at N = 1")
     ap.add_argument("--no-coarse", action="store_true", help="skip the FPFH + SAC-IA initial alignment (identity start)")
     ap.add_argument("--cpu-iters", type=int, default=3)
-    ap.add_argument("--steady", type=int, default=100, help="iterations timed after the K steps, in the converged regime (reported, not `value`)")
+    ap.add_argument("--steady", type=int, default=100, help="iterations timed in the converged regime, after the run has been taken to --settle iterations (reported, not `value`)")
+    ap.add_argument("--settle", type=int, default=150, help="iterations from the coarse pose after which the run counts as settled (the steady-state phase starts there)")
+    ap.add_argument("--full-run", type=int, default=100, help="a second run from the coarse pose, this many iterations timed as a whole (reported as phases.full_run; 0: skip)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal of the N-rank path on a box with ONE GPU: every rank uses device 0, the process group is gloo and the "
                          "sums travel through the library's peer-to-peer slots (handles passed over gloo; RCCL refuses two ranks on one "
@@ -243,7 +245,8 @@ def main() -> int:
     # W warm-up + K timed iterations from the coarse pose (`value`), then S more in the converged regime (reported
     # separately: an iteration is cheaper once the scene has settled on the model)
     S = args.steady
-    params = ope.default_icp_params(max_iterations=W + K + S + 1, transformation_epsilon=0.0,
+    settle = max(0, args.settle - (W + K)) if S > 0 else 0      # untimed iterations between the timed window and the steady-state phase
+    params = ope.default_icp_params(max_iterations=W + K + settle + S + 1, transformation_epsilon=0.0,
                                     euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0, check_every=0,
                                     update_launch=0 if args.update_launch == "overlapped" else 1,
                                     skip_certificates={"auto": ope.CERT_AUTO, "off": ope.CERT_OFF, "always": ope.CERT_ALWAYS}[args.certificates])
@@ -291,12 +294,33 @@ def main() -> int:
     kernels_timed = ctx.icp_kernel_launches()
     overlapped_updates = ctx.icp_overlapped_updates()
     T_timed = ctx.icp_current_transform()
+    cert_timed = ctx.icp_certificate_stats()
     steady = None
     if S > 0:
+        for _ in range(settle):
+            step()
+        c0 = ctx.icp_certificate_stats()
         s_elapsed, s_kern_ms, _ = timed(S, True)
-        steady = {"steps": S, "ms_per_step": s_elapsed / S * 1e3, "iterations_per_s": S / s_elapsed, "kernel_ms": s_kern_ms}
+        c1 = ctx.icp_certificate_stats()
+        steady = {"steps": S, "after_iterations": W + K + settle, "ms_per_step": s_elapsed / S * 1e3, "iterations_per_s": S / s_elapsed, "kernel_ms": s_kern_ms,
+                  "queries_answered_from_certificates_per_launch": (c1["certified"] - c0["certified"]) / S}
     out = ctx.icp_end()
-    assert out.iterations == W + K + S, (out.iterations, W, K, S)
+    assert out.iterations == W + K + settle + S, (out.iterations, W, K, settle, S)
+    # ---- a whole run as the reference's flow has it: from the coarse pose, --full-run iterations, timed as one piece
+    full = None
+    if args.full_run > 0:
+        pf = ope.default_icp_params(max_iterations=args.full_run + 1, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0,
+                                    check_every=0, update_launch=params.update_launch, skip_certificates=params.skip_certificates)
+        ctx.icp_set_global_sizes(n_scene, n_model)
+        ctx.icp_begin(cs, ix, pf, guess)
+        f_elapsed, f_kern_ms, f_n = timed(args.full_run, True)
+        cf = ctx.icp_certificate_stats()
+        f_launch_ms = getattr(timed, "last_launch_ms", None)
+        of = ctx.icp_end()
+        full = {"steps": args.full_run, "ms": f_elapsed * 1e3, "ms_per_step": f_elapsed / args.full_run * 1e3, "kernel_ms_sum": f_kern_ms * f_n,
+                "kernel_ms_by_tens": [round(sum(f_launch_ms[k:k + 10]) / len(f_launch_ms[k:k + 10]), 4) for k in range(0, len(f_launch_ms), 10)] if f_launch_ms else None,
+                "launches_keeping_certificates": cf["launches"], "queries_answered_from_certificates": cf["certified"],
+                "pose_error_vs_ground_truth_frobenius": float(np.linalg.norm(of.T.astype(np.float64) - gt_inv))}
 
     # ---- beside `value`: the configuration estimateFinePose / getIcpNormal really run (poseestimator.cpp:242-246,331-337;
     # regmeshpcd.cpp:140-159): normal shooting over the k = 20 nearest + the surface-normal rejector at 0.7, SVD estimator,
@@ -333,13 +357,15 @@ def main() -> int:
                                "algorithmic_bytes_per_launch": ns_bytes}}
 
     if launched:
-        vals = [elapsed, kern_avg_ms] + ([steady["ms_per_step"], steady["kernel_ms"]] if steady else [])
+        vals = [elapsed, kern_avg_ms] + ([steady["ms_per_step"], steady["kernel_ms"]] if steady else [0.0, 0.0]) + ([full["ms"]] if full else [0.0])
         t = torch.tensor(vals, dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_avg_ms = float(t[0]), float(t[1])
         if steady:
             steady["ms_per_step"], steady["kernel_ms"] = float(t[2]), float(t[3])
             steady["iterations_per_s"] = 1e3 / steady["ms_per_step"]
+        if full:
+            full["ms"] = float(t[4]); full["ms_per_step"] = full["ms"] / full["steps"]
 
     rc = 0
     if rank == 0:
@@ -349,7 +375,13 @@ def main() -> int:
         algo_bytes = 36.0 * n_local + 12.0 * n_model
         achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
         traffic, traffic_source = None, None
-        tf = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
+        if steady and steady["kernel_ms"] > 0:
+            sa = algo_bytes / (steady["kernel_ms"] * 1e-3) / 1e9
+            steady["roofline"] = {"bound": "hbm", "achieved": sa, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sa / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_launch": algo_bytes}
+        tf = os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")
+        if not os.path.exists(tf):
+            tf = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
         if world == 1 and os.path.exists(tf):
             try:
                 rec = json.load(open(tf)).get(args.workload)
@@ -402,7 +434,8 @@ def main() -> int:
                                       + (f" ({args.comm}" + ({ope.COMM_P2P: ": peer-to-peer slots", ope.COMM_RCCL: ": ncclAllReduce"}.get(ctx.comm_transport(), "") if not use_torch_comm else "") + ")" if launched else ""),
                        "start": "identity" if guess is None else "FPFH + SAC-IA coarse pose",
                        "final_mse": out.last_mse, "n_corr": int(out.n_corr),
-                       "update_launch": args.update_launch, "overlapped_updates_so_far": overlapped_updates},
+                       "update_launch": args.update_launch, "overlapped_updates_so_far": overlapped_updates,
+                       "skip_certificates": args.certificates, "certificates_in_timed_window": cert_timed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "icp_accumulate_kernel", "kernel_ms": kern_avg_ms, "launches_timed": kern_n,
@@ -410,7 +443,7 @@ def main() -> int:
                          "kernel_launches_so_far": kernels_timed,
                          "algorithmic_bytes_per_launch": algo_bytes},
             "phases": {"from_coarse_pose": {"steps": K, "after_warmup": W, "ms_per_step": elapsed / K * 1e3, "kernel_ms": kern_avg_ms},
-                       "steady_state": steady},
+                       "steady_state": steady, "full_run": full},
             "pose_check": checks,
         }
         if ns_leg is not None:

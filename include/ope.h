@@ -215,8 +215,8 @@ typedef struct {
    * strictly below the other four, it is the unique nearest neighbour: same index, same d2, bit for bit, and no walk.  Every
    * launch still writes every correspondence and adds every term of the sums.
    * OPE_CERT_AUTO (0, default): launches keep certificates from the iteration on whose update moves no scene point by more than
-   * an eighth of the target's point spacing (decided on the device, no host round trip), and a query builds one when the slack it
-   * can expect — read off its previous distance — is worth eight launches of the scene's current displacement.
+   * 1/24 of the target's point spacing (decided on the device, no host round trip), and a query builds one when the slack it
+   * can expect — read off its previous distance — is worth 24 launches of the scene's current displacement.
    * OPE_CERT_OFF (1): never.  OPE_CERT_ALWAYS (2): from the first launch (tests).  Plain 1-NN runs on the OBB-tree kernel only
    * (not: reciprocal, normal shooting, deterministic_sums, the grid kernel); exact in every mode — the choice moves time only. */
   int skip_certificates;
@@ -262,7 +262,7 @@ int64_t ope_icp_overlapped_updates(const ope_ctx *ctx);
 /* Skip certificates of the run in progress (ope_icp_params.skip_certificates; synchronises the stream): out[0] = queries answered
  * from their certificate, summed over the run's launches; out[1] = accumulate launches that kept certificates; out[2] = 1 if the
  * run has reached the stage where it keeps them; out[3] = the last update's largest scene displacement in nanometres (what the
- * automatic mode compares with an eighth of the target's point spacing). */
+ * automatic mode compares with 1/24 of the target's point spacing). */
 int ope_icp_certificate_stats(ope_ctx *ctx, int64_t out[4]);
 
 /* Registration::align(output, guess) -> IterativeClosestPoint::computeTransformation

@@ -1146,7 +1146,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
                     !dev_env("OPE_NO_CERT");
     const double ex = (double)tgt->bb_hi[0] - tgt->bb_lo[0], ey = (double)tgt->bb_hi[1] - tgt->bb_lo[1], ez = (double)tgt->bb_hi[2] - tgt->bb_lo[2];
     const double spacing = std::sqrt(2.0 * (ex * ey + ey * ez + ez * ex) / (double)std::max<size_t>(tgt->n, 1));
-    h->cert_thr = !ctx->cert_run ? -1.0f : p.skip_certificates == OPE_CERT_ALWAYS ? std::numeric_limits<float>::infinity() : (float)(0.125 * spacing);
+    h->cert_thr = !ctx->cert_run ? -1.0f : p.skip_certificates == OPE_CERT_ALWAYS ? std::numeric_limits<float>::infinity() : (float)(spacing / (double)kCertWorth);
     if (const char *e = dev_env("OPE_CERT_THR")) h->cert_thr = (float)atof(e);   // developer sweep (metres)
     h->cert_mode = (ctx->cert_run && p.skip_certificates == OPE_CERT_ALWAYS) ? 1 : 0;
     ctx->cert_seen = h->cert_mode != 0;

@@ -306,7 +306,6 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       // the rounding of every quantity involved (u = 2^-24: a computed d2 is within 5u of the true one, v_sqrt_f32 within 1 ulp;
       // the factors below leave 16u) — and strictly nearer than every other candidate, it is the unique nearest neighbour: what
       // a walk would return, bit for bit.  Nothing is written but the correspondence.
-      const uint32_t h = active ? hint[i] : 0u;
       const float best_init = active ? cst[15] : -INFINITY;
       const size_t cstride = src.n;
       bool need = active;
@@ -352,18 +351,22 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       // A query without a valid certificate walks.  Whether that walk BUILDS a certificate (a (kCertCand + 1)-nearest walk, dearer
       // than the 1-NN walks) is decided per query from what a certificate would be worth: its slack — distance of the
       // (kCertCand + 1)-th neighbour less the nearest's, ~ cert_k / D for a query D from the surface, at most cert_cap — against
-      // the scene's displacement per launch.  Surface points build soon after the launches start keeping certificates; a point
-      // 10 cm out, whose neighbours all lie within microns of each other in distance, once the scene moves by less than that.
+      // kCertWorth launches of the scene's displacement (the displacements of a converging run sum to about a dozen times the
+      // current one: a certificate built then usually holds to the end).  Surface points build soon after the launches start
+      // keeping certificates; a point 10 cm out, whose neighbours all lie within microns of each other in distance, once the
+      // scene moves by less than a micron per launch.
       bool build = false;
       if (need) {
         const float dprev = __builtin_amdgcn_sqrtf(corr_d2[i]);           // (+inf before the first match: no slack, no certificate yet)
         const float slack = fminf(cst[19], cst[18] * __builtin_amdgcn_rcpf(dprev));
-        build = slack >= 8.0f * cst[17] && !stuck;
+        // (in a slot walked by 8-lane groups the eight lanes of a group carry the same query: one of them builds)
+        build = slack >= kCertWorth * cst[17] && !stuck && owner;
       }
+      const uint32_t h = need ? hint[i] : 0u;   // start leaf of the walks (queries answered from their certificate need none)
 #ifdef OPE_DEVELOPER
       if (owner && build) atomicAdd(work_counter + 47, 1u);   // walks that build a certificate
 #endif
-      const bool fast = need && !build;
+      const bool fast = need && !build && !(oct && __shfl((int)build, (int)(lane_id & ~7u), 64) != 0);   // (a group whose query builds does not walk as well)
       NearestVisitor v{fast ? best_init : -INFINITY, kNoPos, 0};
       const unsigned long long fmask = __ballot(fast);
       if (fmask != 0ull) {

@@ -115,6 +115,7 @@ struct P2pView {
 };
 
 constexpr float kOctSlotShare = 0.42f;   // one of a group-walked chunk's eight slots lasts about this share of the chunk's per-lane duration (tools/chain_probe.py: 0.39-0.53)
+constexpr float kCertWorth = 24.0f;     // a query builds a certificate when the slack it can expect is worth this many launches of the scene's current displacement
 constexpr int kCertCand = 5;            // skip certificates: candidates kept per query (built by a (kCertCand + 1)-nearest walk)
 constexpr int kNumSums = 17;
 constexpr int kNumSumsMax = 44;  // + 21 (upper triangle of AᵀA) + 6 (Aᵀb) for the point-to-plane estimator
