@@ -62,6 +62,13 @@ int ope_ctx_sync(ope_ctx *ctx);
  * fpfh_spfh, fpfh_weight, sacia, index_build, uniform_sampling.  Off by default.  The reference's own instrumentation is
  * pcl::ScopeTime("Initial Alignment" / "Final Alignment") (poseestimator.cpp:61,349): the facade keeps those names. */
 int ope_ctx_set_tracing(ope_ctx *ctx, int on);
+/* Bound of every device-side wait of the overlapped update launches (ope_icp_params.update_launch), seconds, 0 .. 40; default 2.
+ * A launch whose partner has not reported within the bound gives up and the run resumes in line at the next ope_icp_poll /
+ * ope_icp_end (nothing is lost but the time waited; the context launches in line from then on).  Raise it for launches that
+ * legitimately take longer than the bound (a source of hundreds of millions of points); a process that shares its GPU with other
+ * work it cannot predict should rather ask for OPE_UPDATE_IN_LINE.  A bound of a microsecond makes every overlapped update give up at once
+ * (how the test of the recovery path forces it). */
+int ope_ctx_set_wait_limit(ope_ctx *ctx, double seconds);
 const char *ope_last_error(const ope_ctx *ctx);
 
 /* Measurement hook for the coarse-stage and filter kernels (normals_kernel, spfh_kernel, fpfh_kernel, feature_knn_kernel,
@@ -245,7 +252,8 @@ void ope_icp_default_params(ope_icp_params *p);
  * (squared distance) * 1e10 — which therefore also enters the MSE of the convergence test — (correspondence_estimation_mod.hpp:
  * 134-162); normal shooting lists none (…normal_shooting_weighted.hpp:81-101); listed pairs pass the rejectors like any
  * other; then the FIRST rejector alone is applied to the given pairs and the survivors are appended, a second time for those
- * already listed (icp_mod.hpp:210-224; only when a rejector is installed).  SVD estimator only; not with reciprocal
+ * already listed (icp_mod.hpp:210-224; only when a rejector is installed; with both rejectors of ope_icp_params on, "the first"
+ * is the surface-normal one — the params fix the order the reference's programs add them in, poseestimator.cpp:334-336).  SVD estimator only; not with reciprocal
  * correspondences; in a sharded run set them on exactly ONE rank (indices into that rank's shard): every rank that holds
  * pairs adds them to the sums that are then summed over the ranks.  ope_icp_correspondences lists the searched pairs only.  Runs with fixed
  * correspondences launch their update in line. */

@@ -118,6 +118,7 @@ ABI = [
     ("ope_ctx_set_stream", C.c_int, [_vp, _vp]),
     ("ope_ctx_sync", C.c_int, [_vp]),
     ("ope_ctx_set_tracing", C.c_int, [_vp, C.c_int]),
+    ("ope_ctx_set_wait_limit", C.c_int, [_vp, C.c_double]),
     ("ope_last_error", C.c_char_p, [_vp]),
     ("ope_profile_kernels", C.c_int, [_vp, C.c_int]),
     ("ope_profile_kernels_read", C.c_int, [_vp, C.POINTER(KernelTime), C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -291,6 +292,10 @@ class Context:
         self._chk(lib().ope_profile_kernels_read(self.h, buf, 32, C.byref(n)))
         return {buf[i].name.decode(): {"ms": buf[i].ms, "launches": buf[i].launches, "algorithmic_bytes": buf[i].algorithmic_bytes}
                 for i in range(min(n.value, 32))}
+
+    def set_wait_limit(self, seconds: float):
+        """Bound of the device-side waits of the overlapped update launches (ope_ctx_set_wait_limit)."""
+        self._chk(lib().ope_ctx_set_wait_limit(self.h, float(seconds)))
 
     def set_tracing(self, on: bool):
         self._chk(lib().ope_ctx_set_tracing(self.h, int(on)))

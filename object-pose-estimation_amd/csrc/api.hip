@@ -17,7 +17,7 @@ namespace ope {
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
                            uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *, const uint32_t *, hipEvent_t, hipEvent_t, bool,
-                           uint32_t *, uint32_t, float4 *, uint32_t *, uint32_t *, uint32_t);
+                           uint32_t *, uint32_t, float4 *, uint32_t *, uint32_t *, uint32_t, uint32_t);
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
 void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
@@ -30,7 +30,7 @@ hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t,
                             float4 **, float4 **, float4 **);
 void launch_icp_accumulate_grid(hipStream_t, int, bool, const CloudView &, const BvhView &, const GridView &, const IcpState *, double *, int32_t *,
                                 float *, uint32_t *, uint32_t *, const uint32_t *, unsigned char *, const uint32_t *, uint32_t *, const uint32_t *,
-                                double *, hipEvent_t, hipEvent_t, bool, uint32_t *, uint32_t, uint32_t *, uint32_t);
+                                double *, hipEvent_t, hipEvent_t, bool, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t);
 int grid_plan(hipStream_t, bool, const unsigned char *, uint32_t, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, const uint32_t *,
               uint32_t *, uint32_t, uint32_t, float, float, void *, size_t);
 size_t grid_plan_tmp_bytes(uint32_t, uint32_t);
@@ -41,7 +41,7 @@ hipError_t build_grid_device(hipStream_t, const float4 *, const float4 *, size_t
                              float4 **, float4 **, uint32_t **, uint32_t **);
 void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *, int, bool, uint32_t *);
 void launch_icp_update(hipStream_t, IcpState *, double *, int, const float *);
-void launch_icp_update_chained(hipStream_t, IcpState *, int, uint32_t *, uint32_t, uint32_t);
+void launch_icp_update_chained(hipStream_t, IcpState *, int, uint32_t *, uint32_t, uint32_t, uint32_t);
 void launch_gather_fixed_pairs(hipStream_t, const CloudView &, const CloudView &, const uint32_t *, uint32_t, float4 *);
 void launch_icp_fixed_pairs(hipStream_t, const IcpState *, const float4 *, uint32_t, double *);
 void launch_lm_stats(hipStream_t, int, const CloudView &, const BvhView &, const IcpState *, const int32_t *, double *);
@@ -182,7 +182,7 @@ static int switch_kernel(ope_ctx *ctx, bool to_grid, int it_done, uint32_t nch) 
   ctx->plan_valid = false;   // chunk ids mean something else to the other kernel
 
   if (ctx->plan_pending) { OPE_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_plan_done, 0)); ctx->plan_pending = false; }
-  OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * (size_t)(nch + 1), ctx->stream));
+  OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * 2 * ctx->chunk_cap, ctx->stream));
   OPE_HIP(ctx, hipMemsetAsync(ctx->d_work_counter + 8, 0, 8, ctx->stream));
   if (to_grid) {
     // query order and classes start over (the hints into the grid may be stale: a stale hint is still a model point, so
@@ -228,6 +228,12 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   const bool no_plan = no_plan_env || ctx->run_params.deterministic_sums != 0;
   const int it_done = ctx->acc_launches++;
   const uint32_t nch = (uint32_t)((ctx->run_src->n_valid + 63) / 64);
+  // Chunk costs are double-buffered by launch parity: launch L writes half L & 1, and a plan made beside launch L (on the side
+  // stream) reads the half launch L - 1 wrote — the measuring launch in front of every plan, in which every chunk reports.
+  // Launch L + 1, which writes that half again, waits for the plan first (ev_plan_done).  (Round 3 copied the one buffer on the
+  // side stream while launch L was rewriting it: the snapshot mixed two launches' costs.)
+  uint32_t *const cost_w = ctx->d_chunk_cost + (size_t)(it_done & 1) * ctx->chunk_cap;
+  const uint32_t *const cost_r = ctx->d_chunk_cost + (size_t)((it_done + 1) & 1) * ctx->chunk_cap;
   static const int plan_every = [] { const char *e = dev_env("OPE_PLAN_EVERY"); return e ? std::max(1, atoi(e)) : 32; }();  // developer sweep
   {
     // the launch before a plan step measures: no 8-lane group walks (their chunks would keep the cost of the last
@@ -257,7 +263,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     if (plan_step) {
       static const float heavy_env = [] { const char *e = dev_env("OPE_HEAVY_FACTOR"); return e ? (float)atof(e) : -1.0f; }();
       const bool repart = it_done <= 4 || it_done % plan_every == 0 || it_done == ctx->force_plan_at;
-      if (grid_plan(ctx->stream, repart, ctx->d_qclass, (uint32_t)ctx->run_src->n_valid, ctx->d_qorder, ctx->d_work_counter + 8, ctx->d_chunk_cost,
+      if (grid_plan(ctx->stream, repart, ctx->d_qclass, (uint32_t)ctx->run_src->n_valid, ctx->d_qorder, ctx->d_work_counter + 8, cost_r,
                     ctx->d_chunk_keys, ctx->d_chunk_cost_sorted, ctx->d_chunk_ids, ctx->d_chunk_order, nch,
                     (uint32_t)ctx->acc_blocks * (kAccBlock / 64), heavy_env, heavy_load_factor(), ctx->d_part_tmp, ctx->part_tmp_bytes) != 0)
         return set_err(ctx, OPE_EHIP, "grid plan step failed");
@@ -271,10 +277,10 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     ++ctx->kernel_launches[OPE_KERNEL_GRID];
     launch_icp_accumulate_grid(ctx->stream, ctx->acc_blocks, nrm, ctx->run_src->view(), ctx->run_tgt->view(), ctx->run_tgt->grid, ctx->d_state,
                                ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_hint, ctx->d_ghint, ctx->d_qorder, ctx->d_qclass,
-                               ctx->plan_valid ? ctx->d_chunk_order : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8,
+                               ctx->plan_valid ? ctx->d_chunk_order : nullptr, cost_w, ctx->d_work_counter + 8,
                                atomic_sums ? sums_ptr(ctx) : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr,
                                timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr, ctx->measuring_flag,
-                               ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, ctx->d_pace, ++ctx->launch_no);
+                               ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, ctx->d_pace, ++ctx->launch_no, ctx->wait_ticks);
     if (timed) ++ctx->prof_used;
     return OPE_OK;
   }
@@ -319,10 +325,10 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     const bool async = !plan_sync_env;
     hipStream_t ps = async ? ctx->plan_stream : ctx->stream;
     const int nxt = ctx->plan_cur ^ 1;
-    const uint32_t *costs = ctx->d_chunk_cost;
+    const uint32_t *costs = cost_r;
     if (async) {
       OPE_HIP(ctx, hipEventRecord(ctx->ev_acc_done, ctx->stream));       // every launch before this one has finished ...
-      OPE_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_acc_done, 0));         // ... before the costs are copied (this launch overwrites them)
+      OPE_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_acc_done, 0));         // ... before their costs are read (this launch writes the other half)
     }
     // the count of far queries that may move the run back to the grid kernel rides on the same side stream (three dispatches
     // off the launch stream; it reads the distances while this launch rewrites them: a count of two consecutive launches'
@@ -330,10 +336,6 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     if (ctx->grid_auto && it_done >= 8) {
       const int rcp = grid_probe_issue(ctx, ps);
       if (rcp != OPE_OK) return rcp;
-    }
-    if (async) {
-      OPE_HIP(ctx, hipMemcpyAsync(ctx->d_cost_snap, ctx->d_chunk_cost, 4 * (size_t)nch, hipMemcpyDeviceToDevice, ps));
-      costs = ctx->d_cost_snap;
     }
     size_t tb = ctx->plan_tmp_bytes;
     if (chunk_plan(ps, costs, ctx->d_plan_sorted[nxt], ctx->d_chunk_ids, ctx->d_plan_order[nxt], nch, ctx->d_plan_tmp, tb) != 0)
@@ -368,11 +370,11 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   ++ctx->kernel_launches[p.corr_mode != OPE_CORR_NEAREST ? OPE_KERNEL_KNN : (packet && !recip) ? OPE_KERNEL_TREE_PACKET : OPE_KERNEL_TREE_LANE];
   launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
                         recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
-                        ctx->plan_valid ? ctx->d_plan_order[ctx->plan_cur] : nullptr, ctx->d_chunk_cost, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr,
+                        ctx->plan_valid ? ctx->d_plan_order[ctx->plan_cur] : nullptr, cost_w, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr,
                         (ctx->plan_valid && ctx->plan_cur_slots) ? ctx->d_plan_slots[ctx->plan_cur] : nullptr,
                         (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && !dev_env("OPE_NO_KNN_BOUND")) ? ctx->d_knn_rk : nullptr, ctx->d_plan_out + 8 * ctx->plan_cur,
                         timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr,
-                        ctx->measuring_flag, ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, (ctx->cert_run && ctx->cert_seen) ? ctx->d_cert_q : nullptr, ctx->d_cert_pos, ctx->d_pace, ++ctx->launch_no);
+                        ctx->measuring_flag, ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, (ctx->cert_run && ctx->cert_seen) ? ctx->d_cert_q : nullptr, ctx->d_cert_pos, ctx->d_pace, ++ctx->launch_no, ctx->wait_ticks);
   if (timed) ++ctx->prof_used;
   return OPE_OK;
 }
@@ -403,6 +405,8 @@ int ope_ctx_create(ope_ctx **out, int device_ordinal) {
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+    int nx = 0;   // XCDs: blocks are dealt to them round-robin (8 on an MI355X in SPX mode; a partitioned device reports its own)
+    if (hipDeviceGetAttribute(&nx, hipDeviceAttributeNumberOfXccs, device_ordinal) == hipSuccess && nx > 0 && nx <= 64) ctx->n_xcd = nx;
   }
   if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
     delete ctx;
@@ -479,7 +483,20 @@ void ope_ctx_destroy(ope_ctx *ctx) {
 
 int ope_ctx_set_stream(ope_ctx *ctx, void *hip_stream) {
   if (!ctx) return OPE_EINVAL;
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  if (next != ctx->stream) {
+    // temporaries cached for the stream that is left go back to the device (they are keyed by stream: nothing would reuse or
+    // release them once the context has moved on); frees synchronise, so nothing in flight still uses them
+    (void)hipSetDevice(ctx->device);
+    tmp_release_stream(ctx->stream);
+  }
+  ctx->stream = next;
+  return OPE_OK;
+}
+
+int ope_ctx_set_wait_limit(ope_ctx *ctx, double seconds) {
+  if (!ctx || !(seconds >= 0.0) || seconds > 40.0) return set_err(ctx, OPE_EINVAL, "ope_ctx_set_wait_limit: 0 <= seconds <= 40");
+  ctx->wait_ticks = (uint32_t)std::min(4.0e9, seconds * 1.0e8);   // wall_clock64: 100 MHz
   return OPE_OK;
 }
 
@@ -1063,7 +1080,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
       ctx->d_chunk_cost = ctx->d_chunk_cost_sorted = ctx->d_chunk_ids = ctx->d_chunk_order = nullptr;
       ctx->d_plan_tmp = nullptr;
       ctx->chunk_cap = 0;
-      OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_cost, 4 * nch));
+      OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_cost, 4 * 2 * nch));   // two halves, by launch parity (enqueue_accumulate)
       OPE_HIP(ctx, hipMalloc((void **)&ctx->d_chunk_cost_sorted, 4 * nch));
       if (ctx->d_chunk_keys) (void)hipFree(ctx->d_chunk_keys);
       ctx->d_chunk_keys = nullptr;
@@ -1093,7 +1110,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
       ctx->chunk_cap = nch;
     }
     fill_iota(ctx->stream, ctx->d_chunk_ids, (uint32_t)nch);
-    OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * nch, ctx->stream));
+    OPE_HIP(ctx, hipMemsetAsync(ctx->d_chunk_cost, 0, 4 * 2 * ctx->chunk_cap, ctx->stream));
     ctx->plan_pending = false;
     ctx->plan_cur = 0;
     ctx->plan_cur_slots = false;
@@ -1255,8 +1272,7 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     // one block slot left free on EVERY XCD: blocks are dealt to the eight XCDs round-robin and which XCD the update's one
     // workgroup is dealt to is not fixed; with the slot it always finds room, also when it arrives together with a launch
     // whose blocks are all about to wait for it (a host that enqueues no faster than the GPU works)
-    constexpr int kXcds = 8;   // gfx950
-    if (per_cu > 0) ctx->acc_blocks = std::max(1, std::min(ctx->acc_blocks, per_cu * ctx->n_cu - kXcds));
+    if (per_cu > 0) ctx->acc_blocks = std::max(1, std::min(ctx->acc_blocks, per_cu * ctx->n_cu - ctx->n_xcd));
     else ctx->chained = false;
   }
   if (const char *e = dev_env("OPE_ACC_BLOCKS")) ctx->acc_blocks = std::max(1, std::min(atoi(e), (int)kAccMaxBlocks));
@@ -1401,7 +1417,7 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
     TraceRange r_red(ctx, "reduce");
     if (chained) {
       // (the ticket word counts up through the run: acc_blocks is the same for every launch of a run)
-      launch_icp_update_chained(ctx->upd_stream, ctx->d_state, run_nsums(ctx), chain_ptr(ctx), ctx->chain_seq, (ctx->chain_seq + 1u) * (uint32_t)ctx->acc_blocks);
+      launch_icp_update_chained(ctx->upd_stream, ctx->d_state, run_nsums(ctx), chain_ptr(ctx), ctx->chain_seq, (ctx->chain_seq + 1u) * (uint32_t)ctx->acc_blocks, ctx->wait_ticks);
       ++ctx->chain_seq;
       continue;
     }
@@ -1495,7 +1511,7 @@ int ope_icp_profile_launches(ope_ctx *ctx, float *ms, size_t cap, size_t *n_out)
 int ope_debug_chunk_costs(ope_ctx *ctx, uint32_t *cost, uint32_t *order, uint32_t *plan_info4, int n) {
   if (!ctx || !ctx->run_active) return OPE_ESTATE;
   OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  OPE_HIP(ctx, hipMemcpy(cost, ctx->d_chunk_cost, 4 * (size_t)n, hipMemcpyDeviceToHost));
+  OPE_HIP(ctx, hipMemcpy(cost, ctx->d_chunk_cost + (size_t)((ctx->acc_launches + 1) & 1) * ctx->chunk_cap, 4 * (size_t)n, hipMemcpyDeviceToHost));   // the half the last launch wrote
   OPE_HIP(ctx, hipMemcpy(order, ctx->use_grid ? ctx->d_chunk_order : ctx->d_plan_order[ctx->plan_cur], 4 * (size_t)n, hipMemcpyDeviceToHost));
   OPE_HIP(ctx, hipMemcpy(plan_info4, ctx->use_grid ? ctx->d_work_counter + 8 : ctx->d_plan_out + 8 * ctx->plan_cur, 16, hipMemcpyDeviceToHost));
   return OPE_OK;

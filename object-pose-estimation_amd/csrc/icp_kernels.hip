@@ -37,29 +37,29 @@ static_assert(kCertCand >= 1 && kCertCand <= 8, "skip certificates: candidates p
 // its own next to accumulate launch j, is resident long before that launch ends and waits ON THE DEVICE for its blocks
 // (chain[0], one ticket per block, taken after the block's sums are in); accumulate launch j + 1 follows launch j on the
 // launch stream — the one boundary left runs while the update lane computes — and its blocks wait for update j's word
-// (chain[1] = number of updates published) before they read the transform.  Every wait is bounded (kChainTimeoutTicks of the
-// 100 MHz clock): a launch whose partner never shows up sets chain[2] / IcpState::chain_error and ends, so every wave of
+// (chain[1] = number of updates published) before they read the transform.  Every wait is bounded (wait_ticks of the
+// 100 MHz clock, ope_ctx_set_wait_limit): a launch whose partner never shows up sets chain[2] / IcpState::chain_error and ends, so every wave of
 // every launch reaches its exit.
 // The two kernels run at the same time on different XCDs, each with an L2 of its own, so the handful of words they share —
 // the three chain words, the sums, the transform rows, "done" — are only ever touched with agent-scope atomics (sc1: served
 // at the point all XCDs agree on), ordered by s_waitcnt alone.  NO agent-scope fences: on this part a release fence writes the
 // XCD's whole L2 back and an acquire fence invalidates it, and one such fence per block (the first build) evicted the
 // L2-resident index under the blocks still walking it: 145 -> 260 us per launch.
-constexpr unsigned long long kChainTimeoutTicks = 200000000ull;   // 2 s
+// (the bound is a launch argument: ope_ctx_set_wait_limit, 2 s by default)
 __device__ __forceinline__ uint32_t chain_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void chain_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void chain_wait_own_memory_ops() { __builtin_amdgcn_s_waitcnt(0); }   // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's stores and atomics have been acknowledged
 // Head of an accumulate launch: in-line runs (chain == nullptr) early-out on the "done" flag; overlapped runs first wait for
 // update chain_seq - 1 and then fetch the transform rows (s_const[0..11]) and "done" together, one round trip behind the word.
 // Returns false (for the whole block) if the launch has nothing to do.
-__device__ __forceinline__ bool acc_launch_begin(const IcpState *st, uint32_t *chain, uint32_t chain_seq, float *s_const) {
+__device__ __forceinline__ bool acc_launch_begin(const IcpState *st, uint32_t *chain, uint32_t chain_seq, float *s_const, uint32_t wait_ticks) {
   if (chain == nullptr) return st->done == 0;
   __shared__ uint32_t s_go[2];
   if (threadIdx.x == 0) {
     uint32_t go = 1u;
     const unsigned long long t0 = wall_clock64();
     while ((int32_t)(chain_load(chain + 1) - chain_seq) < 0) {
-      if (wall_clock64() - t0 > kChainTimeoutTicks) { go = 0u; atomicOr(chain + 2, 1u); break; }
+      if (wall_clock64() - t0 > (unsigned long long)wait_ticks) { go = 0u; atomicOr(chain + 2, 1u); break; }
       __builtin_amdgcn_s_sleep(2);
     }
     s_go[0] = go;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
     const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list,
     float *__restrict__ knn_rk, const uint32_t *__restrict__ plan_out, uint32_t measuring_launch, uint32_t *chain_arg, uint32_t chain_seq,
-    float4 *__restrict__ cert_q, uint32_t *__restrict__ cert_pos, uint32_t *pace, uint32_t launch_no) {
+    float4 *__restrict__ cert_q, uint32_t *__restrict__ cert_pos, uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks) {
   // pace (host-visible): "launch launch_no has started", i.e. every launch before it is over — the host keeps a bounded lead
   // over the GPU by it (api.hip: pace_wait), which is what lets it notice, a few launches late at most, that the update step
   // has asked for certifying launches (IcpState::cert_mode -> host_cert)
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
   // through): held in registers across the walk they were spilled to scratch, 13 dwords per lane and launch.
   __shared__ __attribute__((aligned(16))) float s_const[20];   // F rows [0..11], pivot [12..14], best0 [15], last_move [17], cert_k [18], cert_cap [19] (CERT)
   __shared__ uint32_t s_ncert;
-  if (!acc_launch_begin(st, chain, chain_seq, s_const)) return;
+  if (!acc_launch_begin(st, chain, chain_seq, s_const, wait_ticks)) return;
   constexpr int BLOCK = (MODE == 0) ? kAccBlock : kKnnBlock;
   constexpr bool OCT_OK = (MODE == 0) && !RECIP;  // the group traversal exists for plain 1-NN only
   __shared__ double s_red[BLOCK / 64][kNumSumsMax];
@@ -682,10 +682,10 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ hint, uint32_t *__restrict__ ghint,
     const uint32_t *__restrict__ qorder, unsigned char *__restrict__ qclass, const uint32_t *__restrict__ chunk_order,
     uint32_t *__restrict__ chunk_cost, const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, uint32_t measuring_launch,
-    uint32_t *chain, uint32_t chain_seq, uint32_t *pace, uint32_t launch_no) {
+    uint32_t *chain, uint32_t chain_seq, uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks) {
   if (pace != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(pace, launch_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // see icp_accumulate_kernel
   __shared__ __attribute__((aligned(16))) float s_const[20];   // F rows [0..11], pivot [12..14], best0 [15]; [16..19]: see icp_accumulate_kernel
-  if (!acc_launch_begin(st, chain, chain_seq, s_const)) return;
+  if (!acc_launch_begin(st, chain, chain_seq, s_const, wait_ticks)) return;
   constexpr int BLOCK = kAccBlock;
   __shared__ double s_red[BLOCK / 64][kNumSumsMax];
   __shared__ float s_stk[kMaxDepth + 1][BLOCK];
@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(64) void icp_update_kernel(IcpState *st, double *S,
 // enqueued behind it drain.  192 VGPRs (it needs 96): the wave must fit into the block slot that api.hip leaves free on every
 // XCD beside an accumulate launch (two of its waves per SIMD).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(192))) void icp_update_chained_kernel(IcpState *st, int nsums, uint32_t *chain,
-                                                                                                uint32_t seq, uint32_t tickets) {
+                                                                                                uint32_t seq, uint32_t tickets, uint32_t wait_ticks) {
   __shared__ double s_S[kNumSumsMax];
   __shared__ IcpState s_st;
   __shared__ uint32_t s_mode;   // 0: the run is over, 1: update, 2: the accumulate launch did not report in time
@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(192))) void icp_
     else {
       const unsigned long long t0 = wall_clock64();
       while ((int32_t)(chain_load(chain) - tickets) < 0) {
-        if (wall_clock64() - t0 > kChainTimeoutTicks) { mode = 2u; break; }
+        if (wall_clock64() - t0 > (unsigned long long)wait_ticks) { mode = 2u; break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -1482,9 +1482,12 @@ __global__ __launch_bounds__(64) void gather_fixed_pairs_kernel(CloudView src, C
 
 __global__ __launch_bounds__(64) void icp_fixed_pairs_kernel(const IcpState *__restrict__ st, const float4 *__restrict__ fix, uint32_t n, double *S) {
   if (st->done) return;
-  __shared__ double s_sum[kNumSums];
-  if (threadIdx.x < kNumSums) s_sum[threadIdx.x] = 0.0;
-  __syncthreads();
+  // (every lane adds its pairs — f = lane, lane + 64, ... — in that order, then the 64 lane sums are added in lane order: the
+  // pairs' share of the sums is the same bits from run to run, as ope_icp_params.deterministic_sums promises for the whole)
+  __shared__ double s_lane[kNumSums][64];
+  double acc[kNumSums];
+#pragma unroll
+  for (int k = 0; k < kNumSums; ++k) acc[k] = 0.0;
   const bool ns_mode = st->corr_mode == OPE_CORR_NORMAL_SHOOTING;
   const bool rej_sn = st->use_surface_normal_rej != 0, rej_so = st->use_self_occluded_rej != 0;
   const double thr_sn = st->surface_normal_thr, thr_so = st->self_occluded_thr;
@@ -1518,10 +1521,16 @@ __global__ __launch_bounds__(64) void icp_fixed_pairs_kernel(const IcpState *__r
                                    w * (tx * sx), w * (tx * sy), w * (tx * sz), w * (ty * sx), w * (ty * sy), w * (ty * sz),
                                    w * (tz * sx), w * (tz * sy), w * (tz * sz), w * (double)dist};
 #pragma unroll
-    for (int k = 0; k < kNumSums; ++k) unsafeAtomicAdd(&s_sum[k], term[k]);
+    for (int k = 0; k < kNumSums; ++k) acc[k] += term[k];
   }
+#pragma unroll
+  for (int k = 0; k < kNumSums; ++k) s_lane[k][threadIdx.x] = acc[k];
   __syncthreads();
-  if (threadIdx.x < kNumSums && s_sum[threadIdx.x] != 0.0) unsafeAtomicAdd(S + threadIdx.x, s_sum[threadIdx.x]);
+  if (threadIdx.x < kNumSums) {
+    double v = 0.0;
+    for (int l = 0; l < 64; ++l) v += s_lane[threadIdx.x][l];
+    if (v != 0.0) unsafeAtomicAdd(S + threadIdx.x, v);   // (one addition per component into sums no other launch touches at this point)
+  }
 }
 
 void launch_gather_fixed_pairs(hipStream_t stream, const CloudView &src, const CloudView &tgt, const uint32_t *pos, uint32_t n, float4 *fix) {
@@ -1695,7 +1704,7 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
                            const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
                            int k_normal_shooting, double *S_atomic, const uint32_t *slot_list, float *knn_rk, const uint32_t *plan_out,
                            hipEvent_t e0, hipEvent_t e1, bool measuring, uint32_t *chain, uint32_t chain_seq, float4 *cert_q, uint32_t *cert_pos,
-                           uint32_t *pace, uint32_t launch_no) {
+                           uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks) {
   const uint32_t mflag = measuring ? 1u : 0u;
   // e0 / e1 (ope_icp_profile): the launch's own start and stop time stamps, taken by the dispatch itself (hipExtLaunchKernelGGL).
   // Round 3 measured what a hipEventRecord before and after every launch costs the loop it times: 7-11 us per iteration (two
@@ -1704,10 +1713,10 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
   do {                                                                                                                        \
     if (e0 != nullptr)                                                                                                        \
       hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, e0, e1, 0, src, tgt, srcix, st, partials, corr_match, \
-                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert_q, cert_pos, pace, launch_no); \
+                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert_q, cert_pos, pace, launch_no, wait_ticks); \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, partials, corr_match, corr_d2,   \
-                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert_q, cert_pos, pace, launch_no); \
+                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert_q, cert_pos, pace, launch_no, wait_ticks); \
   } while (0)
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS) OPE_KLAUNCH((icp_accumulate_kernel<M, N, R>), BLK, LDS)
   const bool certify = cert_q != nullptr && mode == 0 && !recip;   // the certifying instantiation (api.hip decides when)
@@ -1770,16 +1779,16 @@ void launch_icp_accumulate_grid(hipStream_t stream, int nblocks, bool nrm, const
                                 const IcpState *st, double *partials, int32_t *corr_match, float *corr_d2, uint32_t *hint, uint32_t *ghint,
                                 const uint32_t *qorder, unsigned char *qclass, const uint32_t *chunk_order, uint32_t *chunk_cost,
                                 const uint32_t *plan_info, double *S_atomic, hipEvent_t e0, hipEvent_t e1, bool measuring, uint32_t *chain,
-                                uint32_t chain_seq, uint32_t *pace, uint32_t launch_no) {
+                                uint32_t chain_seq, uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks) {
   const uint32_t mflag = measuring ? 1u : 0u;
 #define OPE_KLAUNCH(KERNEL)                                                                                                   \
   do {                                                                                                                        \
     if (e0 != nullptr)                                                                                                        \
       hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, e0, e1, 0, src, tgt, grid, st, partials, corr_match, \
-                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no); \
+                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no, wait_ticks); \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, grid, st, partials, corr_match, corr_d2, \
-                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no); \
+                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no, wait_ticks); \
   } while (0)
   if (nrm) OPE_KLAUNCH((icp_accumulate_grid_kernel<true>));
   else OPE_KLAUNCH((icp_accumulate_grid_kernel<false>));
@@ -1801,8 +1810,8 @@ void launch_icp_lm_update(hipStream_t stream, IcpState *st, double *S, double *s
   hipLaunchKernelGGL(icp_lm_update_kernel, dim3(1), dim3(64), 0, stream, st, S, stats);
 }
 
-void launch_icp_update_chained(hipStream_t stream, IcpState *st, int nsums, uint32_t *chain, uint32_t seq, uint32_t tickets) {
-  hipLaunchKernelGGL(icp_update_chained_kernel, dim3(1), dim3(64), 0, stream, st, nsums, chain, seq, tickets);
+void launch_icp_update_chained(hipStream_t stream, IcpState *st, int nsums, uint32_t *chain, uint32_t seq, uint32_t tickets, uint32_t wait_ticks) {
+  hipLaunchKernelGGL(icp_update_chained_kernel, dim3(1), dim3(64), 0, stream, st, nsums, chain, seq, tickets, wait_ticks);
 }
 
 void launch_icp_update(hipStream_t stream, IcpState *st, double *S, int nsums, const float *Tk_ext) {

@@ -143,6 +143,8 @@ struct default_init_allocator : std::allocator<T> {
 struct ope_ctx {
   int device = -1;
   int n_cu = 256;   // compute units of the device (MI355X: 256)
+  int n_xcd = 8;    // XCDs of the device (hipDeviceAttributeNumberOfXccs; MI355X: 8)
+  uint32_t wait_ticks = 200000000u;   // bound of every device-side wait of the overlapped update launches, 100 MHz ticks (ope_ctx_set_wait_limit; 2 s)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string err;
@@ -400,29 +402,51 @@ inline void tmp_release_stream(hipStream_t s) {
 
 int set_err(ope_ctx *ctx, int code, const std::string &msg);
 
-// Host -> device copy from ANY host memory (the caller's arrays, vectors, stack variables), complete when it returns: through a
-// pinned staging block and a stream-ordered DMA, so that no entry point depends on what hipMemcpyAsync does with pageable
+// Host -> device copy from ANY host memory (the caller's arrays, vectors, stack variables); the SOURCE may be reused when it returns
+// (it has been copied into pinned memory), the device sees the data in stream order: through a pinned staging block and a
+// stream-ordered DMA, so that no entry point depends on what hipMemcpyAsync does with pageable
 // memory (staged at call time, pinned in place, or written through the BAR, by size and release).  Introduced while hunting the
 // facade's run-to-run differences (round 3, see tmp_malloc for what they were); every upload synchronises soon after anyway.
+// Staging is per host thread (contexts driven from different threads do not wait for each other; one thread's calls are serial
+// anyway).  Copies of at most kSmall bytes — transform rows, counters, seeds — go through a ring of pinned slots and do NOT
+// synchronise: a slot is reused only after the ring has come round, and the copy that used it is waited for then (an event).
 inline hipError_t h2d_copy(hipStream_t stream, void *dst, const void *src, size_t bytes) {
-  static std::mutex mu;
-  static unsigned char *stage = nullptr;
-  static size_t cap = 0;
-  constexpr size_t kChunk = (size_t)32 << 20;
+  constexpr size_t kChunk = (size_t)32 << 20, kSmall = 4096;
+  constexpr int kRing = 16;
+  struct Stage {
+    unsigned char *big = nullptr; size_t cap = 0;
+    unsigned char *ring = nullptr; hipEvent_t ev[kRing] = {}; bool used[kRing] = {}; int next = 0;
+  };
+  static thread_local Stage st;
   if (bytes == 0) return hipSuccess;
-  std::lock_guard<std::mutex> lock(mu);
-  const size_t want = std::min(std::max(bytes, (size_t)65536), kChunk);
-  if (cap < want) {
-    if (stage) (void)hipHostFree(stage);
-    stage = nullptr; cap = 0;
-    const hipError_t e = hipHostMalloc((void **)&stage, want, hipHostMallocPortable);
-    if (e != hipSuccess) return e;
-    cap = want;
+  if (bytes <= kSmall) {
+    if (st.ring == nullptr) {
+      hipError_t e = hipHostMalloc((void **)&st.ring, kSmall * kRing, hipHostMallocPortable);
+      if (e != hipSuccess) { st.ring = nullptr; return e; }
+      for (int k = 0; k < kRing; ++k)
+        if ((e = hipEventCreateWithFlags(&st.ev[k], hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    const int k = st.next;
+    st.next = (k + 1) % kRing;
+    if (st.used[k]) { const hipError_t e = hipEventSynchronize(st.ev[k]); if (e != hipSuccess) return e; }
+    std::memcpy(st.ring + (size_t)k * kSmall, src, bytes);
+    hipError_t e = hipMemcpyAsync(dst, st.ring + (size_t)k * kSmall, bytes, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipEventRecord(st.ev[k], stream);
+    st.used[k] = e == hipSuccess;
+    return e;
   }
-  for (size_t off = 0; off < bytes; off += cap) {
-    const size_t c = std::min(cap, bytes - off);
-    std::memcpy(stage, static_cast<const unsigned char *>(src) + off, c);
-    hipError_t e = hipMemcpyAsync(static_cast<unsigned char *>(dst) + off, stage, c, hipMemcpyHostToDevice, stream);
+  const size_t want = std::min(std::max(bytes, (size_t)65536), kChunk);
+  if (st.cap < want) {
+    if (st.big) (void)hipHostFree(st.big);
+    st.big = nullptr; st.cap = 0;
+    const hipError_t e = hipHostMalloc((void **)&st.big, want, hipHostMallocPortable);
+    if (e != hipSuccess) return e;
+    st.cap = want;
+  }
+  for (size_t off = 0; off < bytes; off += st.cap) {
+    const size_t c = std::min(st.cap, bytes - off);
+    std::memcpy(st.big, static_cast<const unsigned char *>(src) + off, c);
+    hipError_t e = hipMemcpyAsync(static_cast<unsigned char *>(dst) + off, st.big, c, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return e;
   }

@@ -106,9 +106,10 @@ def test_automatic_mode_turns_certificates_on_by_itself_and_changes_nothing(ctx,
     # its candidates where a walk takes whichever it visits first — differences of 1e-9 in a sum, amplified by a hundred
     # iterations of a scene that is still settling: 4e-6 seen; north_star's bound is 1e-4)
     assert np.linalg.norm(out0.T.astype(np.float64) - out1.T.astype(np.float64)) < 2e-5
-    # (launch 100 searched with the transform of iteration 99, which the two runs know to ~1e-9: a query within that of a
-    # Voronoi face may differ)
-    assert (m0 != m1).mean() < 1e-4
+    # (launch 100 searched with the transform of iteration 99, which the two runs know to a few 1e-6 — see above —, i.e. the
+    # queries sit a micron apart in the two runs: the one in ten thousand that lies that close to a Voronoi face may differ;
+    # what a launch returns for the transform IT searched with is pinned bit for bit by the tests above)
+    assert (m0 != m1).mean() < 1e-3
     print("automatic mode:", st1)
 
 

@@ -721,6 +721,47 @@ def test_overlapped_batches_interleaved_with_the_step_wise_entry_points(ctx):
     assert frob(T4, ref4.T) < 2e-5
 
 
+def test_overlapped_update_that_gives_up_resumes_in_line_on_the_same_pose():
+    """The recovery branch of the default launch path (api.hip: ope_icp_poll, chain_error).  An overlapped update launch waits on
+    the device, for a bounded time, for the blocks of its accumulate launch; ope_ctx_set_wait_limit makes the bound a
+    microsecond here, so update 0 gives up while launch 0 is still walking: it sets chain_error and "done", every launch and
+    update behind it drains without touching the sums, and the next poll finds the state at the last completed iteration
+    (none), clears the flags and the partial sums, enqueues the lost iterations again in line and stays in line.  The result
+    must be the in-line run's; later runs of the context launch in line, a fresh context overlaps again."""
+    ope = load_pkg()
+    src = synth.scene_cloud(100000)
+    tgt = synth.model_surface(20000, 1)
+    kw = dict(max_iterations=30, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0)
+    c2 = ope.Context(0)
+    try:
+        with pytest.raises(ope.OpeError):
+            c2.set_wait_limit(-1.0)
+        c2.set_wait_limit(1e-6)
+        cs = c2.upload(src)
+        ix = c2.build_index(c2.upload(tgt), grid=0)
+        for batch in (0, 7):                                 # one batch of 30, and batches of 7 with polls in between
+            broken = c2.icp(cs, ix, ope.default_icp_params(update_launch=0, check_every=batch, **kw))
+            if batch == 0:
+                assert c2.icp_overlapped_updates() == 30     # the run WAS launched overlapped ...
+            else:
+                assert c2.icp_overlapped_updates() == 0      # ... and the context launches in line ever after
+            line = c2.icp(cs, ix, ope.default_icp_params(update_launch=1, check_every=batch, **kw))
+            assert broken.iterations == line.iterations == 30 and broken.state == line.state and broken.n_corr == line.n_corr
+            assert frob(broken.T, line.T) < 1e-5             # (run-to-run noise of the atomic sums, as between two in-line runs)
+        ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw))
+        assert frob(broken.T, ref.T) < 2e-5
+    finally:
+        c2.close()
+    c3 = ope.Context(0)
+    try:
+        cs = c3.upload(src)
+        ix = c3.build_index(c3.upload(tgt), grid=0)
+        again = c3.icp(cs, ix, ope.default_icp_params(update_launch=0, **kw))
+        assert c3.icp_overlapped_updates() == 30 and frob(again.T, ref.T) < 2e-5
+    finally:
+        c3.close()
+
+
 # ------------------------------------------------------------------ fixed correspondences (vPCL icp_mod.h:268, icp_mod.hpp:150-151,210-224)
 def _fixed_case():
     src = synth.scene_cloud(20000)
@@ -747,6 +788,11 @@ def test_fixed_correspondences_1nn_match_oracle(ctx, deterministic):
     assert out.n_corr == ref.n_corr == len(src) + len(fq)
     assert frob(out.T, ref.T) < 2e-5
     assert out.last_mse == pytest.approx(ref.last_mse, rel=1e-5)  # dominated by the forty 1e10-scaled distances
+    if deterministic:
+        # the given pairs' share is added in a fixed order too (icp_fixed_pairs_kernel): the same bits from run to run
+        again = ctx.icp(cs, ix, ope.default_icp_params(deterministic_sums=1, **kw))
+        np.testing.assert_array_equal(again.T, out.T)
+        assert again.last_mse == out.last_mse
     ctx.icp_set_fixed_correspondences(None, None)                 # clearCorrespondences
     plain = ctx.icp(cs, ix, ope.default_icp_params(**kw))
     ref0 = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw))
