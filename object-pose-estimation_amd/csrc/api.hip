@@ -30,7 +30,7 @@ hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t,
                             float4 **, float4 **, float4 **);
 void launch_icp_accumulate_grid(hipStream_t, int, bool, const CloudView &, const BvhView &, const GridView &, const IcpState *, double *, int32_t *,
                                 float *, uint32_t *, uint32_t *, const uint32_t *, unsigned char *, const uint32_t *, uint32_t *, const uint32_t *,
-                                double *, hipEvent_t, hipEvent_t, bool, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t);
+                                double *, hipEvent_t, hipEvent_t, bool, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t, float4 *, uint32_t *, uint32_t *);
 int grid_plan(hipStream_t, bool, const unsigned char *, uint32_t, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, const uint32_t *,
               uint32_t *, uint32_t, uint32_t, float, float, void *, size_t);
 size_t grid_plan_tmp_bytes(uint32_t, uint32_t);
@@ -280,7 +280,8 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
                                ctx->plan_valid ? ctx->d_chunk_order : nullptr, cost_w, ctx->d_work_counter + 8,
                                atomic_sums ? sums_ptr(ctx) : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr,
                                timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr, ctx->measuring_flag,
-                               ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, ctx->d_pace, ++ctx->launch_no, ctx->wait_ticks);
+                               ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, ctx->d_pace, ++ctx->launch_no, ctx->wait_ticks,
+                               (ctx->cert_run && ctx->cert_seen) ? ctx->d_cert_q : nullptr, ctx->d_cert_pos, ctx->d_work_counter + 40);
     if (timed) ++ctx->prof_used;
     return OPE_OK;
   }
@@ -519,37 +520,54 @@ int ope_cloud_upload(ope_ctx *ctx, const void *base, size_t n, size_t stride_byt
   ope_cloud *c = new ope_cloud();
   c->ctx = ctx;
   c->n = n;
-  c->h_xyz.resize(n * 3);
+  // The host mirrors (original-order xyz, permutation) are materialised on first use, as for clouds made on the device
+  // (ensure_host): most clouds are uploaded, searched and dropped without anyone asking for them.
+  c->host_valid = false;
   const unsigned char *b = static_cast<const unsigned char *>(base);
-  // one pass: gather xyz out of the caller's structs and take the bounding box of the finite points
-  // (large clouds: a few host threads, each over a contiguous range; min / max / count merge exactly)
+  float *d_raw = nullptr;
+  int32_t *d_perm = nullptr;
+  hipError_t e = hipMalloc((void **)&c->d_xyzw, sizeof(float4) * std::max<size_t>(n, 1));
+  if (e == hipSuccess && n) e = tmp_malloc(ctx->stream, (void **)&d_raw, 12 * n);
+  if (e == hipSuccess && n) e = tmp_malloc(ctx->stream, (void **)&d_perm, 4 * n);
+  // One pass over the caller's structs: xyz gathered STRAIGHT INTO the pinned staging block (a few host threads, each over a
+  // contiguous range; min / max / count merge exactly), one DMA per block of 32 MB.  (Round 3 gathered into a host vector,
+  // copied that into the staging block and read the permutation back: 3 ms per million points, now ~1.)
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   size_t nv = 0;
   {
     struct Part { float lo[3], hi[3]; size_t nv; };
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nt = n >= ((size_t)1 << 18) ? std::min(8u, hw) : 1u;
-    std::vector<Part> parts(nt);
-    float *dst = c->h_xyz.data();
-    auto work = [&](unsigned t) {
-      Part pt{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}, 0};
-      const size_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
-      for (size_t i = i0; i < i1; ++i) {
-        float *p = dst + 3 * i;
-        std::memcpy(p, b + i * stride_bytes + xyz_off, 12);
-        if (!finite3(p)) continue;
-        ++pt.nv;
-        for (int d = 0; d < 3; ++d) { pt.lo[d] = std::min(pt.lo[d], p[d]); pt.hi[d] = std::max(pt.hi[d], p[d]); }
+    unsigned char *blk = nullptr;
+    size_t cap = 0;
+    if (e == hipSuccess && n) e = stage_block(12 * n, &blk, &cap);
+    const size_t per_block = cap / 12;
+    for (size_t i_base = 0; e == hipSuccess && i_base < n; i_base += per_block) {
+      const size_t cnt = std::min(per_block, n - i_base);
+      const unsigned nt = cnt >= ((size_t)1 << 18) ? std::min(8u, hw) : 1u;
+      std::vector<Part> parts(nt);
+      float *dst = reinterpret_cast<float *>(blk);
+      auto work = [&](unsigned t) {
+        Part pt{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}, 0};
+        const size_t i0 = cnt * t / nt, i1 = cnt * (t + 1) / nt;
+        for (size_t i = i0; i < i1; ++i) {
+          float *p = dst + 3 * i;
+          std::memcpy(p, b + (i_base + i) * stride_bytes + xyz_off, 12);
+          if (!finite3(p)) continue;
+          ++pt.nv;
+          for (int d = 0; d < 3; ++d) { pt.lo[d] = std::min(pt.lo[d], p[d]); pt.hi[d] = std::max(pt.hi[d], p[d]); }
+        }
+        parts[t] = pt;
+      };
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
+      work(0);
+      for (auto &th : pool) th.join();
+      for (const Part &pt : parts) {
+        nv += pt.nv;
+        for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], pt.lo[d]); hi[d] = std::max(hi[d], pt.hi[d]); }
       }
-      parts[t] = pt;
-    };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto &th : pool) th.join();
-    for (const Part &pt : parts) {
-      nv += pt.nv;
-      for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], pt.lo[d]); hi[d] = std::max(hi[d], pt.hi[d]); }
+      e = hipMemcpyAsync(reinterpret_cast<unsigned char *>(d_raw) + 12 * i_base, blk, 12 * cnt, hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // (the block is refilled, or handed back, next)
     }
   }
   c->n_valid = nv;
@@ -560,15 +578,7 @@ int ope_cloud_upload(ope_ctx *ctx, const void *base, size_t n, size_t stride_byt
   // gather into float4 {x, y, z, input index} run on the device (a host std::sort of 1 M keys took ~50 ms).
   float inv[3];
   for (int d = 0; d < 3; ++d) inv[d] = (hi[d] > lo[d]) ? 1023.999f / (hi[d] - lo[d]) : 0.f;
-  c->perm.resize(n);
-  float *d_raw = nullptr;
-  int32_t *d_perm = nullptr;
-  hipError_t e = hipMalloc((void **)&c->d_xyzw, sizeof(float4) * std::max<size_t>(n, 1));
-  if (e == hipSuccess && n) e = tmp_malloc(ctx->stream, (void **)&d_raw, 12 * n);
-  if (e == hipSuccess && n) e = tmp_malloc(ctx->stream, (void **)&d_perm, 4 * n);
-  if (e == hipSuccess && n) e = h2d_copy(ctx->stream, d_raw, c->h_xyz.data(), 12 * n);
   if (e == hipSuccess && n) e = morton_order_device(ctx->stream, d_raw, n, lo, inv, c->d_xyzw, d_perm);
-  if (e == hipSuccess && n) e = hipMemcpy(c->perm.data(), d_perm, 4 * n, hipMemcpyDeviceToHost);
   tmp_free(ctx->stream, d_raw);
   tmp_free(ctx->stream, d_perm);
   if (e != hipSuccess) {

@@ -163,6 +163,101 @@ __global__ __launch_bounds__(256) void level_key_kernel(const float4 *__restrict
   keys[p] = ((unsigned long long)node << 16) | (unsigned long long)qk;
 }
 
+// The same key in 32 bits for the levels where it fits (node < 2^level, level + 16 <= 32): a third less traffic per radix pass.
+__global__ __launch_bounds__(256) void level_key32_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ order, uint32_t n, int D,
+                                                           int level, const uint32_t *__restrict__ mn, const uint32_t *__restrict__ mx,
+                                                           uint32_t *__restrict__ keys) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t node = leaf_of(p, n, D) >> (D - level);
+  const float ex = dec_f32(mx[3 * node + 0]) - dec_f32(mn[3 * node + 0]), ey = dec_f32(mx[3 * node + 1]) - dec_f32(mn[3 * node + 1]),
+              ez = dec_f32(mx[3 * node + 2]) - dec_f32(mn[3 * node + 2]);
+  int dim = 0;
+  float e = ex;
+  if (ey > e) { dim = 1; e = ey; }
+  if (ez > e) dim = 2;
+  const float4 q = pts[order[p]];
+  const float c = dim == 0 ? q.x : (dim == 1 ? q.y : q.z);
+  const float lo_d = dec_f32(mn[3 * node + dim]);
+  const float ext = dim == 0 ? ex : (dim == 1 ? ey : ez);
+  const float tq = ext > 0.f ? (c - lo_d) * (65535.0f / ext) : 0.f;
+  keys[p] = (node << 16) | (uint32_t)fminf(fmaxf(tq, 0.f), 65535.0f);
+}
+
+// ---- the bottom of the tree in ONE launch.  From the level on at which a node holds at most kBotPoints points, a block takes one
+// node and carries its range through ALL remaining levels: per level the sub-nodes' bounding boxes (LDS atomics on the
+// order-preserving images), the widest axis, the same 16-bit position key, and a stable block-wide radix sort of
+// (sub-node, key) with the point's source index as payload — registers and LDS only, the points themselves are gathered from
+// global memory (L2) once per level.  A level of the global loop above is a dozen launches (two fills, boxes, keys and the
+// passes of a device-wide sort); for a cloud of 500 k points that loop now ends after eight levels instead of fifteen, and a
+// cloud of up to kBotPoints points (key points, descriptor clouds) is ordered by a single block.
+// 16-bit position of a point along the widest axis of its node's bounding box (level_key_kernel's key).  Not inlined: with
+// this selection chain inlined into the eight-item loop below, instruction selection of ROCm 7.2's compiler crashes.
+__device__ __noinline__ uint32_t split_key16(float x, float y, float z, float lx, float ly, float lz, float hx, float hy, float hz) {
+  const float ex = hx - lx, ey = hy - ly, ez = hz - lz;
+  const bool by = ey > ex;
+  const float e1 = by ? ey : ex;
+  const bool bz = ez > e1;
+  const float cc = bz ? z : (by ? y : x), lo = bz ? lz : (by ? ly : lx), ext = bz ? ez : e1;
+  const float tq = ext > 0.f ? (cc - lo) * (65535.0f / ext) : 0.f;
+  return (uint32_t)fminf(fmaxf(tq, 0.f), 65535.0f);
+}
+constexpr int kBotItems = 8;
+constexpr uint32_t kBotPoints = 256 * kBotItems;
+constexpr int kBotMaxLevels = 11;   // 2048 points -> buckets of one point
+__global__ __launch_bounds__(256) void bottom_levels_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ order_in, uint32_t n, int D,
+                                                             int L0, uint32_t *__restrict__ order_out) {
+  using Sort = rocprim::block_radix_sort<uint32_t, 256, kBotItems, uint32_t>;
+  __shared__ typename Sort::storage_type s_sort;
+  __shared__ uint32_t s_mn[3u << (kBotMaxLevels - 1)], s_mx[3u << (kBotMaxLevels - 1)];
+  const uint32_t j0 = blockIdx.x;   // node (L0, j0)
+  const uint32_t b = leaf_start((unsigned long long)j0 << (D - L0), n, D), e = leaf_start((unsigned long long)(j0 + 1) << (D - L0), n, D);
+  const uint32_t m = e - b;
+  uint32_t idx[kBotItems], leaf[kBotItems];
+#pragma unroll
+  for (int i = 0; i < kBotItems; ++i) {   // blocked arrangement: item i of thread t is position t * kBotItems + i of the range
+    const uint32_t p = threadIdx.x * kBotItems + i;
+    idx[i] = p < m ? order_in[b + p] : 0xffffffffu;
+    leaf[i] = p < m ? leaf_of(b + p, n, D) : 0u;
+  }
+  for (int level = L0; level < D; ++level) {
+    const uint32_t nsub = 1u << (level - L0), sub0 = j0 << (level - L0);
+    for (uint32_t k = threadIdx.x; k < nsub * 3u; k += 256u) { s_mn[k] = 0xffffffffu; s_mx[k] = 0u; }
+    __syncthreads();
+    float c[kBotItems][3];
+    uint32_t sub[kBotItems];
+#pragma unroll
+    for (int i = 0; i < kBotItems; ++i) {
+      const bool live = idx[i] != 0xffffffffu;
+      sub[i] = live ? (leaf[i] >> (D - level)) - sub0 : 0u;
+      const float4 q = pts[live ? idx[i] : 0u];
+      c[i][0] = q.x; c[i][1] = q.y; c[i][2] = q.z;
+      if (live) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { atomicMin(&s_mn[3u * sub[i] + d], enc_f32(c[i][d])); atomicMax(&s_mx[3u * sub[i] + d], enc_f32(c[i][d])); }
+      }
+    }
+    __syncthreads();
+    uint32_t keys[kBotItems];
+#pragma unroll
+    for (int i = 0; i < kBotItems; ++i) {
+      const bool live = idx[i] != 0xffffffffu;
+      const uint32_t sn = sub[i];
+      const uint32_t q16 = split_key16(c[i][0], c[i][1], c[i][2], dec_f32(s_mn[3u * sn]), dec_f32(s_mn[3u * sn + 1u]), dec_f32(s_mn[3u * sn + 2u]),
+                                       dec_f32(s_mx[3u * sn]), dec_f32(s_mx[3u * sn + 1u]), dec_f32(s_mx[3u * sn + 2u]));
+      keys[i] = live ? ((sn << 16) | q16) : 0xffffffffu;   // (padding sorts behind every point)
+    }
+    __syncthreads();
+    Sort().sort(keys, idx, s_sort, 0, 32);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < kBotItems; ++i) {
+    const uint32_t p = threadIdx.x * kBotItems + i;
+    if (p < m) order_out[b + p] = idx[i];
+  }
+}
+
 __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *v, uint32_t n, uint32_t value) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) v[i] = value;
@@ -531,19 +626,35 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
   if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_order2, 4 * n);
   if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_mn, 12 * ((size_t)1 << D));
   if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_mx, 12 * ((size_t)1 << D));
-  size_t tmp_bytes = 0;
+  // the levels whose nodes hold more than kBotPoints points: one device-wide sort each; everything below: one launch
+  int L0 = 0;
+  while (L0 < D && ((n + ((size_t)1 << L0) - 1) >> L0) > (size_t)kBotPoints) ++L0;
+  if (D - L0 > kBotMaxLevels) L0 = D - kBotMaxLevels;   // (leaf size 1 on a small cloud: the kernel's box table has 2^10 rows)
+  uint32_t *d_keys32 = reinterpret_cast<uint32_t *>(d_keys), *d_keys32b = reinterpret_cast<uint32_t *>(d_keys2);
+  size_t tmp_bytes = 0, tmp_bytes32 = 0;
   if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_order, d_order2, n, 0, 64, stream);
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes32, d_keys32, d_keys32b, d_order, d_order2, n, 0, 32, stream);
+  tmp_bytes = std::max(tmp_bytes, tmp_bytes32);
   if (e == hipSuccess) e = tmp_malloc(stream, &d_tmp, tmp_bytes);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(iota_u32_kernel, dim3(nb), dim3(256), 0, stream, d_order, nn);
-    for (int level = 0; level < D && e == hipSuccess; ++level) {
+    for (int level = 0; level < L0 && e == hipSuccess; ++level) {
       const uint32_t cnt = 3u << level;
       hipLaunchKernelGGL(fill_u32_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_mn, cnt, 0xffffffffu);
       hipLaunchKernelGGL(fill_u32_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_mx, cnt, 0u);
       hipLaunchKernelGGL(level_bbox_kernel, dim3(nb_bbox), dim3(256), 0, stream, d_src, d_order, nn, D, level, bbox_rows, d_mn, d_mx);
-      hipLaunchKernelGGL(level_key_kernel, dim3(nb), dim3(256), 0, stream, d_src, d_order, nn, D, level, d_mn, d_mx, d_keys);
       size_t tb = tmp_bytes;
-      e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_order, d_order2, n, 0, 16 + std::max(level, 1), stream);
+      if (level + 16 <= 32) {
+        hipLaunchKernelGGL(level_key32_kernel, dim3(nb), dim3(256), 0, stream, d_src, d_order, nn, D, level, d_mn, d_mx, d_keys32);
+        e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys32, d_keys32b, d_order, d_order2, n, 0, 16 + std::max(level, 1), stream);
+      } else {
+        hipLaunchKernelGGL(level_key_kernel, dim3(nb), dim3(256), 0, stream, d_src, d_order, nn, D, level, d_mn, d_mx, d_keys);
+        e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_order, d_order2, n, 0, 16 + std::max(level, 1), stream);
+      }
+      std::swap(d_order, d_order2);
+    }
+    if (e == hipSuccess && L0 < D) {
+      hipLaunchKernelGGL(bottom_levels_kernel, dim3(1u << L0), dim3(256), 0, stream, d_src, d_order, nn, D, L0, d_order2);
       std::swap(d_order, d_order2);
     }
   }

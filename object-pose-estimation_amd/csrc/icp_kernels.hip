@@ -136,6 +136,75 @@ __device__ __forceinline__ void add_query_sums(double *acc, lds_cfloat_ptr cs2, 
     }
 }
 
+// ---- skip certificates: the two pieces the tree kernel and the grid kernel share (see icp_accumulate_kernel, "certified search")
+// The check.  Returns true if the query at (x, y, z) is answered by its certificate: best / pos (position in the index's point
+// order) then hold what a search would return.  stuck: the certificate failed where it was built (a new one would be no better).
+__device__ __forceinline__ bool cert_check(const BvhView &tgt, const float4 *__restrict__ cert_q, const uint32_t *__restrict__ cert_pos, size_t cstride,
+                                           uint32_t i, float x, float y, float z, float best_init, float last_move, float &best, uint32_t &pos,
+                                           bool &stuck, bool &has_cert) {
+  stuck = false;
+  const uint32_t p0 = cert_pos[i];
+  has_cert = p0 != 0u;
+  if (!has_cert) return false;
+  const v4f c = ld16(cert_q + i);
+  uint32_t pj[kCertCand];
+  pj[0] = p0;
+#pragma unroll
+  for (int j = 1; j < kCertCand; ++j) pj[j] = cert_pos[(size_t)j * cstride + i];
+  float b1 = INFINITY;   // the nearest candidate, from where the query is now
+  uint32_t bp = 0u;
+#pragma unroll
+  for (int j = 0; j < kCertCand; ++j) {
+    const v4f tp = ld16(tgt.pts + ((pj[j] != 0u ? pj[j] : p0) - 1u));
+    const float dj = pj[j] != 0u ? sq_dist3(__fsub_rn(x, tp.x), __fsub_rn(y, tp.y), __fsub_rn(z, tp.z)) : INFINITY;
+    const bool lt = dj < b1;
+    bp = lt ? pj[j] - 1u : bp;
+    b1 = lt ? dj : b1;
+  }
+  const float dl = __builtin_amdgcn_sqrtf(sq_dist3(__fsub_rn(x, c.x), __fsub_rn(y, c.y), __fsub_rn(z, c.z)));
+  // L - dl rounded DOWN (one float below the rounded difference); a query that sits where it walked keeps its L
+  const float L1 = dl == 0.f ? c.w : __uint_as_float(__float_as_uint(__fsub_rn(c.w, __fmaf_rn(dl, 1.000001f, 1e-30f))) - 1u);
+  const float T = __fmul_rn(__fmul_rn(L1, L1), 0.999999f);
+  // (Two candidates at the very same computed d2: which of them a search returns is a matter of its visiting order — the
+  // reference's kd-tree, the walks here and the oracle each have their own — and the distance is the same bit for bit: the
+  // certificate takes the first in its list, as the tests allow every search on exact ties.)
+  if (L1 > 0.f && b1 < T && b1 < best_init) { best = b1; pos = bp; return true; }
+  stuck = !(dl > 4.0f * last_move);
+  return false;
+}
+// The walk that builds one: the kCertCand + 1 nearest from (x, y, z), start leaf h.  best / pos / leaf: the nearest (what the 1-NN
+// search returns); `write`: this lane records the certificate.
+__device__ __forceinline__ void cert_build(const BvhView &tgt, float4 *__restrict__ cert_q, uint32_t *__restrict__ cert_pos, size_t cstride, uint32_t i,
+                                           float x, float y, float z, float best_init, uint32_t h, float *stk, int stk_stride, bool build, bool write,
+                                           float &best, uint32_t &pos, uint32_t &leaf) {
+  constexpr int K = kCertCand + 1;
+  KnnRegVisitor<K> kv;
+  kv.init(build, best_init);
+  if (build) bvh_traverse(tgt, x, y, z, kv, stk, stk_stride, h);
+  if (build) {
+    best = kv.count > 0 ? kv.d[0] : best_init;
+    pos = kv.count > 0 ? kv.p[0] : kNoPos;
+    leaf = kv.count > 0 ? kv.leaf : h;
+    if (write) {
+      // every point outside the list has a computed d2 of at least d[K-1] (a list that is not full still holds the walk's
+      // starting bound there) -> a true distance of at least its square root less 2.5u; the square root is good to 1 ulp
+      const float Lw = __fmul_rn(__builtin_amdgcn_sqrtf(kv.d[K - 1]), 0.9999995f);
+#pragma unroll
+      for (int j = 0; j < kCertCand; ++j) cert_pos[(size_t)j * cstride + i] = j < kv.count ? kv.p[j] + 1u : 0u;
+      cert_q[i] = make_float4(x, y, z, Lw);
+    }
+  }
+}
+// Whether a query that has to walk builds a certificate: what one would be worth — its slack, distance of the (kCertCand + 1)-th
+// neighbour less the nearest's, ~ cert_k / D for a query D from the surface, at most cert_cap — against kCertWorth launches of the
+// scene's displacement (the displacements of a converging run sum to about a dozen times the current one: a certificate built then
+// usually holds to the end).  Surface points build soon after the launches start keeping certificates; a point 10 cm out, whose
+// neighbours all lie within microns of each other in distance, once the scene moves by less than a micron per launch.
+__device__ __forceinline__ bool cert_worth_building(float d2_prev, float cert_k, float cert_cap, float last_move) {
+  const float dprev = __builtin_amdgcn_sqrtf(d2_prev);           // (+inf before the first match: no slack, no certificate yet)
+  return fminf(cert_cap, cert_k * __builtin_amdgcn_rcpf(dprev)) >= kCertWorth * last_move;
+}
+
 // MODE 0: 1-NN correspondences.  MODE 2: normal shooting over the k nearest, list in KREG >= k registers (every k <= 32:
 // KREG = k rounded up to a multiple of four, plus 10, the class default of vPCL
 // correspondence_estimation_normal_shooting_weighted.h:117; the reference uses 20, poseestimator.cpp:246,
@@ -308,60 +377,15 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       // a walk would return, bit for bit.  Nothing is written but the correspondence.
       const float best_init = active ? cst[15] : -INFINITY;
       const size_t cstride = src.n;
-      bool need = active;
-      bool stuck = false;   // a certificate that fails where it was built: a new one from here would be no better
+      bool need = active, stuck = false, has_cert = false;
       float c_best = INFINITY;
       uint32_t c_pos = 0u;
-      if (active) {
-        const uint32_t p0 = cert_pos[i];
-        if (p0 != 0u) {
-          const v4f c = ld16(cert_q + i);
-          uint32_t pj[kCertCand];
-          pj[0] = p0;
-#pragma unroll
-          for (int j = 1; j < kCertCand; ++j) pj[j] = cert_pos[(size_t)j * cstride + i];
-          float b1 = INFINITY, b2 = INFINITY;   // nearest and runner-up among the candidates, from where the query is now
-          uint32_t bp = 0u;
-#pragma unroll
-          for (int j = 0; j < kCertCand; ++j) {
-            const v4f tp = ld16(tgt.pts + ((pj[j] != 0u ? pj[j] : p0) - 1u));
-            const float dj = pj[j] != 0u ? sq_dist3(__fsub_rn(x, tp.x), __fsub_rn(y, tp.y), __fsub_rn(z, tp.z)) : INFINITY;
-            const bool lt = dj < b1;
-            b2 = lt ? b1 : fminf(b2, dj);
-            bp = lt ? pj[j] - 1u : bp;
-            b1 = lt ? dj : b1;
-          }
-          const float dl = __builtin_amdgcn_sqrtf(sq_dist3(__fsub_rn(x, c.x), __fsub_rn(y, c.y), __fsub_rn(z, c.z)));
-          // L - dl rounded DOWN (one float below the rounded difference); a query that sits where it walked keeps its L
-          const float L1 = dl == 0.f ? c.w : __uint_as_float(__float_as_uint(__fsub_rn(c.w, __fmaf_rn(dl, 1.000001f, 1e-30f))) - 1u);
-          const float T = __fmul_rn(__fmul_rn(L1, L1), 0.999999f);
-          // (b1 == b2: two candidates at the very same computed d2.  Which of them a search returns is a matter of its visiting
-          // order — the reference's kd-tree, the walks here and the oracle each have their own — and the distance is the same
-          // bit for bit: the certificate takes the first in its list, as the tests allow every search on exact ties.)
-          if (L1 > 0.f && b1 < T && b1 < best_init) { need = false; c_best = b1; c_pos = bp; }
-          else stuck = !(dl > 4.0f * cst[17]);
-#ifdef OPE_DEVELOPER   // tools/cert_probe.py: why certificates fail {expired: the bound, a tie among the candidates}
-          if (need && owner) atomicAdd(work_counter + (stuck ? 45 : 44), 1u);
+      if (active) need = !cert_check(tgt, cert_q, cert_pos, cstride, i, x, y, z, best_init, cst[17], c_best, c_pos, stuck, has_cert);
+#ifdef OPE_DEVELOPER   // tools/cert_probe.py: why certificates fail {expired, stuck where it was built, none yet}
+      if (need && owner) atomicAdd(work_counter + (!has_cert ? 46 : stuck ? 45 : 44), 1u);
 #endif
-        }
-#ifdef OPE_DEVELOPER
-        else if (owner) atomicAdd(work_counter + 46, 1u);   // no certificate
-#endif
-      }
-      // A query without a valid certificate walks.  Whether that walk BUILDS a certificate (a (kCertCand + 1)-nearest walk, dearer
-      // than the 1-NN walks) is decided per query from what a certificate would be worth: its slack — distance of the
-      // (kCertCand + 1)-th neighbour less the nearest's, ~ cert_k / D for a query D from the surface, at most cert_cap — against
-      // kCertWorth launches of the scene's displacement (the displacements of a converging run sum to about a dozen times the
-      // current one: a certificate built then usually holds to the end).  Surface points build soon after the launches start
-      // keeping certificates; a point 10 cm out, whose neighbours all lie within microns of each other in distance, once the
-      // scene moves by less than a micron per launch.
-      bool build = false;
-      if (need) {
-        const float dprev = __builtin_amdgcn_sqrtf(corr_d2[i]);           // (+inf before the first match: no slack, no certificate yet)
-        const float slack = fminf(cst[19], cst[18] * __builtin_amdgcn_rcpf(dprev));
-        // (in a slot walked by 8-lane groups the eight lanes of a group carry the same query: one of them builds)
-        build = slack >= kCertWorth * cst[17] && !stuck && owner;
-      }
+      // (in a slot walked by 8-lane groups the eight lanes of a group carry the same query: one of them builds)
+      const bool build = need && !stuck && owner && cert_worth_building(corr_d2[i], cst[18], cst[19], cst[17]);
       const uint32_t h = need ? hint[i] : 0u;   // start leaf of the walks (queries answered from their certificate need none)
 #ifdef OPE_DEVELOPER
       if (owner && build) atomicAdd(work_counter + 47, 1u);   // walks that build a certificate
@@ -397,25 +421,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       }
       float r_best = fast ? v.best : c_best;
       uint32_t r_pos = fast ? v.pos : c_pos, r_leaf = fast ? v.leaf : h;
-      if (__ballot(build) != 0ull) {
-        constexpr int K = kCertCand + 1;
-        KnnRegVisitor<K> kv;
-        kv.init(build, best_init);
-        if (build) bvh_traverse(tgt, x, y, z, kv, stk, BLOCK, h);
-        if (build) {
-          r_best = kv.count > 0 ? kv.d[0] : best_init;
-          r_pos = kv.count > 0 ? kv.p[0] : kNoPos;
-          r_leaf = kv.count > 0 ? kv.leaf : h;
-          if (owner) {
-            // every point outside the list has a computed d2 of at least d[K-1] (a list that is not full still holds the walk's
-            // starting bound there) -> a true distance of at least its square root less 2.5u; the square root is good to 1 ulp
-            const float Lw = __fmul_rn(__builtin_amdgcn_sqrtf(kv.d[K - 1]), 0.9999995f);
-#pragma unroll
-            for (int j = 0; j < kCertCand; ++j) cert_pos[(size_t)j * cstride + i] = j < kv.count ? kv.p[j] + 1u : 0u;
-            cert_q[i] = make_float4(x, y, z, Lw);
-          }
-        }
-      }
+      if (__ballot(build) != 0ull) cert_build(tgt, cert_q, cert_pos, cstride, i, x, y, z, best_init, h, stk, BLOCK, build, build, r_best, r_pos, r_leaf);
       {
         const uint32_t nc = (uint32_t)__popcll(__ballot(owner && !need));
         if (lane_id == 0 && nc != 0u) atomicAdd(&s_ncert, nc);
@@ -676,14 +682,16 @@ __device__ __forceinline__ bool grid_scan(const GridView &g, float qx, float qy,
   return true;
 }
 
-template <bool NRM>
+template <bool NRM, bool CERT = false>
 __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_grid_kernel(
     CloudView src, BvhView tgt, GridView grid, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ hint, uint32_t *__restrict__ ghint,
     const uint32_t *__restrict__ qorder, unsigned char *__restrict__ qclass, const uint32_t *__restrict__ chunk_order,
     uint32_t *__restrict__ chunk_cost, const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, uint32_t measuring_launch,
-    uint32_t *chain, uint32_t chain_seq, uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks) {
+    uint32_t *chain, uint32_t chain_seq, uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks, float4 *__restrict__ cert_q,
+    uint32_t *__restrict__ cert_pos, uint32_t *__restrict__ cert_stats) {
   if (pace != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(pace, launch_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // see icp_accumulate_kernel
+  __shared__ uint32_t s_ncert;
   __shared__ __attribute__((aligned(16))) float s_const[20];   // F rows [0..11], pivot [12..14], best0 [15]; [16..19]: see icp_accumulate_kernel
   if (!acc_launch_begin(st, chain, chain_seq, s_const, wait_ticks)) return;
   constexpr int BLOCK = kAccBlock;
@@ -700,7 +708,12 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
   if (threadIdx.x < 12) { if (chain == nullptr) s_const[threadIdx.x] = st->Ff[threadIdx.x]; }   // (overlapped: fetched by acc_launch_begin)
   else if (threadIdx.x < 15) s_const[threadIdx.x] = (float)st->pivot[threadIdx.x - 12];
   else if (threadIdx.x == 15) s_const[15] = best0;
+  else if (threadIdx.x == 17) { if (chain == nullptr) s_const[17] = st->last_move; }
+  else if (threadIdx.x == 18) s_const[18] = st->cert_k;
+  else if (threadIdx.x == 19) s_const[19] = st->cert_cap;
+  else if (threadIdx.x == 30) s_ncert = 0u;
   __syncthreads();
+  if (CERT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(cert_stats + 2, 1u);   // launches that kept certificates
   const bool rej_sn = NRM && st->use_surface_normal_rej;
   const bool rej_so = NRM && st->use_self_occluded_rej;
   const double thr_sn = st->surface_normal_thr, thr_so = st->self_occluded_thr;
@@ -770,9 +783,31 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
       ny = rot_row(F + 4, n4.x, n4.y, n4.z);
       nz = rot_row(F + 8, n4.x, n4.y, n4.z);
     }
+    // ---- skip certificates (CERT instantiation; see icp_accumulate_kernel): a query answered by its certificate neither scans
+    // nor walks; one that has to search and whose certificate would be worth it builds one (a 6-nearest TREE walk: candidates are
+    // positions in the tree's point order, which this kernel reads its matches from as well in that case); everybody else — `live`
+    // — takes the grid scan / tree walk below as in the plain instantiation.
+    bool live = active, certified = false, build = false;
+    float c_best = INFINITY;
+    uint32_t c_pos = kNoPos, c_leaf = 0u;
+    if constexpr (CERT) {
+      const float best_init = active ? cst[15] : -INFINITY;
+      bool stuck = false, has_cert = false;
+      if (active) certified = cert_check(tgt, cert_q, cert_pos, (size_t)src.n, i, x, y, z, best_init, cst[17], c_best, c_pos, stuck, has_cert);
+      build = active && !certified && !stuck && owner && cert_worth_building(corr_d2[i], cst[18], cst[19], cst[17]);
+      const bool group_builds = oct && __shfl((int)build, (int)(lane_id & ~7u), 64) != 0;   // (the eight lanes of a group carry one query)
+      live = active && !certified && !build && !group_builds;
+      if (__ballot(build) != 0ull) {
+        const uint32_t hb = build ? hint[i] : 0u;
+        cert_build(tgt, cert_q, cert_pos, (size_t)src.n, i, x, y, z, best_init, hb, stk, BLOCK, build, build, c_best, c_pos, c_leaf);
+        if (build && c_leaf != 0u && c_leaf != hb) hint[i] = c_leaf;
+      }
+      const uint32_t nc = (uint32_t)__popcll(__ballot(owner && certified));
+      if (lane_id == 0 && nc != 0u) atomicAdd(&s_ncert, nc);
+    }
     // ---- the previous match, if any: it bounds the search
-    const uint32_t gh = active ? ghint[i] : 0u;
-    float best = active ? cst[15] : -INFINITY;   // +inf, or just above the largest admissible d2
+    const uint32_t gh = live ? ghint[i] : 0u;
+    float best = live ? cst[15] : -INFINITY;   // +inf, or just above the largest admissible d2
     uint32_t gpos = kNoPos;
     bool by_grid = false;
     if (gh != 0u) {
@@ -782,9 +817,9 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
       if (!oct && gpos != kNoPos) by_grid = grid_scan(grid, x, y, z, best, gpos);
     }
     // ---- everything else: the tree, seeded with what is known
-    const bool need_tree = active && !by_grid;
+    const bool need_tree = live && !by_grid;
     if (oct) {
-      if (active) {
+      if (live) {
         NearestVisitor v{gpos != kNoPos ? nextafterf(best, INFINITY) : best, kNoPos, 0};
         bvh_traverse_oct(tgt, x, y, z, v, &s_stk[0][threadIdx.x & ~7u], BLOCK, hint[i]);
         if (v.pos != kNoPos) { best = v.best; gpos = grid.gpos_of_bvhpos[v.pos]; }
@@ -803,18 +838,22 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
         if (v.leaf != 0u && v.leaf != h) hint[i] = v.leaf;
       }
     }
-    const bool found = active && gpos != kNoPos;
+    // a query served by its certificate (or by the walk that built one) has its match as a position in the TREE's point order
+    const bool by_cert = CERT && (certified || build);
+    if (by_cert) best = c_best;
+    const bool found = active && (by_cert ? c_pos != kNoPos : gpos != kNoPos);
     bool ok = found && !((double)best > max_d2);
     const float d2 = found ? best : INFINITY;
-    const v4f tm = ld16(grid.gpts + (found ? gpos : 0u));
+    const v4f tm = by_cert ? ld16(tgt.pts + (found ? c_pos : 0u)) : ld16(grid.gpts + (found ? gpos : 0u));
     const int match = found ? __float_as_int(tm.w) : -1;
-    if (owner) {
+    if (owner && !by_cert) {
       if (found && gpos + 1u != gh) ghint[i] = gpos + 1u;
       const unsigned char cls = by_grid ? 1 : 0;
       if (cls != (tree_part ? 0 : 1) || !chunk_order) qclass[i] = cls;   // the partition's expectation is written at the plan step
     }
+    if (CERT && owner && build && found) ghint[i] = grid.gpos_of_bvhpos[c_pos] + 1u;   // (the scans of later launches start from it)
     if (NRM && ok && rej_sn) {
-      const float4 tn = grid.gnrm[gpos];
+      const float4 tn = by_cert ? tgt.nrm[c_pos] : grid.gnrm[gpos];
       const float score = __fadd_rn(__fadd_rn(__fmul_rn(nx, tn.x), __fmul_rn(ny, tn.y)), __fmul_rn(nz, tn.z));
       ok = (double)score > thr_sn;
     }
@@ -829,7 +868,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
       __builtin_nontemporal_store(d2, corr_d2 + i);
     }
     add_query_sums<NRM>(s_red[threadIdx.x >> 6], (lds_cfloat_ptr)s_const, lane_id, ok, p2p, x, y, z, make_float4(tm.x, tm.y, tm.z, tm.w),
-                        (NRM && p2p) ? grid.gnrm[ok ? gpos : 0u] : make_float4(0.f, 0.f, 0.f, 0.f), d2);
+                        (NRM && p2p) ? (by_cert ? tgt.nrm[ok ? c_pos : 0u] : grid.gnrm[ok ? gpos : 0u]) : make_float4(0.f, 0.f, 0.f, 0.f), d2);
     // tree chunks record their cost under their id, grid chunks behind them (the plan only needs their sum)
     if (lane_id == 0 && !oct) chunk_cost[tree_part ? chunk : n_tc + gchunk] = (uint32_t)((__builtin_amdgcn_s_memtime() - t_begin) >> 4);
   }
@@ -841,6 +880,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     if (S_atomic != nullptr) unsafeAtomicAdd(S_atomic + threadIdx.x, v);
     else partials[threadIdx.x * kAccMaxBlocks + blockIdx.x] = v;
   }
+  if (CERT && threadIdx.x == 64 && s_ncert != 0u) atomicAdd(reinterpret_cast<unsigned long long *>(cert_stats), (unsigned long long)s_ncert);
   acc_launch_end(chain);
 }
 
@@ -1757,8 +1797,14 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
 int icp_accumulate_blocks_per_cu(bool nrm, bool packet, bool grid) {
   int nb = 0;
   hipError_t e;
-  if (grid) e = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_grid_kernel<true>, kAccBlock, 0)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_grid_kernel<false>, kAccBlock, 0);
+  if (grid) {
+    e = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_grid_kernel<true>, kAccBlock, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_grid_kernel<false>, kAccBlock, 0);
+    int nc = 0;
+    const hipError_t ec = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_grid_kernel<true, true>, kAccBlock, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_grid_kernel<false, true>, kAccBlock, 0);
+    if (e == hipSuccess && ec == hipSuccess && nc > 0) nb = std::min(nb, nc);
+  }
   else if (packet) e = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, true, false, true>, kAccBlock, 0)
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, false, false, true>, kAccBlock, 0);
   else e = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, true, false, false>, kAccBlock, 0)
@@ -1779,18 +1825,20 @@ void launch_icp_accumulate_grid(hipStream_t stream, int nblocks, bool nrm, const
                                 const IcpState *st, double *partials, int32_t *corr_match, float *corr_d2, uint32_t *hint, uint32_t *ghint,
                                 const uint32_t *qorder, unsigned char *qclass, const uint32_t *chunk_order, uint32_t *chunk_cost,
                                 const uint32_t *plan_info, double *S_atomic, hipEvent_t e0, hipEvent_t e1, bool measuring, uint32_t *chain,
-                                uint32_t chain_seq, uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks) {
+                                uint32_t chain_seq, uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks, float4 *cert_q, uint32_t *cert_pos,
+                                uint32_t *cert_stats) {
   const uint32_t mflag = measuring ? 1u : 0u;
 #define OPE_KLAUNCH(KERNEL)                                                                                                   \
   do {                                                                                                                        \
     if (e0 != nullptr)                                                                                                        \
       hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, e0, e1, 0, src, tgt, grid, st, partials, corr_match, \
-                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no, wait_ticks); \
+                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no, wait_ticks, cert_q, cert_pos, cert_stats); \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, grid, st, partials, corr_match, corr_d2, \
-                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no, wait_ticks); \
+                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no, wait_ticks, cert_q, cert_pos, cert_stats); \
   } while (0)
-  if (nrm) OPE_KLAUNCH((icp_accumulate_grid_kernel<true>));
+  if (cert_q != nullptr) { if (nrm) OPE_KLAUNCH((icp_accumulate_grid_kernel<true, true>)); else OPE_KLAUNCH((icp_accumulate_grid_kernel<false, true>)); }
+  else if (nrm) OPE_KLAUNCH((icp_accumulate_grid_kernel<true>));
   else OPE_KLAUNCH((icp_accumulate_grid_kernel<false>));
 #undef OPE_KLAUNCH
 }

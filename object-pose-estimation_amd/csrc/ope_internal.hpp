@@ -410,14 +410,33 @@ int set_err(ope_ctx *ctx, int code, const std::string &msg);
 // Staging is per host thread (contexts driven from different threads do not wait for each other; one thread's calls are serial
 // anyway).  Copies of at most kSmall bytes — transform rows, counters, seeds — go through a ring of pinned slots and do NOT
 // synchronise: a slot is reused only after the ring has come round, and the copy that used it is waited for then (an event).
+constexpr size_t kStageChunk = (size_t)32 << 20, kStageSmall = 4096;
+constexpr int kStageRing = 16;
+struct UploadStage {
+  unsigned char *big = nullptr; size_t cap = 0;
+  unsigned char *ring = nullptr; hipEvent_t ev[kStageRing] = {}; bool used[kStageRing] = {}; int next = 0;
+};
+inline UploadStage &upload_stage() { static thread_local UploadStage st; return st; }
+// the calling thread's pinned block, at least min(bytes, kStageChunk) large (for callers that fill it themselves: ope_cloud_upload
+// gathers the caller's structs straight into it); *cap_out = its size
+inline hipError_t stage_block(size_t bytes, unsigned char **block, size_t *cap_out) {
+  UploadStage &st = upload_stage();
+  const size_t want = std::min(std::max(bytes, (size_t)65536), kStageChunk);
+  if (st.cap < want) {
+    if (st.big) (void)hipHostFree(st.big);
+    st.big = nullptr; st.cap = 0;
+    const hipError_t e = hipHostMalloc((void **)&st.big, want, hipHostMallocPortable);
+    if (e != hipSuccess) return e;
+    st.cap = want;
+  }
+  *block = st.big;
+  *cap_out = st.cap;
+  return hipSuccess;
+}
 inline hipError_t h2d_copy(hipStream_t stream, void *dst, const void *src, size_t bytes) {
-  constexpr size_t kChunk = (size_t)32 << 20, kSmall = 4096;
-  constexpr int kRing = 16;
-  struct Stage {
-    unsigned char *big = nullptr; size_t cap = 0;
-    unsigned char *ring = nullptr; hipEvent_t ev[kRing] = {}; bool used[kRing] = {}; int next = 0;
-  };
-  static thread_local Stage st;
+  constexpr size_t kSmall = kStageSmall;
+  constexpr int kRing = kStageRing;
+  UploadStage &st = upload_stage();
   if (bytes == 0) return hipSuccess;
   if (bytes <= kSmall) {
     if (st.ring == nullptr) {
@@ -435,13 +454,10 @@ inline hipError_t h2d_copy(hipStream_t stream, void *dst, const void *src, size_
     st.used[k] = e == hipSuccess;
     return e;
   }
-  const size_t want = std::min(std::max(bytes, (size_t)65536), kChunk);
-  if (st.cap < want) {
-    if (st.big) (void)hipHostFree(st.big);
-    st.big = nullptr; st.cap = 0;
-    const hipError_t e = hipHostMalloc((void **)&st.big, want, hipHostMallocPortable);
+  {
+    unsigned char *blk; size_t cap;
+    const hipError_t e = stage_block(bytes, &blk, &cap);
     if (e != hipSuccess) return e;
-    st.cap = want;
   }
   for (size_t off = 0; off < bytes; off += st.cap) {
     const size_t c = std::min(st.cap, bytes - off);
