@@ -17,10 +17,11 @@ namespace ope {
 void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &, const BvhView &, const BvhView &,
                            const IcpState *, double *, int32_t *, float *, uint32_t *, uint32_t *, const uint32_t *,
                            uint32_t *, const uint32_t *, bool, int, double *, const uint32_t *, float *, const uint32_t *, hipEvent_t, hipEvent_t, bool,
-                           uint32_t *, uint32_t, float4 *, uint32_t *, uint32_t *, uint32_t, uint32_t);
+                           uint32_t *, uint32_t, float4 *, uint32_t *, uint32_t *, uint32_t, uint32_t, float *);
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
 void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
+int icp_accumulate_cert_blocks_per_cu(bool, bool);
 extern bool g_plan_no_alone;
 int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t, void *, size_t &);
 void fill_iota(hipStream_t, uint32_t *, uint32_t);
@@ -30,7 +31,7 @@ hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t,
                             float4 **, float4 **, float4 **);
 void launch_icp_accumulate_grid(hipStream_t, int, bool, const CloudView &, const BvhView &, const GridView &, const IcpState *, double *, int32_t *,
                                 float *, uint32_t *, uint32_t *, const uint32_t *, unsigned char *, const uint32_t *, uint32_t *, const uint32_t *,
-                                double *, hipEvent_t, hipEvent_t, bool, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t, float4 *, uint32_t *, uint32_t *);
+                                double *, hipEvent_t, hipEvent_t, bool, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t, float4 *, uint32_t *, uint32_t *, float *);
 int grid_plan(hipStream_t, bool, const unsigned char *, uint32_t, uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t *, const uint32_t *,
               uint32_t *, uint32_t, uint32_t, float, float, void *, size_t);
 size_t grid_plan_tmp_bytes(uint32_t, uint32_t);
@@ -274,6 +275,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
       }
     }
     const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
+    ctx->launch_blocks = ctx->acc_blocks;
     ++ctx->kernel_launches[OPE_KERNEL_GRID];
     launch_icp_accumulate_grid(ctx->stream, ctx->acc_blocks, nrm, ctx->run_src->view(), ctx->run_tgt->view(), ctx->run_tgt->grid, ctx->d_state,
                                ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_hint, ctx->d_ghint, ctx->d_qorder, ctx->d_qclass,
@@ -281,7 +283,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
                                atomic_sums ? sums_ptr(ctx) : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr,
                                timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr, ctx->measuring_flag,
                                ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, ctx->d_pace, ++ctx->launch_no, ctx->wait_ticks,
-                               (ctx->cert_run && ctx->cert_seen) ? ctx->d_cert_q : nullptr, ctx->d_cert_pos, ctx->d_work_counter + 40);
+                               (ctx->cert_run && ctx->cert_seen) ? ctx->d_cert_q : nullptr, ctx->d_cert_pos, ctx->d_work_counter + 40, ctx->d_cert_l);
     if (timed) ++ctx->prof_used;
     return OPE_OK;
   }
@@ -369,13 +371,16 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   const bool packet = p.tree_walk == OPE_WALK_PACKET ? (ctx->run_tgt->d_axis2 != nullptr && p.corr_mode == OPE_CORR_NEAREST && !recip)
                       : p.tree_walk == OPE_WALK_LANE ? false : (!no_packet && nch > packet_min);
   ++ctx->kernel_launches[p.corr_mode != OPE_CORR_NEAREST ? OPE_KERNEL_KNN : (packet && !recip) ? OPE_KERNEL_TREE_PACKET : OPE_KERNEL_TREE_LANE];
-  launch_icp_accumulate(ctx->stream, ctx->acc_blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
+  const bool certify = ctx->cert_run && ctx->cert_seen && p.corr_mode == OPE_CORR_NEAREST && !recip;
+  const int blocks = certify ? std::min(ctx->acc_blocks, ctx->acc_blocks_cert) : ctx->acc_blocks;   // (the certifying instantiation holds fewer blocks per CU)
+  ctx->launch_blocks = blocks;
+  launch_icp_accumulate(ctx->stream, blocks, p.corr_mode, nrm, recip, ctx->run_src->view(), ctx->run_tgt->view(),
                         recip ? ctx->run_src_index->view() : ctx->run_tgt->view(), ctx->d_state, ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_work_counter, ctx->d_hint,
                         ctx->plan_valid ? ctx->d_plan_order[ctx->plan_cur] : nullptr, cost_w, ctx->d_work_counter + 8, packet, p.k_normal_shooting, atomic_sums ? sums_ptr(ctx) : nullptr,
                         (ctx->plan_valid && ctx->plan_cur_slots) ? ctx->d_plan_slots[ctx->plan_cur] : nullptr,
                         (p.corr_mode == OPE_CORR_NORMAL_SHOOTING && !dev_env("OPE_NO_KNN_BOUND")) ? ctx->d_knn_rk : nullptr, ctx->d_plan_out + 8 * ctx->plan_cur,
                         timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr,
-                        ctx->measuring_flag, ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, (ctx->cert_run && ctx->cert_seen) ? ctx->d_cert_q : nullptr, ctx->d_cert_pos, ctx->d_pace, ++ctx->launch_no, ctx->wait_ticks);
+                        ctx->measuring_flag, ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, certify ? ctx->d_cert_q : nullptr, ctx->d_cert_pos, ctx->d_pace, ++ctx->launch_no, ctx->wait_ticks, ctx->d_cert_l);
   if (timed) ++ctx->prof_used;
   return OPE_OK;
 }
@@ -467,6 +472,7 @@ void ope_ctx_destroy(ope_ctx *ctx) {
   if (ctx->d_hint) (void)hipFree(ctx->d_hint);
   if (ctx->d_cert_q) (void)hipFree(ctx->d_cert_q);
   if (ctx->d_cert_pos) (void)hipFree(ctx->d_cert_pos);
+  if (ctx->d_cert_l) (void)hipFree(ctx->d_cert_l);
   if (ctx->d_knn_rk) (void)hipFree(ctx->d_knn_rk);
   for (void *p : {(void *)ctx->d_ghint, (void *)ctx->d_qorder, (void *)ctx->d_qclass, ctx->d_part_tmp, (void *)ctx->d_chunk_keys})
     if (p) (void)hipFree(p);
@@ -1025,12 +1031,15 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
     if (ctx->d_hint) (void)hipFree(ctx->d_hint);
     if (ctx->d_cert_q) (void)hipFree(ctx->d_cert_q);
     if (ctx->d_cert_pos) (void)hipFree(ctx->d_cert_pos);
+    if (ctx->d_cert_l) (void)hipFree(ctx->d_cert_l);
+    ctx->d_cert_l = nullptr;
     ctx->d_corr_match = nullptr; ctx->d_corr_d2 = nullptr; ctx->d_hint = nullptr; ctx->d_cert_q = nullptr; ctx->d_cert_pos = nullptr; ctx->corr_cap = 0;
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_corr_match, sizeof(int32_t) * std::max<size_t>(src->n, 1)));
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_corr_d2, sizeof(float) * std::max<size_t>(src->n, 1)));
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_hint, sizeof(uint32_t) * std::max<size_t>(src->n, 1)));
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_cert_q, sizeof(float4) * std::max<size_t>(src->n, 1)));
     OPE_HIP(ctx, hipMalloc((void **)&ctx->d_cert_pos, sizeof(uint32_t) * kCertCand * std::max<size_t>(src->n, 1)));
+    OPE_HIP(ctx, hipMalloc((void **)&ctx->d_cert_l, sizeof(float) * std::max<size_t>(src->n, 1)));
     ctx->corr_cap = std::max<size_t>(src->n, 1);
   }
   ctx->use_grid = false;
@@ -1274,6 +1283,13 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   ctx->n_fixed_run = ctx->n_fixed;
   ctx->chain_on = false;
   ctx->chain_seq = 0;
+  ctx->chain_tickets = 0;
+  ctx->acc_blocks_cert = ctx->acc_blocks;
+  if (ctx->cert_run) {
+    const bool nrm = p.use_surface_normal_rej || p.use_self_occluded_rej || p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
+    const int pc = std::min(icp_accumulate_cert_blocks_per_cu(nrm, false), icp_accumulate_cert_blocks_per_cu(nrm, true));
+    if (pc > 0) ctx->acc_blocks_cert = std::max(1, std::min(ctx->acc_blocks, pc * ctx->n_cu - ctx->n_xcd));
+  }
   if (ctx->chained) {
     const bool nrm = p.use_surface_normal_rej || p.use_self_occluded_rej || p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
     int per_cu = icp_accumulate_blocks_per_cu(nrm, false, false);
@@ -1426,8 +1442,9 @@ int ope_icp_iterate(ope_ctx *ctx, int n_iterations) {
     if (rc != OPE_OK) return rc;
     TraceRange r_red(ctx, "reduce");
     if (chained) {
-      // (the ticket word counts up through the run: acc_blocks is the same for every launch of a run)
-      launch_icp_update_chained(ctx->upd_stream, ctx->d_state, run_nsums(ctx), chain_ptr(ctx), ctx->chain_seq, (ctx->chain_seq + 1u) * (uint32_t)ctx->acc_blocks, ctx->wait_ticks);
+      // (the ticket word counts up through the run: one ticket per block of every overlapped launch so far, this one included)
+      ctx->chain_tickets += (uint32_t)ctx->launch_blocks;
+      launch_icp_update_chained(ctx->upd_stream, ctx->d_state, run_nsums(ctx), chain_ptr(ctx), ctx->chain_seq, ctx->chain_tickets, ctx->wait_ticks);
       ++ctx->chain_seq;
       continue;
     }

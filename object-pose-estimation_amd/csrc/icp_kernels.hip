@@ -139,31 +139,43 @@ __device__ __forceinline__ void add_query_sums(double *acc, lds_cfloat_ptr cs2, 
 // ---- skip certificates: the two pieces the tree kernel and the grid kernel share (see icp_accumulate_kernel, "certified search")
 // The check.  Returns true if the query at (x, y, z) is answered by its certificate: best / pos (position in the index's point
 // order) then hold what a search would return.  stuck: the certificate failed where it was built (a new one would be no better).
-__device__ __forceinline__ bool cert_check(const BvhView &tgt, const float4 *__restrict__ cert_q, const uint32_t *__restrict__ cert_pos, size_t cstride,
+__device__ __forceinline__ bool cert_check(const BvhView &tgt, const float4 *__restrict__ cert_q, const float *__restrict__ cert_l,
+                                           const uint32_t *__restrict__ cert_pos, size_t cstride,
                                            uint32_t i, float x, float y, float z, float best_init, float last_move, float &best, uint32_t &pos,
                                            bool &stuck, bool &has_cert) {
   stuck = false;
   const uint32_t p0 = cert_pos[i];
   has_cert = p0 != 0u;
   if (!has_cert) return false;
-  const v4f c = ld16(cert_q + i);
+  const v4f c = ld16(cert_q + i);   // {q_ref, L2}
+  const v4f t1 = ld16(tgt.pts + (p0 - 1u));
+  const float d1 = sq_dist3(__fsub_rn(x, t1.x), __fsub_rn(y, t1.y), __fsub_rn(z, t1.z));
+  const float dl = __builtin_amdgcn_sqrtf(sq_dist3(__fsub_rn(x, c.x), __fsub_rn(y, c.y), __fsub_rn(z, c.z)));
+  const float dl_up = __fmaf_rn(dl, 1.000001f, 1e-30f);
+  // ---- first tier: c_1 alone.  From q_ref every OTHER target point — the other candidates included — was at least L2 (the
+  // runner-up's distance) away; L2 - dl rounded DOWN (one float below the rounded difference; a query that sits where it walked
+  // keeps its bound).  Most queries of a settled scene end here: 20 bytes and one gather.
+  {
+    const float A = dl == 0.f ? c.w : __uint_as_float(__float_as_uint(__fsub_rn(c.w, dl_up)) - 1u);
+    const float TA = __fmul_rn(__fmul_rn(A, A), 0.999999f);
+    if (A > 0.f && d1 < TA && d1 < best_init) { best = d1; pos = p0 - 1u; return true; }
+  }
+  // ---- second tier: the nearest of all candidates against L, the bound on every non-candidate
   uint32_t pj[kCertCand];
-  pj[0] = p0;
 #pragma unroll
   for (int j = 1; j < kCertCand; ++j) pj[j] = cert_pos[(size_t)j * cstride + i];
-  float b1 = INFINITY;   // the nearest candidate, from where the query is now
-  uint32_t bp = 0u;
+  float b1 = d1;   // the nearest candidate, from where the query is now
+  uint32_t bp = p0 - 1u;
 #pragma unroll
-  for (int j = 0; j < kCertCand; ++j) {
+  for (int j = 1; j < kCertCand; ++j) {
     const v4f tp = ld16(tgt.pts + ((pj[j] != 0u ? pj[j] : p0) - 1u));
     const float dj = pj[j] != 0u ? sq_dist3(__fsub_rn(x, tp.x), __fsub_rn(y, tp.y), __fsub_rn(z, tp.z)) : INFINITY;
     const bool lt = dj < b1;
     bp = lt ? pj[j] - 1u : bp;
     b1 = lt ? dj : b1;
   }
-  const float dl = __builtin_amdgcn_sqrtf(sq_dist3(__fsub_rn(x, c.x), __fsub_rn(y, c.y), __fsub_rn(z, c.z)));
-  // L - dl rounded DOWN (one float below the rounded difference); a query that sits where it walked keeps its L
-  const float L1 = dl == 0.f ? c.w : __uint_as_float(__float_as_uint(__fsub_rn(c.w, __fmaf_rn(dl, 1.000001f, 1e-30f))) - 1u);
+  const float Lq = cert_l[i];
+  const float L1 = dl == 0.f ? Lq : __uint_as_float(__float_as_uint(__fsub_rn(Lq, dl_up)) - 1u);
   const float T = __fmul_rn(__fmul_rn(L1, L1), 0.999999f);
   // (Two candidates at the very same computed d2: which of them a search returns is a matter of its visiting order — the
   // reference's kd-tree, the walks here and the oracle each have their own — and the distance is the same bit for bit: the
@@ -174,7 +186,7 @@ __device__ __forceinline__ bool cert_check(const BvhView &tgt, const float4 *__r
 }
 // The walk that builds one: the kCertCand + 1 nearest from (x, y, z), start leaf h.  best / pos / leaf: the nearest (what the 1-NN
 // search returns); `write`: this lane records the certificate.
-__device__ __forceinline__ void cert_build(const BvhView &tgt, float4 *__restrict__ cert_q, uint32_t *__restrict__ cert_pos, size_t cstride, uint32_t i,
+__device__ __forceinline__ void cert_build(const BvhView &tgt, float4 *__restrict__ cert_q, float *__restrict__ cert_l, uint32_t *__restrict__ cert_pos, size_t cstride, uint32_t i,
                                            float x, float y, float z, float best_init, uint32_t h, float *stk, int stk_stride, bool build, bool write,
                                            float &best, uint32_t &pos, uint32_t &leaf) {
   constexpr int K = kCertCand + 1;
@@ -189,9 +201,11 @@ __device__ __forceinline__ void cert_build(const BvhView &tgt, float4 *__restric
       // every point outside the list has a computed d2 of at least d[K-1] (a list that is not full still holds the walk's
       // starting bound there) -> a true distance of at least its square root less 2.5u; the square root is good to 1 ulp
       const float Lw = __fmul_rn(__builtin_amdgcn_sqrtf(kv.d[K - 1]), 0.9999995f);
+      const float L2w = __fmul_rn(__builtin_amdgcn_sqrtf(kv.d[1]), 0.9999995f);   // the same for everything but the nearest (first tier)
 #pragma unroll
       for (int j = 0; j < kCertCand; ++j) cert_pos[(size_t)j * cstride + i] = j < kv.count ? kv.p[j] + 1u : 0u;
-      cert_q[i] = make_float4(x, y, z, Lw);
+      cert_q[i] = make_float4(x, y, z, L2w);
+      cert_l[i] = Lw;
     }
   }
 }
@@ -218,13 +232,13 @@ __device__ __forceinline__ bool cert_worth_building(float d2_prev, float cert_k,
 __device__ unsigned long long g_knn_stats[8];
 #endif
 template <int MODE, bool NRM, bool RECIP = false, bool PACKET = false, int KREG = 20, bool CERT = false>
-__global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !RECIP) ? kAccWavesPerSimd : 4) void icp_accumulate_kernel(
+__global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !RECIP && !CERT) ? kAccWavesPerSimd : 4) void icp_accumulate_kernel(
     CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
     const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, const uint32_t *__restrict__ slot_list,
     float *__restrict__ knn_rk, const uint32_t *__restrict__ plan_out, uint32_t measuring_launch, uint32_t *chain_arg, uint32_t chain_seq,
-    float4 *__restrict__ cert_q, uint32_t *__restrict__ cert_pos, uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks) {
+    float4 *__restrict__ cert_q, uint32_t *__restrict__ cert_pos, uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks, float *__restrict__ cert_l) {
   // pace (host-visible): "launch launch_no has started", i.e. every launch before it is over — the host keeps a bounded lead
   // over the GPU by it (api.hip: pace_wait), which is what lets it notice, a few launches late at most, that the update step
   // has asked for certifying launches (IcpState::cert_mode -> host_cert)
@@ -380,7 +394,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       bool need = active, stuck = false, has_cert = false;
       float c_best = INFINITY;
       uint32_t c_pos = 0u;
-      if (active) need = !cert_check(tgt, cert_q, cert_pos, cstride, i, x, y, z, best_init, cst[17], c_best, c_pos, stuck, has_cert);
+      if (active) need = !cert_check(tgt, cert_q, cert_l, cert_pos, cstride, i, x, y, z, best_init, cst[17], c_best, c_pos, stuck, has_cert);
 #ifdef OPE_DEVELOPER   // tools/cert_probe.py: why certificates fail {expired, stuck where it was built, none yet}
       if (need && owner) atomicAdd(work_counter + (!has_cert ? 46 : stuck ? 45 : 44), 1u);
 #endif
@@ -421,7 +435,7 @@ __global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !R
       }
       float r_best = fast ? v.best : c_best;
       uint32_t r_pos = fast ? v.pos : c_pos, r_leaf = fast ? v.leaf : h;
-      if (__ballot(build) != 0ull) cert_build(tgt, cert_q, cert_pos, cstride, i, x, y, z, best_init, h, stk, BLOCK, build, build, r_best, r_pos, r_leaf);
+      if (__ballot(build) != 0ull) cert_build(tgt, cert_q, cert_l, cert_pos, cstride, i, x, y, z, best_init, h, stk, BLOCK, build, build, r_best, r_pos, r_leaf);
       {
         const uint32_t nc = (uint32_t)__popcll(__ballot(owner && !need));
         if (lane_id == 0 && nc != 0u) atomicAdd(&s_ncert, nc);
@@ -689,7 +703,7 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     const uint32_t *__restrict__ qorder, unsigned char *__restrict__ qclass, const uint32_t *__restrict__ chunk_order,
     uint32_t *__restrict__ chunk_cost, const uint32_t *__restrict__ plan_info, double *__restrict__ S_atomic, uint32_t measuring_launch,
     uint32_t *chain, uint32_t chain_seq, uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks, float4 *__restrict__ cert_q,
-    uint32_t *__restrict__ cert_pos, uint32_t *__restrict__ cert_stats) {
+    uint32_t *__restrict__ cert_pos, uint32_t *__restrict__ cert_stats, float *__restrict__ cert_l) {
   if (pace != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(pace, launch_no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // see icp_accumulate_kernel
   __shared__ uint32_t s_ncert;
   __shared__ __attribute__((aligned(16))) float s_const[20];   // F rows [0..11], pivot [12..14], best0 [15]; [16..19]: see icp_accumulate_kernel
@@ -793,13 +807,13 @@ __global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_gr
     if constexpr (CERT) {
       const float best_init = active ? cst[15] : -INFINITY;
       bool stuck = false, has_cert = false;
-      if (active) certified = cert_check(tgt, cert_q, cert_pos, (size_t)src.n, i, x, y, z, best_init, cst[17], c_best, c_pos, stuck, has_cert);
+      if (active) certified = cert_check(tgt, cert_q, cert_l, cert_pos, (size_t)src.n, i, x, y, z, best_init, cst[17], c_best, c_pos, stuck, has_cert);
       build = active && !certified && !stuck && owner && cert_worth_building(corr_d2[i], cst[18], cst[19], cst[17]);
       const bool group_builds = oct && __shfl((int)build, (int)(lane_id & ~7u), 64) != 0;   // (the eight lanes of a group carry one query)
       live = active && !certified && !build && !group_builds;
       if (__ballot(build) != 0ull) {
         const uint32_t hb = build ? hint[i] : 0u;
-        cert_build(tgt, cert_q, cert_pos, (size_t)src.n, i, x, y, z, best_init, hb, stk, BLOCK, build, build, c_best, c_pos, c_leaf);
+        cert_build(tgt, cert_q, cert_l, cert_pos, (size_t)src.n, i, x, y, z, best_init, hb, stk, BLOCK, build, build, c_best, c_pos, c_leaf);
         if (build && c_leaf != 0u && c_leaf != hb) hint[i] = c_leaf;
       }
       const uint32_t nc = (uint32_t)__popcll(__ballot(owner && certified));
@@ -1744,7 +1758,7 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
                            const uint32_t *chunk_order, uint32_t *chunk_cost, const uint32_t *plan_info, bool packet,
                            int k_normal_shooting, double *S_atomic, const uint32_t *slot_list, float *knn_rk, const uint32_t *plan_out,
                            hipEvent_t e0, hipEvent_t e1, bool measuring, uint32_t *chain, uint32_t chain_seq, float4 *cert_q, uint32_t *cert_pos,
-                           uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks) {
+                           uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks, float *cert_l) {
   const uint32_t mflag = measuring ? 1u : 0u;
   // e0 / e1 (ope_icp_profile): the launch's own start and stop time stamps, taken by the dispatch itself (hipExtLaunchKernelGGL).
   // Round 3 measured what a hipEventRecord before and after every launch costs the loop it times: 7-11 us per iteration (two
@@ -1753,10 +1767,10 @@ void launch_icp_accumulate(hipStream_t stream, int nblocks, int mode, bool nrm, 
   do {                                                                                                                        \
     if (e0 != nullptr)                                                                                                        \
       hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, e0, e1, 0, src, tgt, srcix, st, partials, corr_match, \
-                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert_q, cert_pos, pace, launch_no, wait_ticks); \
+                            corr_d2, work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert_q, cert_pos, pace, launch_no, wait_ticks, cert_l); \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(BLK), LDS, stream, src, tgt, srcix, st, partials, corr_match, corr_d2,   \
-                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert_q, cert_pos, pace, launch_no, wait_ticks); \
+                         work_counter, hint, chunk_order, chunk_cost, plan_info, S_atomic, slot_list, knn_rk, plan_out, mflag, chain, chain_seq, cert_q, cert_pos, pace, launch_no, wait_ticks, cert_l); \
   } while (0)
 #define OPE_LAUNCH_ACC(M, N, R, BLK, LDS) OPE_KLAUNCH((icp_accumulate_kernel<M, N, R>), BLK, LDS)
   const bool certify = cert_q != nullptr && mode == 0 && !recip;   // the certifying instantiation (api.hip decides when)
@@ -1809,16 +1823,18 @@ int icp_accumulate_blocks_per_cu(bool nrm, bool packet, bool grid) {
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, false, false, true>, kAccBlock, 0);
   else e = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, true, false, false>, kAccBlock, 0)
                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, false, false, false>, kAccBlock, 0);
-  if (e == hipSuccess && !grid) {   // a run may move to the certifying instantiation: the launch geometry must hold both
-    int nc = 0;
-    hipError_t ec;
-    if (packet) ec = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, true, false, true, 20, true>, kAccBlock, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, false, false, true, 20, true>, kAccBlock, 0);
-    else ec = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, true, false, false, 20, true>, kAccBlock, 0)
-                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, false, false, false, 20, true>, kAccBlock, 0);
-    if (ec == hipSuccess && nc > 0) nb = std::min(nb, nc);
-  }
   return (e == hipSuccess && nb > 0) ? nb : 0;
+}
+// the same for the certifying tree instantiations (128 VGPRs, 4 waves per SIMD: their walks and list builds would spill at 80,
+// and a launch that answers from certificates is short of bandwidth, not of waves)
+int icp_accumulate_cert_blocks_per_cu(bool nrm, bool packet) {
+  int nc = 0;
+  hipError_t ec;
+  if (packet) ec = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, true, false, true, 20, true>, kAccBlock, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, false, false, true, 20, true>, kAccBlock, 0);
+  else ec = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, true, false, false, 20, true>, kAccBlock, 0)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, false, false, false, 20, true>, kAccBlock, 0);
+  return (ec == hipSuccess && nc > 0) ? nc : 0;
 }
 
 void launch_icp_accumulate_grid(hipStream_t stream, int nblocks, bool nrm, const CloudView &src, const BvhView &tgt, const GridView &grid,
@@ -1826,16 +1842,16 @@ void launch_icp_accumulate_grid(hipStream_t stream, int nblocks, bool nrm, const
                                 const uint32_t *qorder, unsigned char *qclass, const uint32_t *chunk_order, uint32_t *chunk_cost,
                                 const uint32_t *plan_info, double *S_atomic, hipEvent_t e0, hipEvent_t e1, bool measuring, uint32_t *chain,
                                 uint32_t chain_seq, uint32_t *pace, uint32_t launch_no, uint32_t wait_ticks, float4 *cert_q, uint32_t *cert_pos,
-                                uint32_t *cert_stats) {
+                                uint32_t *cert_stats, float *cert_l) {
   const uint32_t mflag = measuring ? 1u : 0u;
 #define OPE_KLAUNCH(KERNEL)                                                                                                   \
   do {                                                                                                                        \
     if (e0 != nullptr)                                                                                                        \
       hipExtLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, e0, e1, 0, src, tgt, grid, st, partials, corr_match, \
-                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no, wait_ticks, cert_q, cert_pos, cert_stats); \
+                            corr_d2, hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no, wait_ticks, cert_q, cert_pos, cert_stats, cert_l); \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(nblocks), dim3(kAccBlock), 0, stream, src, tgt, grid, st, partials, corr_match, corr_d2, \
-                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no, wait_ticks, cert_q, cert_pos, cert_stats); \
+                         hint, ghint, qorder, qclass, chunk_order, chunk_cost, plan_info, S_atomic, mflag, chain, chain_seq, pace, launch_no, wait_ticks, cert_q, cert_pos, cert_stats, cert_l); \
   } while (0)
   if (cert_q != nullptr) { if (nrm) OPE_KLAUNCH((icp_accumulate_grid_kernel<true, true>)); else OPE_KLAUNCH((icp_accumulate_grid_kernel<false, true>)); }
   else if (nrm) OPE_KLAUNCH((icp_accumulate_grid_kernel<true>));

@@ -197,6 +197,7 @@ struct ope_ctx {
   bool pace_off = false;            // a wait ran into its limit (a stream held up from outside): no pacing for the rest of the run
   // skip certificates, per sorted query: where the query was when it built its certificate and the lower bound L (metres) that walk
   // proved on its distance to every target point but the candidates {x, y, z, L}; the candidates
+  float *d_cert_l = nullptr;        // L: the bound on every non-candidate (cert_q.w holds L2, the bound on everything but the nearest candidate)
   float4 *d_cert_q = nullptr;
   uint32_t *d_cert_pos = nullptr;   // [kCertCand][n]: 1 + position in the index's point order, nearest first; 0: none
   float *d_knn_rk = nullptr;        // k-NN runs: per sorted query the squared distance of the last list entry of the previous launch (+inf: none)
@@ -225,6 +226,9 @@ struct ope_ctx {
   ope_icp_params run_params{};
   bool run_active = false;
   int acc_blocks = 0;
+  int acc_blocks_cert = 0;       // grid of the certifying tree instantiation (fewer blocks per CU)
+  int launch_blocks = 0;         // blocks of the accumulate launch enqueued last
+  uint32_t chain_tickets = 0;    // tickets the overlapped launches of this run will have taken once they are done
   int64_t n_src_total = 0, n_tgt_total = 0;
   int iters_enqueued = 0;
   double *d_sums_ext = nullptr;   // caller-owned 17-double buffer (e.g. a torch tensor) or null
