@@ -222,10 +222,12 @@ typedef struct {
    * strictly below the other four, it is the unique nearest neighbour: same index, same d2, bit for bit, and no walk.  Every
    * launch still writes every correspondence and adds every term of the sums.
    * OPE_CERT_AUTO (0, default): launches keep certificates from the iteration on whose update moves no scene point by more than
-   * 1/24 of the target's point spacing (decided on the device, no host round trip), and a query builds one when the slack it
-   * can expect — read off its previous distance — is worth 24 launches of the scene's current displacement.
-   * OPE_CERT_OFF (1): never.  OPE_CERT_ALWAYS (2): from the first launch (tests).  Plain 1-NN runs on the OBB-tree kernel only
-   * (not: reciprocal, normal shooting, deterministic_sums, the grid kernel); exact in every mode — the choice moves time only. */
+   * 1/24 of the target's point spacing (1/512 for a run that starts on the tree kernel because more than 3 % of its queries lie
+   * far outside the target: clutter, whose walks set the pace until it can hold certificates too); decided on the device, no host
+   * round trip.  A query builds one when the slack it can expect — read off its previous distance — is worth 24 launches of the
+   * scene's current displacement.
+   * OPE_CERT_OFF (1): never.  OPE_CERT_ALWAYS (2): from the first launch (tests).  Plain 1-NN runs, tree and grid kernel
+   * (not: reciprocal, normal shooting, deterministic_sums); exact in every mode — the choice moves time only. */
   int skip_certificates;
 } ope_icp_params;
 enum { OPE_WALK_AUTO = 0, OPE_WALK_LANE = 1, OPE_WALK_PACKET = 2 };

@@ -1182,7 +1182,16 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
                     !dev_env("OPE_NO_CERT");
     const double ex = (double)tgt->bb_hi[0] - tgt->bb_lo[0], ey = (double)tgt->bb_hi[1] - tgt->bb_lo[1], ez = (double)tgt->bb_hi[2] - tgt->bb_lo[2];
     const double spacing = std::sqrt(2.0 * (ex * ey + ey * ez + ez * ex) / (double)std::max<size_t>(tgt->n, 1));
-    h->cert_thr = !ctx->cert_run ? -1.0f : p.skip_certificates == OPE_CERT_ALWAYS ? std::numeric_limits<float>::infinity() : (float)(spacing / (double)kCertWorth);
+    // When launches start keeping certificates (automatic mode).  A run on a clean source — every query near the surface: the
+    // grid kernel's case, or an index without a grid — profits as soon as surface points can hold one: the update that moves the
+    // scene by less than spacing / 24.  A run that starts on the tree kernel BECAUSE the device counted more than 3 % of its
+    // queries far outside the target (clutter) does not: its launches last as long as the walks of the far queries, whose
+    // neighbours lie within microns of each other in distance, whatever the surface points save (C3's first
+    // hundred iterations got 6 % slower with the early threshold) — it waits until the scene moves by less than spacing / 512,
+    // shortly before those queries can hold certificates too.
+    const bool cluttered = ctx->grid_auto && !ctx->use_grid;
+    h->cert_thr = !ctx->cert_run ? -1.0f : p.skip_certificates == OPE_CERT_ALWAYS ? std::numeric_limits<float>::infinity()
+                                 : (float)(spacing / (cluttered ? 512.0 : (double)kCertWorth));
     if (const char *e = dev_env("OPE_CERT_THR")) h->cert_thr = (float)atof(e);   // developer sweep (metres)
     h->cert_mode = (ctx->cert_run && p.skip_certificates == OPE_CERT_ALWAYS) ? 1 : 0;
     ctx->cert_seen = h->cert_mode != 0;
