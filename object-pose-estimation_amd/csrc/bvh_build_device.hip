@@ -204,7 +204,7 @@ __device__ __noinline__ uint32_t split_key16(float x, float y, float z, float lx
 }
 constexpr int kBotItems = 8;
 constexpr uint32_t kBotPoints = 256 * kBotItems;
-constexpr int kBotMaxLevels = 11;   // 2048 points -> buckets of one point
+constexpr int kBotMaxLevels = 11;   // sub-nodes of a block's node: at most 2^10 (rows of the box table)
 __global__ __launch_bounds__(256) void bottom_levels_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ order_in, uint32_t n, int D,
                                                              int L0, uint32_t *__restrict__ order_out) {
   using Sort = rocprim::block_radix_sort<uint32_t, 256, kBotItems, uint32_t>;
@@ -261,6 +261,10 @@ __global__ __launch_bounds__(256) void bottom_levels_kernel(const float4 *__rest
 __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *v, uint32_t n, uint32_t value) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) v[i] = value;
+}
+__global__ __launch_bounds__(256) void fill_boxes_kernel(uint32_t *mn, uint32_t *mx, uint32_t n) {   // empty boxes: min above, max below every image
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { mn[i] = 0xffffffffu; mx[i] = 0u; }
 }
 __global__ __launch_bounds__(256) void iota_u32_kernel(uint32_t *v, uint32_t n) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -640,8 +644,7 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
     hipLaunchKernelGGL(iota_u32_kernel, dim3(nb), dim3(256), 0, stream, d_order, nn);
     for (int level = 0; level < L0 && e == hipSuccess; ++level) {
       const uint32_t cnt = 3u << level;
-      hipLaunchKernelGGL(fill_u32_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_mn, cnt, 0xffffffffu);
-      hipLaunchKernelGGL(fill_u32_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_mx, cnt, 0u);
+      hipLaunchKernelGGL(fill_boxes_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, d_mn, d_mx, cnt);
       hipLaunchKernelGGL(level_bbox_kernel, dim3(nb_bbox), dim3(256), 0, stream, d_src, d_order, nn, D, level, bbox_rows, d_mn, d_mx);
       size_t tb = tmp_bytes;
       if (level + 16 <= 32) {
