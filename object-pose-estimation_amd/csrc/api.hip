@@ -21,7 +21,7 @@ void launch_icp_accumulate(hipStream_t, int, int, bool, bool, const CloudView &,
 void plan_heavy(hipStream_t, const uint32_t *, uint32_t, float, float, uint32_t, uint32_t *);
 void plan_slots(hipStream_t, const uint32_t *, uint32_t, const uint32_t *, uint32_t *);
 int icp_accumulate_blocks_per_cu(bool, bool, bool);
-int icp_accumulate_cert_blocks_per_cu(bool, bool);
+int icp_accumulate_cert_blocks_per_cu(bool, bool, bool);
 extern bool g_plan_no_alone;
 int chunk_plan(hipStream_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint32_t, void *, size_t &);
 void fill_iota(hipStream_t, uint32_t *, uint32_t);
@@ -275,15 +275,16 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
       }
     }
     const bool timed = ctx->prof_enabled && ctx->prof_used < ctx->prof_events.size() / 2;
-    ctx->launch_blocks = ctx->acc_blocks;
+    const bool certify = ctx->cert_run && ctx->cert_seen;
+    ctx->launch_blocks = certify ? std::min(ctx->acc_blocks, ctx->acc_blocks_cert) : ctx->acc_blocks;   // (the certifying instantiation holds fewer blocks per CU)
     ++ctx->kernel_launches[OPE_KERNEL_GRID];
-    launch_icp_accumulate_grid(ctx->stream, ctx->acc_blocks, nrm, ctx->run_src->view(), ctx->run_tgt->view(), ctx->run_tgt->grid, ctx->d_state,
+    launch_icp_accumulate_grid(ctx->stream, ctx->launch_blocks, nrm, ctx->run_src->view(), ctx->run_tgt->view(), ctx->run_tgt->grid, ctx->d_state,
                                ctx->d_partials, ctx->d_corr_match, ctx->d_corr_d2, ctx->d_hint, ctx->d_ghint, ctx->d_qorder, ctx->d_qclass,
                                ctx->plan_valid ? ctx->d_chunk_order : nullptr, cost_w, ctx->d_work_counter + 8,
                                atomic_sums ? sums_ptr(ctx) : nullptr, timed ? ctx->prof_events[2 * ctx->prof_used] : nullptr,
                                timed ? ctx->prof_events[2 * ctx->prof_used + 1] : nullptr, ctx->measuring_flag,
                                ctx->chain_on ? chain_ptr(ctx) : nullptr, ctx->chain_seq, ctx->d_pace, ++ctx->launch_no, ctx->wait_ticks,
-                               (ctx->cert_run && ctx->cert_seen) ? ctx->d_cert_q : nullptr, ctx->d_cert_pos, ctx->d_work_counter + 40, ctx->d_cert_l);
+                               certify ? ctx->d_cert_q : nullptr, ctx->d_cert_pos, ctx->d_work_counter + 40, ctx->d_cert_l);
     if (timed) ++ctx->prof_used;
     return OPE_OK;
   }
@@ -1296,7 +1297,8 @@ static int icp_begin_impl(ope_ctx *ctx, const ope_cloud *src, const ope_index *t
   ctx->acc_blocks_cert = ctx->acc_blocks;
   if (ctx->cert_run) {
     const bool nrm = p.use_surface_normal_rej || p.use_self_occluded_rej || p.estimator == OPE_EST_POINT_TO_PLANE_LLS;
-    const int pc = std::min(icp_accumulate_cert_blocks_per_cu(nrm, false), icp_accumulate_cert_blocks_per_cu(nrm, true));
+    int pc = std::min(icp_accumulate_cert_blocks_per_cu(nrm, false, false), icp_accumulate_cert_blocks_per_cu(nrm, true, false));
+    if (tgt->has_grid) pc = std::min(pc, icp_accumulate_cert_blocks_per_cu(nrm, false, true));
     if (pc > 0) ctx->acc_blocks_cert = std::max(1, std::min(ctx->acc_blocks, pc * ctx->n_cu - ctx->n_xcd));
   }
   if (ctx->chained) {

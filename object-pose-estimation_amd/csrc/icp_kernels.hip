@@ -697,7 +697,7 @@ __device__ __forceinline__ bool grid_scan(const GridView &g, float qx, float qy,
 }
 
 template <bool NRM, bool CERT = false>
-__global__ __launch_bounds__(kAccBlock, kAccWavesPerSimd) void icp_accumulate_grid_kernel(
+__global__ __launch_bounds__(kAccBlock, CERT ? 4 : kAccWavesPerSimd) void icp_accumulate_grid_kernel(
     CloudView src, BvhView tgt, GridView grid, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ hint, uint32_t *__restrict__ ghint,
     const uint32_t *__restrict__ qorder, unsigned char *__restrict__ qclass, const uint32_t *__restrict__ chunk_order,
@@ -1814,10 +1814,6 @@ int icp_accumulate_blocks_per_cu(bool nrm, bool packet, bool grid) {
   if (grid) {
     e = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_grid_kernel<true>, kAccBlock, 0)
             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_grid_kernel<false>, kAccBlock, 0);
-    int nc = 0;
-    const hipError_t ec = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_grid_kernel<true, true>, kAccBlock, 0)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_grid_kernel<false, true>, kAccBlock, 0);
-    if (e == hipSuccess && ec == hipSuccess && nc > 0) nb = std::min(nb, nc);
   }
   else if (packet) e = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, true, false, true>, kAccBlock, 0)
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, icp_accumulate_kernel<0, false, false, true>, kAccBlock, 0);
@@ -1827,10 +1823,12 @@ int icp_accumulate_blocks_per_cu(bool nrm, bool packet, bool grid) {
 }
 // the same for the certifying tree instantiations (128 VGPRs, 4 waves per SIMD: their walks and list builds would spill at 80,
 // and a launch that answers from certificates is short of bandwidth, not of waves)
-int icp_accumulate_cert_blocks_per_cu(bool nrm, bool packet) {
+int icp_accumulate_cert_blocks_per_cu(bool nrm, bool packet, bool grid) {
   int nc = 0;
   hipError_t ec;
-  if (packet) ec = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, true, false, true, 20, true>, kAccBlock, 0)
+  if (grid) ec = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_grid_kernel<true, true>, kAccBlock, 0)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_grid_kernel<false, true>, kAccBlock, 0);
+  else if (packet) ec = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, true, false, true, 20, true>, kAccBlock, 0)
                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, false, false, true, 20, true>, kAccBlock, 0);
   else ec = nrm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, true, false, false, 20, true>, kAccBlock, 0)
                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nc, icp_accumulate_kernel<0, false, false, false, 20, true>, kAccBlock, 0);
