@@ -66,9 +66,18 @@ static bool read_guess(const char *path, Mat4 &T) {
   return true;
 }
 
-static void print_line(const char *mode, int iterations, double ms_per_iteration, const Mat4 &T, double fitness, bool converged, size_t ns, size_t nt) {
-  std::printf("{\"impl\": \"%s\", \"mode\": \"%s\", \"n_source\": %zu, \"n_target\": %zu, \"iterations\": %d, \"ms_per_iteration\": %.6f, \"converged\": %s, \"fitness\": %.9g, \"T\": [",
+// given: the caller's list of injected pairs after align() — its distance fields are written by the correspondence estimation
+// of every iteration (impl/correspondence_estimation_mod.hpp:159), so they hold the last iteration's values
+static void print_line(const char *mode, int iterations, double ms_per_iteration, const Mat4 &T, double fitness, bool converged, size_t ns, size_t nt,
+                       const pcl::Correspondences *given = nullptr) {
+  std::printf("{\"impl\": \"%s\", \"mode\": \"%s\", \"n_source\": %zu, \"n_target\": %zu, \"iterations\": %d, \"ms_per_iteration\": %.6f, \"converged\": %s, \"fitness\": %.9g, ",
               kImpl, mode, ns, nt, iterations, ms_per_iteration, converged ? "true" : "false", fitness);
+  if (given) {
+    std::printf("\"given_distance\": [");
+    for (size_t i = 0; i < given->size(); ++i) std::printf("%s%.9g", i ? ", " : "", (double)(*given)[i].distance);
+    std::printf("], ");
+  }
+  std::printf("\"T\": [");
   for (int r = 0; r < 4; ++r)
     for (int c = 0; c < 4; ++c) std::printf("%s%.9g", (r || c) ? ", " : "", (double)T(r, c));
   std::printf("]}\n");
@@ -108,7 +117,8 @@ static int run_nn(const std::string &scene_path, const std::string &model_path, 
   const auto t0 = std::chrono::steady_clock::now();
   icp.align(out, guess);
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  print_line(fixed_pairs ? "nnfix" : "nn", iterations, ms / iterations, icp.getFinalTransformation(), icp.getFitnessScore(), icp.hasConverged(), scene->size(), model->size());
+  print_line(fixed_pairs ? "nnfix" : "nn", iterations, ms / iterations, icp.getFinalTransformation(), icp.getFitnessScore(), icp.hasConverged(), scene->size(), model->size(),
+             fixed_pairs ? &given : nullptr);
   return 0;
 }
 

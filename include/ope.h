@@ -261,6 +261,14 @@ void ope_icp_default_params(ope_icp_params *p);
  * correspondences launch their update in line. */
 int ope_icp_set_fixed_correspondences(ope_ctx *ctx, const ope_cloud *src, const ope_cloud *tgt_cloud, const int32_t *index_query,
                                       const int32_t *index_match, size_t n);
+/* The given pairs as the LAST iteration of the last run saw them, in the order they were given (any output may be NULL;
+ * *n = number of pairs set): distance[f] = the value the reference writes back into the caller's list through the pointer,
+ * every iteration (impl/correspondence_estimation_mod.hpp:150-161: squared distance * 1e10 as float; under normal shooting the
+ * squared distance to the source normal's line, impl/correspondence_estimation_normal_shooting_weighted.hpp:81-101);
+ * listed[f] = 1 if the pair stands in the final correspondence list in front of the searched pairs (1-NN estimation, through
+ * every rejector); appended[f] = 1 if it stands behind them once more (first rejector alone, impl/icp_mod.hpp:210-224).
+ * The reference's correspondences_ = listed pairs, ope_icp_correspondences' pairs, appended pairs. */
+int ope_icp_fixed_correspondences(ope_ctx *ctx, float *distance, int32_t *listed, int32_t *appended, size_t cap, size_t *n);
 
 /* How many accumulate launches of the current (or last) run each search kernel served: the bucketed grid kernel, the
  * OBB-tree kernel in its per-lane and in its packet instantiation, the k-NN (normal shooting) kernel.  A run may move

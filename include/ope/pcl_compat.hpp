@@ -396,8 +396,9 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
   template <class TE> void setTransformationEstimation(const std::shared_ptr<TE> &) { params_.estimator = TE::ope_estimator; }
   std::shared_ptr<registration::DefaultConvergenceCriteria> getConvergeCriteria() { return criteria_; }
   // vPCL icp_mod.h:268-281 — the reference's injection of given pairs into every iteration (unused by its own programs).
-  // The pointer is kept, as in the reference; the pairs are read at align().  (The reference's correspondence estimation also
-  // writes each pair's `distance` field back through the pointer, every iteration; the façade leaves the caller's list untouched.)
+  // The pointer is kept, as in the reference; the pairs are read at align().  The reference's correspondence estimation also
+  // writes each pair's `distance` field back through the pointer, every iteration (correspondence_estimation_mod.hpp:150-161):
+  // align() leaves the last iteration's values there, which is what a caller of the reference finds after align().
   void setFixedCorrespondences(Correspondences *correspondences) { corres_fixed_ = correspondences; }
   Correspondences getFixedCorrespondences() { return *corres_fixed_; }
   void clearCorrespondences() { if (corres_fixed_) corres_fixed_->clear(); }
@@ -437,10 +438,10 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
       if (tgt_dev_->h && ope_index_build(ctx, tgt_dev_->h, nullptr, &tgt_index_->h) != OPE_OK) log_error("align", ctx);
     }
     if (!src_dev_->h || !tgt_index_->h) return;
+    // icp_mod.hpp:150-151: the given pairs, if any, go to the correspondence estimation of THIS run (the context is shared
+    // between objects: they are cleared again below)
+    std::vector<int32_t> fq, fm;
     {
-      // icp_mod.hpp:150-151: the given pairs, if any, go to the correspondence estimation of THIS run (the context is shared
-      // between objects: they are cleared again below)
-      std::vector<int32_t> fq, fm;
       if (corres_fixed_)
         for (const Correspondence &c : *corres_fixed_) { fq.push_back(c.index_query); fm.push_back(c.index_match); }
       if (ope_icp_set_fixed_correspondences(ctx, src_dev_->h, tgt_dev_->h, fq.data(), fm.data(), fq.size()) != OPE_OK) {
@@ -450,7 +451,19 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
     }
     ope_icp_result res;
     const int rc_run = ope_icp_run(ctx, src_dev_->h, tgt_index_->h, guess.m, &p, final_.m, &res);
-    if (corres_fixed_ && !corres_fixed_->empty()) (void)ope_icp_set_fixed_correspondences(ctx, nullptr, nullptr, nullptr, nullptr, 0);
+    std::vector<int32_t> fixed_listed, fixed_appended;
+    if (corres_fixed_ && !corres_fixed_->empty()) {
+      std::vector<float> fd(fq.size());
+      fixed_listed.resize(fq.size());
+      fixed_appended.resize(fq.size());
+      size_t nf = 0;
+      if (rc_run == OPE_OK && ope_icp_fixed_correspondences(ctx, fd.data(), fixed_listed.data(), fixed_appended.data(), fd.size(), &nf) == OPE_OK &&
+          nf == corres_fixed_->size())
+        for (size_t f = 0; f < nf; ++f) (*corres_fixed_)[f].distance = fd[f];
+      else
+        fixed_listed.clear(), fixed_appended.clear();
+      (void)ope_icp_set_fixed_correspondences(ctx, nullptr, nullptr, nullptr, nullptr, 0);
+    }
     if (rc_run != OPE_OK) {
       log_error("align", ctx);
       final_ = Matrix4f::Identity();
@@ -468,8 +481,15 @@ template <class PointSource, class PointTarget, class Scalar = float> class Iter
       std::vector<float> d(input_->size());
       size_t n = 0;
       if (ope_icp_correspondences(ctx, q.data(), m.data(), d.data(), q.size(), &n) == OPE_OK) {
-        correspondences_.resize(n);
-        for (size_t i = 0; i < n; ++i) { correspondences_[i].index_query = q[i]; correspondences_[i].index_match = m[i]; correspondences_[i].distance = d[i]; }
+        // the reference's list: given pairs that the estimation listed (through every rejector), the searched pairs, the given
+        // pairs once more where the first rejector alone lets them through (icp_mod.hpp:210-224)
+        for (size_t f = 0; f < fixed_listed.size(); ++f)
+          if (fixed_listed[f]) correspondences_.push_back((*corres_fixed_)[f]);
+        const size_t at = correspondences_.size();
+        correspondences_.resize(at + n);
+        for (size_t i = 0; i < n; ++i) { correspondences_[at + i].index_query = q[i]; correspondences_[at + i].index_match = m[i]; correspondences_[at + i].distance = d[i]; }
+        for (size_t f = 0; f < fixed_appended.size(); ++f)
+          if (fixed_appended[f]) correspondences_.push_back((*corres_fixed_)[f]);
       }
     }
     transformOutput(output);  // icp_mod.hpp:269-271

@@ -152,6 +152,7 @@ ABI = [
     ("ope_icp_overlapped_updates", C.c_int64, [_vp]),
     ("ope_icp_certificate_stats", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("ope_icp_set_fixed_correspondences", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t]),
+    ("ope_icp_fixed_correspondences", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ope_icp_profile_launches", C.c_int, [_vp, _fp, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ope_cloud_select", C.c_int, [_vp, _vp, _ip, C.c_size_t, C.POINTER(_vp)]),
     ("ope_remove_nan_cloud", C.c_int, [_vp, _vp, C.POINTER(_vp), _ip, C.POINTER(C.c_size_t)]),
@@ -475,6 +476,17 @@ class Context:
         assert len(q) == len(m)
         self._chk(lib().ope_icp_set_fixed_correspondences(self.h, src.h if src is not None else None, tgt_cloud.h if tgt_cloud is not None else None,
                                                           q.ctypes.data_as(C.POINTER(C.c_int32)), m.ctypes.data_as(C.POINTER(C.c_int32)), len(q)))
+
+    def icp_fixed_correspondences(self):
+        """The given pairs as the last iteration saw them: (distance field the reference writes back through the caller's pointer,
+        listed in front of the searched pairs, appended behind them) — correspondence_estimation_mod.hpp:150-161, icp_mod.hpp:210-224."""
+        n = C.c_size_t(0)
+        self._chk(lib().ope_icp_fixed_correspondences(self.h, None, None, None, 0, C.byref(n)))
+        d, a, b = np.zeros(n.value, np.float32), np.zeros(n.value, np.int32), np.zeros(n.value, np.int32)
+        if n.value:
+            self._chk(lib().ope_icp_fixed_correspondences(self.h, d.ctypes.data_as(C.POINTER(C.c_float)), a.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                          b.ctypes.data_as(C.POINTER(C.c_int32)), n.value, C.byref(n)))
+        return d, a.astype(bool), b.astype(bool)
 
     def icp_overlapped_updates(self) -> int:
         """Update steps of the current / last run that were launched overlapped (ope_icp_params.update_launch)."""

@@ -44,7 +44,7 @@ void launch_icp_reduce_update(hipStream_t, IcpState *, const double *, double *,
 void launch_icp_update(hipStream_t, IcpState *, double *, int, const float *);
 void launch_icp_update_chained(hipStream_t, IcpState *, int, uint32_t *, uint32_t, uint32_t, uint32_t);
 void launch_gather_fixed_pairs(hipStream_t, const CloudView &, const CloudView &, const uint32_t *, uint32_t, float4 *);
-void launch_icp_fixed_pairs(hipStream_t, const IcpState *, const float4 *, uint32_t, double *);
+void launch_icp_fixed_pairs(hipStream_t, const IcpState *, const float4 *, uint32_t, double *, float2 *);
 void launch_lm_stats(hipStream_t, int, const CloudView &, const BvhView &, const IcpState *, const int32_t *, double *);
 void launch_icp_lm_update(hipStream_t, IcpState *, double *, double *);
 void launch_lm_pos_to_orig(hipStream_t, const BvhView &, int32_t *, uint32_t);
@@ -1356,11 +1356,13 @@ int ope_icp_set_fixed_correspondences(ope_ctx *ctx, const ope_cloud *src, const 
     return set_err(ctx, OPE_EINVAL, "ope_icp_set_fixed_correspondences: index out of range");
   uint32_t *d_pos = nullptr;
   OPE_HIP(ctx, hipMalloc((void **)&d_pos, sizeof(uint32_t) * 2 * n));
-  if (hipMalloc((void **)&ctx->d_fixed, sizeof(float4) * 4 * n) != hipSuccess) { (void)hipFree(d_pos); ctx->d_fixed = nullptr; return set_err(ctx, OPE_ENOMEM, "ope_icp_set_fixed_correspondences: out of device memory"); }
+  // (+ one float2 per pair behind the gathered points: what the last launch saw of it, ope_icp_fixed_correspondences)
+  if (hipMalloc((void **)&ctx->d_fixed, sizeof(float4) * 4 * n + sizeof(float2) * n) != hipSuccess) { (void)hipFree(d_pos); ctx->d_fixed = nullptr; return set_err(ctx, OPE_ENOMEM, "ope_icp_set_fixed_correspondences: out of device memory"); }
   hipError_t e = hipMemcpyAsync(d_pos, pos.data(), sizeof(uint32_t) * 2 * n, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     launch_gather_fixed_pairs(ctx->stream, src->view(), tgt_cloud->view(), d_pos, (uint32_t)n, ctx->d_fixed);
-    e = hipStreamSynchronize(ctx->stream);
+    e = hipMemsetAsync(ctx->d_fixed + 4 * n, 0, sizeof(float2) * n, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
   (void)hipFree(d_pos);
   if (e != hipSuccess) { (void)hipFree(ctx->d_fixed); ctx->d_fixed = nullptr; return set_err(ctx, OPE_EHIP, "ope_icp_set_fixed_correspondences: gather failed"); }
@@ -1376,7 +1378,31 @@ int ope_icp_set_fixed_correspondences(ope_ctx *ctx, const ope_cloud *src, const 
 // indices into that rank's shard, so that they are added once)
 static void enqueue_fixed_pairs(ope_ctx *ctx) {
   if (ctx->n_fixed_run == 0) return;
-  launch_icp_fixed_pairs(ctx->stream, ctx->d_state, ctx->d_fixed, (uint32_t)ctx->n_fixed_run, sums_ptr(ctx));
+  launch_icp_fixed_pairs(ctx->stream, ctx->d_state, ctx->d_fixed, (uint32_t)ctx->n_fixed_run, sums_ptr(ctx),
+                         (float2 *)(ctx->d_fixed + 4 * ctx->n_fixed_run));
+}
+
+// The given pairs as the last iteration of the last run saw them: the reference's correspondence estimation writes each
+// pair's `distance` back through the caller's pointer every iteration (correspondence_estimation_mod.hpp:150-161), lists the
+// pair in front of the searched ones, and ICP appends the survivors of the first rejector behind them (icp_mod.hpp:210-224).
+int ope_icp_fixed_correspondences(ope_ctx *ctx, float *distance, int32_t *listed, int32_t *appended, size_t cap, size_t *n_out) {
+  if (!ctx || !n_out) return set_err(ctx, OPE_EINVAL, "ope_icp_fixed_correspondences: bad argument");
+  const size_t n = ctx->n_fixed;
+  *n_out = n;
+  if (n == 0 || cap == 0) return OPE_OK;
+  if (ctx->n_fixed_run != n) return set_err(ctx, OPE_ESTATE, "ope_icp_fixed_correspondences: no run has used the pairs that are set");
+  OPE_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<float2> seen(n);
+  OPE_HIP(ctx, hipMemcpyAsync(seen.data(), ctx->d_fixed + 4 * n, sizeof(float2) * n, hipMemcpyDeviceToHost, ctx->stream));
+  OPE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t f = 0; f < n && f < cap; ++f) {
+    int bits;
+    std::memcpy(&bits, &seen[f].y, sizeof bits);
+    if (distance) distance[f] = seen[f].x;
+    if (listed) listed[f] = bits & 1;
+    if (appended) appended[f] = (bits >> 1) & 1;
+  }
+  return OPE_OK;
 }
 
 int ope_icp_accumulate(ope_ctx *ctx) {

@@ -1534,7 +1534,11 @@ __global__ __launch_bounds__(64) void gather_fixed_pairs_kernel(CloudView src, C
   fix[4 * f + 3] = tgt.nrm ? tgt.nrm[pt] : z;
 }
 
-__global__ __launch_bounds__(64) void icp_fixed_pairs_kernel(const IcpState *__restrict__ st, const float4 *__restrict__ fix, uint32_t n, double *S) {
+// seen: per pair {the distance field the reference writes back through the caller's pointer every iteration
+// (correspondence_estimation_mod.hpp:159), bit 0 = listed and through every rejector | bit 1 = appended by the first rejector}
+// as THIS launch saw them — ope_icp_fixed_correspondences reads the last launch's.
+__global__ __launch_bounds__(64) void icp_fixed_pairs_kernel(const IcpState *__restrict__ st, const float4 *__restrict__ fix, uint32_t n, double *S,
+                                                             float2 *__restrict__ seen) {
   if (st->done) return;
   // (every lane adds its pairs — f = lane, lane + 64, ... — in that order, then the 64 lane sums are added in lane order: the
   // pairs' share of the sums is the same bits from run to run, as ope_icp_params.deterministic_sums promises for the whole)
@@ -1565,8 +1569,10 @@ __global__ __launch_bounds__(64) void icp_fixed_pairs_kernel(const IcpState *__r
       const double sl = sqrt((double)__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
       pass_so = (double)nx * (-(double)x / sl) + (double)ny * (-(double)y / sl) + (double)nz * (-(double)z / sl) > thr_so;
     }
-    int mult = (!ns_mode && pass_sn && pass_so) ? 1 : 0;                 // listed by the estimation, through every rejector
-    if (rej_sn || rej_so) mult += (rej_sn ? pass_sn : pass_so) ? 1 : 0;  // the first rejector alone, appended
+    const int listed = (!ns_mode && pass_sn && pass_so) ? 1 : 0;                            // listed by the estimation, through every rejector
+    const int appended = ((rej_sn || rej_so) && (rej_sn ? pass_sn : pass_so)) ? 1 : 0;      // the first rejector alone, appended
+    seen[f] = make_float2(dist, __int_as_float(listed | (appended << 1)));
+    const int mult = listed + appended;
     if (mult == 0) continue;
     const double w = (double)mult;
     const double sx = (double)x - px, sy = (double)y - py, sz = (double)z - pz;
@@ -1590,8 +1596,8 @@ __global__ __launch_bounds__(64) void icp_fixed_pairs_kernel(const IcpState *__r
 void launch_gather_fixed_pairs(hipStream_t stream, const CloudView &src, const CloudView &tgt, const uint32_t *pos, uint32_t n, float4 *fix) {
   hipLaunchKernelGGL(gather_fixed_pairs_kernel, dim3((n + 63u) / 64u), dim3(64), 0, stream, src, tgt, pos, n, fix);
 }
-void launch_icp_fixed_pairs(hipStream_t stream, const IcpState *st, const float4 *fix, uint32_t n, double *S) {
-  hipLaunchKernelGGL(icp_fixed_pairs_kernel, dim3(1), dim3(64), 0, stream, st, fix, n, S);
+void launch_icp_fixed_pairs(hipStream_t stream, const IcpState *st, const float4 *fix, uint32_t n, double *S, float2 *seen) {
+  hipLaunchKernelGGL(icp_fixed_pairs_kernel, dim3(1), dim3(64), 0, stream, st, fix, n, S, seen);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -86,6 +86,10 @@ def test_pcl_ab_harness_facade_build_matches_the_oracle(tmp_path, mode):
         assert ref.iterations == K
         assert float(np.linalg.norm(T - ref.T.astype(np.float64))) < 1e-4
         if fixed is not None:
+            # the caller's own list after align(): its distance fields hold what the last iteration's correspondence estimation
+            # wrote through the pointer (correspondence_estimation_mod.hpp:150-161: squared distance x 1e10)
+            # (the two runs' transforms differ by ~1e-6 after K iterations: 2e-4 of a pair 2 mm apart, less of the others)
+            np.testing.assert_allclose(line["given_distance"], ref.corr_d2[:8], rtol=2e-3)
             assert float(np.linalg.norm(T - oracle.icp(src, tgt, p, guess=guess).T.astype(np.float64))) > 1e-4   # (they do move the result)
     else:
         ns_, nt_ = oracle.normals_knn(src, 30)[0], oracle.normals_knn(tgt, 30)[0]

@@ -788,6 +788,14 @@ def test_fixed_correspondences_1nn_match_oracle(ctx, deterministic):
     assert out.n_corr == ref.n_corr == len(src) + len(fq)
     assert frob(out.T, ref.T) < 2e-5
     assert out.last_mse == pytest.approx(ref.last_mse, rel=1e-5)  # dominated by the forty 1e10-scaled distances
+    # what the reference writes back into the caller's list through the pointer, every iteration
+    # (correspondence_estimation_mod.hpp:150-161), and where the pairs stand in the last iteration's list: in front
+    dist, listed, appended = ctx.icp_fixed_correspondences()
+    assert listed.all() and not appended.any()
+    np.testing.assert_array_equal(ref.corr_q[:len(fq)], fq)
+    np.testing.assert_array_equal(ref.corr_m[:len(fq)], fm)
+    np.testing.assert_allclose(dist, ref.corr_d2[:len(fq)], rtol=1e-4)
+    assert dist.min() > 1e5                                        # (x 1e10: squared distances of centimetres)
     if deterministic:
         # the given pairs' share is added in a fixed order too (icp_fixed_pairs_kernel): the same bits from run to run
         again = ctx.icp(cs, ix, ope.default_icp_params(deterministic_sums=1, **kw))
@@ -813,9 +821,23 @@ def test_fixed_correspondences_with_a_rejector_are_counted_as_the_reference_coun
     ix = ctx.build_index(ct)
     ctx.icp_set_fixed_correspondences(cs, ct, fq, fm)
     out = ctx.icp(cs, ix, ope.default_icp_params(**kw))
+    dist, listed, appended = ctx.icp_fixed_correspondences()
+    q, m, d2 = ctx.icp_correspondences(len(src))
     ctx.icp_set_fixed_correspondences(None, None)
+    assert len(ctx.icp_fixed_correspondences()[0]) == 0
     base = ctx.icp(cs, ix, ope.default_icp_params(**kw))
     ref = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw), src_nrm=sn, tgt_nrm=tn, fixed=(fq, fm))
+    # the last iteration's list as the reference holds it (and the facade's getCorrespondences builds it): given pairs the
+    # estimation listed and every rejector passed, the searched pairs, the first rejector's survivors among the given once more
+    nl, na = int(listed.sum()), int(appended.sum())
+    assert nl + len(q) + na == out.n_corr
+    assert (nl == 0) if ns_mode else (listed == appended).all()   # (one rejector installed: the two tests are the same test)
+    assert 0 < na < len(fq)
+    np.testing.assert_array_equal(ref.corr_q[:nl], fq[listed])
+    np.testing.assert_array_equal(ref.corr_m[:nl], fm[listed])
+    np.testing.assert_array_equal(ref.corr_q[ref.n_corr - na:], fq[appended])
+    np.testing.assert_array_equal(ref.corr_m[ref.n_corr - na:], fm[appended])
+    np.testing.assert_allclose(dist[appended], ref.corr_d2[ref.n_corr - na:], rtol=2e-3 if ns_mode else 1e-4)
     ref0 = oracle.icp(src, tgt, orc_params(acc_mode=1, transform_mode=1, **kw), src_nrm=sn, tgt_nrm=tn)
     assert abs(base.n_corr - ref0.n_corr) <= 3
     assert abs(out.n_corr - ref.n_corr) <= 3 and ref.n_corr > ref0.n_corr
