@@ -245,6 +245,9 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
     // 152-157; a slot lasts 51-60 us whatever its chunk costs per lane.  Measured, not kept.)
     // (round 3, later: plans every 4 or 2 launches between 8 and 32 from the costs at hand, with and without the measuring launch
     // in front of plan 16 — the driver's window stayed at 176-180 us per step in every combination: measured, not kept)
+    // (round 4, with the costs double-buffered: a plan after EVERY launch of 5..16, 8..16 or 8..32 — the launches that creep from
+    // 150 to 175 us behind a plan then stay at 160-168: kernel 163-167 us against 161-165, value 5 250-5 590 against 5 700-5 810.  The
+    // plan is at its best right behind a measuring launch, whose costs are the only complete ones; plan period 6/8/12/16/24: 32 stays best)
     const bool measuring = !no_plan && nch > 1 && ((((nx & (nx - 1)) == 0 && nx <= plan_every) || nx % plan_every == 0 || nx == ctx->force_plan_at));
     ctx->measuring_flag = measuring;   // handed to the launch as a kernel argument (round 2 kept it in device memory: two memset dispatches per plan step on the critical path)
   }
