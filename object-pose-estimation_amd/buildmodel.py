@@ -239,3 +239,54 @@ def register_point_clouds_sharded(ope, ctx, frames, corr_rej_thresh: float = 0.7
         res.pairs.append(pr)
     res.cloud = acc
     return res
+
+
+def register_point_clouds_sharded_native(ope, ctx, frames, world: int, rank: int, corr_rej_thresh: float = 0.7,
+                                         max_iterations: int = 500, k_normals: int = 12, estimator: str = "lm") -> RegistrationResult:
+    """The same loop (regmeshpcd.cpp:210-271) as the multi-GPU path proper: device-resident like register_point_clouds, sharded
+    like register_point_clouds_sharded, the sums exchanged by the library's own communicator — the caller has connected `ctx`
+    (comm_p2p_connect or comm_init) — and the reference's estimator (Levenberg-Marquardt point-to-plane, :162,:193).
+
+    Every rank keeps the whole accumulated cloud on its GPU (any point's normal needs its neighbours from the whole cloud, and
+    `cloudTemp = aligned + target` is the same concat everywhere: the ranks' transforms are bit-identical, the sums being added in
+    rank order on every rank); what a rank owns is a contiguous slice of it — gathered on the device (ope_cloud_select), its
+    normals searched in the whole cloud's index (ope_normals_from), its share of the sums.  Per pair a rank builds the index of
+    the accumulated cloud and the concat in full and 1/world of the normals and of the ICP launches; nothing but a new frame
+    and the slice's index list crosses PCIe, nothing but 17 + 91 sums per iteration crosses the fabric."""
+    from . import sharded
+
+    if len(frames) == 0:
+        raise ValueError("register_point_clouds_sharded_native: no frames")
+    p = icp_params_with_normals(ope, corr_rej_thresh, max_iterations, None, estimator)
+    res = RegistrationResult(np.ascontiguousarray(frames[0], np.float32))
+    acc = ctx.upload(res.cloud)
+    try:
+        for i in range(len(frames) - 1):
+            tgt = ctx.upload(np.ascontiguousarray(frames[i + 1], np.float32))
+            index = src = None
+            try:
+                lo, hi = sharded.shard_range(acc.n, world, rank)
+                all_index = ctx.build_index(acc)
+                try:
+                    src = ctx.select(acc, np.arange(lo, hi, dtype=np.int32))
+                    ctx.normals_from(src, all_index, k_normals, fetch=False)   # :72-84, this rank's slice
+                finally:
+                    all_index.free()
+                ctx.normals(tgt, k_normals, fetch=False)                       # :86-90
+                index = ctx.build_index(tgt)
+                ctx.icp_set_global_sizes(acc.n, tgt.n)
+                out = ctx.icp(src, index, p)                                   # :196
+                res.pairs.append(PairResult(out.T, out.iterations, out.converged, float("nan"), acc.n, tgt.n))
+                nxt = ctx.concat(acc, out.T, tgt)                              # :203, :254
+            finally:
+                if index is not None:
+                    index.free()
+                if src is not None:
+                    src.free()
+            acc.free()
+            tgt.free()
+            acc = nxt
+        res.cloud = ctx.download(acc)
+    finally:
+        acc.free()
+    return res

@@ -151,37 +151,51 @@ def bumpy_torus(n: int, seed: int = 11) -> np.ndarray:
     return np.stack([x, y, z], axis=1).astype(np.float32)
 
 
+def _frame_view(i: int, n_per_frame: int, noise_sigma: float, n_azimuths: int):
+    az = 2.0 * np.pi * i / n_azimuths
+    view = np.array([np.cos(az), np.sin(az), 0.35])
+    view /= np.linalg.norm(view)
+    pts = np.empty((0, 3))
+    seed = 200 + i
+    draw = 0
+    while len(pts) < n_per_frame:
+        p, nr = model_surface(int(n_per_frame * 2.4) + 1024, seed + 1000 * draw, return_normals=True)
+        vis = p[(nr.astype(np.float64) @ view) > 0.05].astype(np.float64)
+        pts = np.concatenate([pts, vis], axis=0)
+        draw += 1
+    pts = pts[:n_per_frame]
+    rp = np.random.default_rng(100 + i)
+    ang = rp.uniform(-3.0, 3.0, 3)
+    T = np.eye(4)
+    T[:3, :3] = rot_xyz(*ang)
+    T[:3, 3] = rp.uniform(-0.005, 0.005, 3)
+    pts = pts @ T[:3, :3].T + T[:3, 3]
+    pts += np.random.default_rng(300 + i).standard_normal(pts.shape) * noise_sigma
+    return pts.astype(np.float32), T
+
+
 def frame_views(n_frames: int, n_per_frame: int, noise_sigma: float = 0.0002, return_poses: bool = False,
-                n_azimuths: int | None = None):
+                n_azimuths: int | None = None, workers: int = 1):
     """BuildModel input (config C5): the model surface seen from `n_frames` azimuths.
 
     Frame i holds `n_per_frame` independently sampled surface points (seed 200+i) whose outward normal faces a
     viewer on the circle at azimuth 2πi/n_frames (back-face culled), moved by the frame's own small pose
     (≤3°, ≤5 mm, seed 100+i) and noised.  Returns a list of float32 (n_per_frame,3) arrays
     (+ the list of 4x4 frame poses if asked).  `n_azimuths` keeps C5's 32-step spacing with fewer frames.
+    `workers` > 1: the frames are made by that many spawned processes (each frame has its own seeds: same arrays).
     """
-    frames, poses = [], []
     n_azimuths = n_frames if n_azimuths is None else n_azimuths
-    for i in range(n_frames):
-        az = 2.0 * np.pi * i / n_azimuths
-        view = np.array([np.cos(az), np.sin(az), 0.35])
-        view /= np.linalg.norm(view)
-        pts = np.empty((0, 3))
-        seed = 200 + i
-        draw = 0
-        while len(pts) < n_per_frame:
-            p, nr = model_surface(int(n_per_frame * 2.4) + 1024, seed + 1000 * draw, return_normals=True)
-            vis = p[(nr.astype(np.float64) @ view) > 0.05].astype(np.float64)
-            pts = np.concatenate([pts, vis], axis=0)
-            draw += 1
-        pts = pts[:n_per_frame]
-        rp = np.random.default_rng(100 + i)
-        ang = rp.uniform(-3.0, 3.0, 3)
-        T = np.eye(4)
-        T[:3, :3] = rot_xyz(*ang)
-        T[:3, 3] = rp.uniform(-0.005, 0.005, 3)
-        pts = pts @ T[:3, :3].T + T[:3, 3]
-        pts += np.random.default_rng(300 + i).standard_normal(pts.shape) * noise_sigma
-        frames.append(pts.astype(np.float32))
-        poses.append(T)
+    args = [(i, n_per_frame, noise_sigma, n_azimuths) for i in range(n_frames)]
+    out = None
+    if workers > 1 and n_frames > 1:
+        import concurrent.futures as cf
+        import multiprocessing as mp
+        try:   # (spawn: the caller may hold a GPU context; an executor whose workers cannot start raises instead of respawning them)
+            with cf.ProcessPoolExecutor(min(workers, n_frames), mp_context=mp.get_context("spawn")) as pool:
+                out = list(pool.map(_frame_view, *zip(*args)))
+        except Exception:
+            out = None
+    if out is None:
+        out = [_frame_view(*a) for a in args]
+    frames, poses = [f for f, _ in out], [T for _, T in out]
     return (frames, poses) if return_poses else frames
