@@ -420,6 +420,72 @@ __global__ __launch_bounds__(BLOCK) void fit_obb_kernel(const float4 *__restrict
 }
 
 
+// The levels whose nodes hold at most 64 points (the leaves and the two or three levels above them: most of the nodes): one LANE
+// per node instead of one wave — a block of 64 threads per 14-point leaf kept 50 lanes idle through four passes and a Jacobi
+// solve on lane 0 (leaf level of a 914 k-point index: 254 us).  Same formulas, margins and pass structure as fit_obb_kernel; the
+// sums run in point order instead of a tree (boxes differ in their last bits, never in what they hold).
+__global__ __launch_bounds__(64) void fit_obb_small_kernel(const float4 *__restrict__ pts, uint32_t n, int D, int level, double scale,
+                                                           float *__restrict__ nodes, float4 *__restrict__ axis2) {
+  const uint32_t j = blockIdx.x * 64u + threadIdx.x;
+  if (j >= (1u << level)) return;
+  const uint32_t node = (1u << level) + j;
+  const uint32_t b = leaf_start((unsigned long long)j << (D - level), n, D), e = leaf_start((unsigned long long)(j + 1) << (D - level), n, D);
+  float *o = nodes + (size_t)kNodeFloats * node;
+  if (e <= b) {  // empty leaf (n < 2^D): a box nothing can be close to
+    for (int k = 0; k < kNodeFloats; ++k) o[k] = k < 3 ? 1e30f : (k == 4 || k == 9) ? 1.f : 0.f;
+    axis2[node] = make_float4(0.f, 0.f, 1.f, 0.f);
+    return;
+  }
+  const double cnt = (double)(e - b);
+  double sx = 0, sy = 0, sz = 0;
+  for (uint32_t i = b; i < e; ++i) { const float4 p = pts[i]; sx += p.x; sy += p.y; sz += p.z; }
+  const double mx = sx / cnt, my = sy / cnt, mz = sz / cnt;
+  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+  for (uint32_t i = b; i < e; ++i) {
+    const float4 p = pts[i];
+    const double vx = p.x - mx, vy = p.y - my, vz = p.z - mz;
+    c00 += vx * vx; c01 += vx * vy; c02 += vx * vz; c11 += vy * vy; c12 += vy * vz; c22 += vz * vz;
+  }
+  double C[9] = {c00, c01, c02, c01, c11, c12, c02, c12, c22}, V[9];
+  jacobi_eig3_dev(C, V);
+  float a0[3], a1[3];
+  for (int d = 0; d < 3; ++d) { a0[d] = (float)V[3 * d + 0]; a1[d] = (float)V[3 * d + 1]; }
+  double A[9];
+  for (int d = 0; d < 3; ++d) { A[d] = a0[d]; A[3 + d] = a1[d]; }
+  A[6] = A[1] * A[5] - A[2] * A[4];
+  A[7] = A[2] * A[3] - A[0] * A[5];
+  A[8] = A[0] * A[4] - A[1] * A[3];
+  double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+  for (uint32_t i = b; i < e; ++i) {
+    const float4 p = pts[i];
+    for (int k = 0; k < 3; ++k) {
+      const double t = A[3 * k] * p.x + A[3 * k + 1] * p.y + A[3 * k + 2] * p.z;
+      lo[k] = t < lo[k] ? t : lo[k];
+      hi[k] = t > hi[k] ? t : hi[k];
+    }
+  }
+  const double mid[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+  float cf[3];
+  for (int d = 0; d < 3; ++d) cf[d] = (float)(mid[0] * A[d] + mid[1] * A[3 + d] + mid[2] * A[6 + d]);
+  double h[3] = {0, 0, 0}, far = 0;
+  for (uint32_t i = b; i < e; ++i) {
+    const float4 p = pts[i];
+    const double vx = (double)p.x - cf[0], vy = (double)p.y - cf[1], vz = (double)p.z - cf[2];
+    const double r = sqrt(vx * vx + vy * vy + vz * vz);
+    far = r > far ? r : far;
+    for (int k = 0; k < 3; ++k) {
+      const double t = fabs(A[3 * k] * vx + A[3 * k + 1] * vy + A[3 * k + 2] * vz);
+      h[k] = t > h[k] ? t : h[k];
+    }
+  }
+  const double margin = 4e-6 * far + 1e-7 * scale;   // as fit_obb_kernel
+  o[0] = cf[0]; o[1] = cf[1]; o[2] = cf[2];
+  o[4] = a0[0]; o[5] = a0[1]; o[6] = a0[2];
+  o[8] = a1[0]; o[9] = a1[1]; o[10] = a1[2];
+  for (int k = 0; k < 3; ++k) o[4 * k + 3] = nextafterf((float)(h[k] + margin), FLT_MAX);
+  axis2[node] = make_float4((float)A[6], (float)A[7], (float)A[8], 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Top of the tree for large clouds.  One block per node leaves the first levels to a handful of blocks (the root of a
 // 4 M-point cloud: one block, four passes over every point, 17 ms).  For levels < kTopLevels the fit is therefore
@@ -597,6 +663,15 @@ __global__ __launch_bounds__(kFitBlock) void top_write_kernel(const TopWork *__r
 
 }  // namespace
 
+// The level sorts: rocPRIM's default takes its merge sort up to 2^20 items — two dozen launches of 5-8 us for a 17..25-bit key over
+// 913 k points (165 us per level, nine levels: half of that index's build) — where three or four Onesweep passes do.
+// Measured (ope_index_build, ms, default / Onesweep above 64 k items): 100 k points 0.92 / 1.15, 500 k 2.1 / 1.98, 1 M 2.75 / 2.5,
+// the outlier filter of the C3 frame (914 k points) 5.45 / 4.85: Onesweep from 256 k items on.
+#ifndef OPE_LEVEL_MERGE_SORT_LIMIT
+#define OPE_LEVEL_MERGE_SORT_LIMIT 262144
+#endif
+using LevelSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, OPE_LEVEL_MERGE_SORT_LIMIT>;
+
 // d_src: n finite points (float4, w = original index bits) in any order, d_src_nrm optional (same order).
 // Allocates *d_nodes ((2 << D) * 48 B), *d_pts and (if normals) *d_nrm.
 hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float4 *d_src_nrm, size_t n, int leaf_size,
@@ -636,8 +711,8 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
   if (D - L0 > kBotMaxLevels) L0 = D - kBotMaxLevels;   // (leaf size 1 on a small cloud: the kernel's box table has 2^10 rows)
   uint32_t *d_keys32 = reinterpret_cast<uint32_t *>(d_keys), *d_keys32b = reinterpret_cast<uint32_t *>(d_keys2);
   size_t tmp_bytes = 0, tmp_bytes32 = 0;
-  if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_order, d_order2, n, 0, 64, stream);
-  if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes32, d_keys32, d_keys32b, d_order, d_order2, n, 0, 32, stream);
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs<LevelSortConfig>(nullptr, tmp_bytes, d_keys, d_keys2, d_order, d_order2, n, 0, 64, stream);
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs<LevelSortConfig>(nullptr, tmp_bytes32, d_keys32, d_keys32b, d_order, d_order2, n, 0, 32, stream);
   tmp_bytes = std::max(tmp_bytes, tmp_bytes32);
   if (e == hipSuccess) e = tmp_malloc(stream, &d_tmp, tmp_bytes);
   if (e == hipSuccess) {
@@ -649,10 +724,10 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
       size_t tb = tmp_bytes;
       if (level + 16 <= 32) {
         hipLaunchKernelGGL(level_key32_kernel, dim3(nb), dim3(256), 0, stream, d_src, d_order, nn, D, level, d_mn, d_mx, d_keys32);
-        e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys32, d_keys32b, d_order, d_order2, n, 0, 16 + std::max(level, 1), stream);
+        e = rocprim::radix_sort_pairs<LevelSortConfig>(d_tmp, tb, d_keys32, d_keys32b, d_order, d_order2, n, 0, 16 + std::max(level, 1), stream);
       } else {
         hipLaunchKernelGGL(level_key_kernel, dim3(nb), dim3(256), 0, stream, d_src, d_order, nn, D, level, d_mn, d_mx, d_keys);
-        e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_order, d_order2, n, 0, 16 + std::max(level, 1), stream);
+        e = rocprim::radix_sort_pairs<LevelSortConfig>(d_tmp, tb, d_keys, d_keys2, d_order, d_order2, n, 0, 16 + std::max(level, 1), stream);
       }
       std::swap(d_order, d_order2);
     }
@@ -684,7 +759,11 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
       }
     }
     for (int level = first_level; level <= D && e == hipSuccess; ++level) {
-      if ((n >> level) > 512)
+      // (one lane per node pays once a level has lanes for the GPU: 800-point index 0.195 -> 0.232 ms with it, 4 M points 6.0 -> 4.5)
+      if (((n + ((size_t)1 << level) - 1) >> level) <= 64 && level >= 12)
+        hipLaunchKernelGGL(fit_obb_small_kernel, dim3(((1u << level) + 63u) / 64u), dim3(64), 0, stream, *d_pts, nn, D, level, scale,
+                           reinterpret_cast<float *>(*d_nodes), *d_axis2);
+      else if ((n >> level) > 512)
         hipLaunchKernelGGL(fit_obb_kernel<kFitBlock>, dim3(1u << level), dim3(kFitBlock), 0, stream, *d_pts, nn, D, level, scale,
                            reinterpret_cast<float *>(*d_nodes), *d_axis2);
       else

@@ -247,6 +247,65 @@ __global__ __launch_bounds__(256) void sor_flags_kernel(const float *__restrict_
   if (i < n) keep[i] = !((double)dist[i] > thr) ? 1 : 0;
 }
 
+// The filter's threshold without the trip through the host.  The reference sums the distance vector and its squares
+// sequentially in double (filters/impl/statistical_outlier_removal.hpp as restated in oracle/filters.c:155-159); a parallel
+// sum rounds differently in the last bits, so what the device computes is an INTERVAL that holds the reference's threshold
+// whatever order it adds in — both orders lie within gamma_n = n u / (1 - n u) of the exact sums, u = 2^-53, and every later
+// operation adds u — and then counts the distances inside it.  None there (the interval is ~1e-9 of the threshold wide): every
+// comparison `distance > threshold` comes out as the reference's, bit for bit the same selection.  One there: the caller
+// takes the sequential sums on the host, as before.
+// out[0] = sum, out[1] = sum of squares (fp64 atomics over block partials)
+__global__ __launch_bounds__(256) void sor_sums_kernel(const float *__restrict__ dist, uint32_t n, double *__restrict__ out) {
+  __shared__ double s_a[256], s_b[256];
+  double a = 0.0, b = 0.0;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const double d = (double)dist[i];
+    a += d;
+    b += d * d;
+  }
+  s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) { s_a[threadIdx.x] += s_a[threadIdx.x + off]; s_b[threadIdx.x] += s_b[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { unsafeAtomicAdd(out, s_a[0]); unsafeAtomicAdd(out + 1, s_b[0]); }
+}
+// keep[i] as sor_flags_kernel with the interval's midpoint; *in_band += distances inside [thr_lo, thr_hi]
+__global__ __launch_bounds__(256) void sor_flags_band_kernel(const float *__restrict__ dist, uint32_t n, double thr, double thr_lo, double thr_hi,
+                                                             unsigned char *__restrict__ keep, uint32_t *__restrict__ in_band) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  bool band = false;
+  if (i < n) {
+    const double d = (double)dist[i];
+    keep[i] = !(d > thr) ? 1 : 0;
+    band = d >= thr_lo && d <= thr_hi;
+  }
+  if (__ballot(band) != 0ull && band) atomicAdd(in_band, 1u);
+}
+
+// the interval of the reference's threshold from sums of any order; false: no usable interval (take the sequential sums)
+static bool sor_threshold_interval(double S, double Q, double n, double valid, double mul, double &thr, double &lo, double &hi) {
+  if (!(valid > 1.0) || !(S >= 0.0) || !(Q >= 0.0) || !std::isfinite(S) || !std::isfinite(Q) || !std::isfinite(mul)) return false;
+  const double u = 1.1102230246251565e-16;            // 2^-53
+  const double eps = 4.0 * (n + 2.0) * u, w = 8.0 * u;  // (2 gamma_n with room; a few roundings of single operations)
+  const double S_lo = S * (1.0 - eps), S_hi = S * (1.0 + eps), Q_lo = Q * (1.0 - eps), Q_hi = Q * (1.0 + eps);
+  const double mean_lo = S_lo / valid * (1.0 - w), mean_hi = S_hi / valid * (1.0 + w);
+  const double t_lo = S_lo * S_lo / valid * (1.0 - w), t_hi = S_hi * S_hi / valid * (1.0 + w);
+  const double num_lo = Q_lo - t_hi, num_hi = Q_hi - t_lo;
+  if (!(num_lo > 0.0)) return false;                   // (a variance that may round to zero or below: sqrt decides, sequentially)
+  const double var_lo = num_lo * (1.0 - w) / (valid - 1.0) * (1.0 - w), var_hi = num_hi * (1.0 + w) / (valid - 1.0) * (1.0 + w);
+  const double sd_lo = std::sqrt(var_lo) * (1.0 - w), sd_hi = std::sqrt(var_hi) * (1.0 + w);
+  const double a = mul * sd_lo, b = mul * sd_hi;
+  const double x = mean_lo + std::min(a, b), y = mean_hi + std::max(a, b);
+  lo = x - std::fabs(x) * w - std::fabs(std::min(a, b)) * w;
+  hi = y + std::fabs(y) * w + std::fabs(std::max(a, b)) * w;
+  const double mean = S / valid, variance = (Q - S * S / valid) / (valid - 1.0);
+  thr = mean + mul * std::sqrt(variance);
+  if (!(thr >= lo && thr <= hi)) thr = 0.5 * (lo + hi);
+  return std::isfinite(lo) && std::isfinite(hi) && lo <= hi;
+}
+
 }  // namespace ope
 
 using namespace ope;
@@ -345,6 +404,9 @@ static int sor_core(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double std
   const size_t n = cloud->n;
   if (n == 0) return want_cloud ? select_cloud_device(ctx, cloud, nullptr, 0, out_cloud) : OPE_OK;
   OPE_HIP(ctx, hipSetDevice(ctx->device));
+  // the device-resident form keeps the distances on the device unless its threshold interval leaves a comparison open
+  static const bool host_thr_env = getenv("OPE_SOR_HOST_THRESHOLD") != nullptr;   // tests: force the sequential sums
+  const bool device_threshold = want_cloud && out_mean_dist == nullptr && cloud->n_valid > 1 && !host_thr_env;
   std::vector<float> dist(n, 0.0f);
   float *d_dist = nullptr;
   OPE_HIP(ctx, tmp_malloc(ctx->stream, (void **)&d_dist, 4 * n));
@@ -373,13 +435,57 @@ static int sor_core(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double std
                            mean_k, d_dist, d_self_leaf);
       if (d_self_leaf) tmp_free(ctx->stream, d_self_leaf);
       kt.stop();
-      e = hipMemcpyAsync(dist.data(), d_dist, 4 * n, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (!device_threshold) {
+        e = hipMemcpyAsync(dist.data(), d_dist, 4 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      }
     }
     ope_index_free(ix);
     if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_statistical_outlier_removal: ") + hipGetErrorString(e));
   } else {
     OPE_HIP(ctx, hipMemsetAsync(d_dist, 0, 4 * n, ctx->stream));
+  }
+  if (device_threshold) {
+    // ---- the device-resident form: threshold interval from parallel sums, selection on the device (sor_sums_kernel)
+    double *d_sums = nullptr;
+    uint32_t *d_band = nullptr;
+    unsigned char *d_flags = nullptr;
+    int32_t *d_sel = nullptr;
+    hipError_t e = tmp_malloc(ctx->stream, (void **)&d_sums, 32);
+    d_band = reinterpret_cast<uint32_t *>(d_sums + 2);
+    if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_flags, n);
+    if (e == hipSuccess && out_idx) e = tmp_malloc(ctx->stream, (void **)&d_sel, 4 * n);
+    struct FreeAll { hipStream_t s; void *a, *b, *c; ~FreeAll() { tmp_free(s, a); tmp_free(s, b); tmp_free(s, c); } } free_all{ctx->stream, d_sums, d_flags, d_sel};
+    double hs[2] = {0.0, 0.0};
+    if (e == hipSuccess) e = hipMemsetAsync(d_sums, 0, 32, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(sor_sums_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, ctx->stream, d_dist, (uint32_t)n, d_sums);
+      e = hipMemcpyAsync(hs, d_sums, 16, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_statistical_outlier_removal_cloud: ") + hipGetErrorString(e));
+    double thr = 0.0, thr_lo = 0.0, thr_hi = 0.0;
+    bool settled = sor_threshold_interval(hs[0], hs[1], (double)n, (double)cloud->n_valid, stddev_mul, thr, thr_lo, thr_hi);
+    int rc = OPE_OK;
+    size_t count = 0;
+    if (settled) {
+      uint32_t band = 0;
+      hipLaunchKernelGGL(sor_flags_band_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_dist, (uint32_t)n, thr, thr_lo, thr_hi, d_flags, d_band);
+      e = hipMemcpyAsync(&band, d_band, 4, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) rc = compact_cloud_device(ctx, cloud, d_flags, out_cloud, d_sel, &count);   // (synchronises: `band` has arrived)
+      if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_statistical_outlier_removal_cloud: ") + hipGetErrorString(e));
+      if (rc != OPE_OK) return rc;
+      settled = band == 0u;
+      if (!settled) { ope_cloud_free(*out_cloud); *out_cloud = nullptr; }
+    }
+    if (settled) {
+      if (out_idx && count) e = hipMemcpy(out_idx, d_sel, 4 * count, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) { ope_cloud_free(*out_cloud); *out_cloud = nullptr; return set_err(ctx, OPE_EHIP, std::string("ope_statistical_outlier_removal_cloud: ") + hipGetErrorString(e)); }
+      if (n_out) *n_out = count;
+      return OPE_OK;
+    }
+    // a distance inside the interval (or no interval): the reference's own sequential sums decide
+    OPE_HIP(ctx, hipMemcpy(dist.data(), d_dist, 4 * n, hipMemcpyDeviceToHost));
   }
   // mean and standard deviation of the distance vector: the reference's own sequential double sums over the points in
   // input order (4 bytes per point through the host)

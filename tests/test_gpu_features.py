@@ -384,3 +384,29 @@ def test_statistical_outlier_removal_equals_oracle(ctx, n, mean_k, mul):
     np.testing.assert_array_equal(got, want)
     if n >= 5000:
         assert 0.5 * n < len(got) < n          # the fog goes, the surface stays
+    # the device-resident form never brings the distances to the host: its threshold is an interval that holds the reference's
+    # sequential double sums whatever the order of addition (filters.hip: sor_sums_kernel) — same survivors
+    cdev, idev = ctx.statistical_outlier_removal_cloud(ctx.upload(x), mean_k, mul, want_idx=True)
+    np.testing.assert_array_equal(idev, want)
+    assert cdev.n == len(want)
+
+
+@pytest.mark.parametrize("case", ["two_points", "three_points", "lattice", "line"])
+def test_statistical_outlier_removal_on_the_device_where_the_threshold_is_a_close_call(ctx, case):
+    """Clouds whose mean distances are all (nearly) equal: the variance is zero or a rounding residue, the threshold sits ON
+    the distances, and which side a point falls depends on the last bit of the reference's sequential sums.  The device's
+    interval cannot settle these; it must notice and take the sequential sums (same survivors as the oracle either way)."""
+    if case == "two_points":
+        x = np.array([[0, 0, 0], [0.01, 0, 0]], np.float32)
+    elif case == "three_points":
+        x = np.array([[0, 0, 0], [0.01, 0, 0], [0, 0.01, 0]], np.float32)
+    elif case == "lattice":
+        g = np.arange(12, dtype=np.float32) * np.float32(0.0078125)
+        x = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    else:
+        x = np.zeros((500, 3), np.float32); x[:, 0] = np.arange(500, dtype=np.float32) * np.float32(0.001953125)
+    for mean_k, mul in ((1, 0.0), (6, 0.0), (6, 1.0), (30, 1.0)):
+        want = oracle.statistical_outlier_removal(x, mean_k, mul)
+        cdev, idev = ctx.statistical_outlier_removal_cloud(ctx.upload(x), mean_k, mul, want_idx=True)
+        np.testing.assert_array_equal(idev, want)
+        np.testing.assert_array_equal(ctx.statistical_outlier_removal(ctx.upload(x), mean_k, mul), want)
