@@ -226,9 +226,13 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   if (ctx->cert_run && !ctx->cert_seen && ctx->h_pace != nullptr && *(volatile uint32_t *)(ctx->h_pace + 1) != 0u) ctx->cert_seen = true;
   // re-sort the chunks by the cost they measured: after launches 1, 2, 4, ..., 32 and then every 32
   static const bool no_plan_env = dev_env("OPE_NO_PLAN") != nullptr;  // developer A/B switch
-  const bool no_plan = no_plan_env || ctx->run_params.deterministic_sums != 0;
   const int it_done = ctx->acc_launches++;
   const uint32_t nch = (uint32_t)((ctx->run_src->n_valid + 63) / 64);
+  // (a k-NN launch with dozens of chunks per resident wave is bound by throughput, its tail is one chunk of forty: the cost-sorted
+  // order buys nothing there and its sorts queue up behind the launch — BuildModel's loop, 20 views of 500 k points: 1.50 s with plans,
+  // 1.46-1.47 s without)
+  const bool no_plan = no_plan_env || ctx->run_params.deterministic_sums != 0 ||
+                       (ctx->run_params.corr_mode == OPE_CORR_NORMAL_SHOOTING && nch > 8u * (uint32_t)ctx->n_cu * 4u * 4u);
   // Chunk costs are double-buffered by launch parity: launch L writes half L & 1, and a plan made beside launch L (on the side
   // stream) reads the half launch L - 1 wrote — the measuring launch in front of every plan, in which every chunk reports.
   // Launch L + 1, which writes that half again, waits for the plan first (ev_plan_done).  (Round 3 copied the one buffer on the

@@ -3,6 +3,8 @@ import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ope = importlib.import_module("object-pose-estimation_amd")
+if os.environ.get("PROBE_LIB"):   # an A/B build of the library (make VARIANT=...)
+    ope.LIB_PATH = os.path.join(os.path.dirname(ope.LIB_PATH), f"libope_hip_{os.environ['PROBE_LIB']}.so")
 synth = importlib.import_module("object-pose-estimation_amd.synth")
 bm = importlib.import_module("object-pose-estimation_amd.buildmodel")
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 8
