@@ -59,6 +59,8 @@ def main() -> int:
     ap.add_argument("--leaf", type=int, default=0, help="index leaf size override (0 = library default)")
     ap.add_argument("--no-grid", action="store_true", help="OBB tree only (A/B against the bucketed search)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wait-limit", type=float, default=None,
+                    help="rehearsal: the bound of the device-side waits of overlapped update launches in seconds (ope_ctx_set_wait_limit; 1e-6 forces the fall-back to in-line launches)")
     ap.add_argument("--update-launch", default="overlapped", choices=["overlapped", "in-line"],
                     help="ope_icp_params.update_launch (include/ope.h): the library's default, or accumulate -> update -> accumulate "
                          "on one stream as in rounds 1-2 (A/B; and what a profiler that serialises dispatches, rocprofv3 --pmc, wants)")
@@ -250,9 +252,6 @@ def main() -> int:
                                     euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0, check_every=0,
                                     update_launch=0 if args.update_launch == "overlapped" else 1,
                                     skip_certificates={"auto": ope.CERT_AUTO, "off": ope.CERT_OFF, "always": ope.CERT_ALWAYS}[args.certificates])
-    ctx.icp_set_global_sizes(n_scene, n_model)
-    ctx.icp_begin(cs, ix, params, guess)
-
     def step():
         if use_torch_comm:
             ctx.icp_accumulate()
@@ -287,13 +286,30 @@ def main() -> int:
             ctx.icp_profile(0)
         return dt, (km / max(kn, 1)), kn
 
-    for _ in range(W):
-        step()
-    elapsed, kern_avg_ms, kern_n = timed(K, True)
-    launch_ms = getattr(timed, "last_launch_ms", None)
-    kernels_timed = ctx.icp_kernel_launches()
-    overlapped_updates = ctx.icp_overlapped_updates()
-    T_timed = ctx.icp_current_transform()
+    # An overlapped update launch that gives up its bounded wait (ope.h: ope_icp_update_fallbacks — the GPU held up by something
+    # else for two seconds) leaves the launches behind it as no-ops until the next poll re-enqueues them in line: a window
+    # bracketed by stream synchronisation would then have timed nothing.  The counter is checked right after the window; a run
+    # that fell back is ended and measured again from the same pose (the context launches in line from then on, and says so).
+    update_launch_note = args.update_launch
+    if args.wait_limit is not None:
+        ctx.set_wait_limit(args.wait_limit)
+    for attempt in range(2):
+        fallbacks0 = ctx.icp_update_fallbacks()
+        ctx.icp_set_global_sizes(n_scene, n_model)
+        ctx.icp_begin(cs, ix, params, guess)
+        for _ in range(W):
+            step()
+        elapsed, kern_avg_ms, kern_n = timed(K, True)
+        launch_ms = getattr(timed, "last_launch_ms", None)
+        kernels_timed = ctx.icp_kernel_launches()
+        overlapped_updates = ctx.icp_overlapped_updates()
+        T_timed = ctx.icp_current_transform()      # (polls: a fallback is noticed here at the latest)
+        if ctx.icp_update_fallbacks() == fallbacks0:
+            break
+        assert attempt == 0, "the run fell back to in-line update launches twice"
+        ctx.icp_end()
+        update_launch_note = "in-line (an overlapped update launch of the first attempt gave up its bounded wait: measured again, in line)"
+        print("[bench] an overlapped update launch gave up its bounded wait; the timed window is measured again with in-line launches", file=sys.stderr, flush=True)
     cert_timed = ctx.icp_certificate_stats()
     steady = None
     if S > 0:
@@ -311,12 +327,16 @@ def main() -> int:
     if args.full_run > 0:
         pf = ope.default_icp_params(max_iterations=args.full_run + 1, transformation_epsilon=0.0, euclidean_fitness_epsilon=0.0, mse_threshold_absolute=-1.0,
                                     check_every=0, update_launch=params.update_launch, skip_certificates=params.skip_certificates)
-        ctx.icp_set_global_sizes(n_scene, n_model)
-        ctx.icp_begin(cs, ix, pf, guess)
-        f_elapsed, f_kern_ms, f_n = timed(args.full_run, True)
-        cf = ctx.icp_certificate_stats()
-        f_launch_ms = getattr(timed, "last_launch_ms", None)
-        of = ctx.icp_end()
+        for attempt in range(2):   # (measured again if an overlapped update launch gave up its wait, as above)
+            fallbacks0 = ctx.icp_update_fallbacks()
+            ctx.icp_set_global_sizes(n_scene, n_model)
+            ctx.icp_begin(cs, ix, pf, guess)
+            f_elapsed, f_kern_ms, f_n = timed(args.full_run, True)
+            cf = ctx.icp_certificate_stats()
+            f_launch_ms = getattr(timed, "last_launch_ms", None)
+            of = ctx.icp_end()
+            if ctx.icp_update_fallbacks() == fallbacks0:
+                break
         full = {"steps": args.full_run, "ms": f_elapsed * 1e3, "ms_per_step": f_elapsed / args.full_run * 1e3, "kernel_ms_sum": f_kern_ms * f_n,
                 "kernel_ms_by_tens": [round(sum(f_launch_ms[k:k + 10]) / len(f_launch_ms[k:k + 10]), 4) for k in range(0, len(f_launch_ms), 10)] if f_launch_ms else None,
                 "launches_keeping_certificates": cf["launches"], "queries_answered_from_certificates": cf["certified"],
@@ -434,7 +454,7 @@ def main() -> int:
                                       + (f" ({args.comm}" + ({ope.COMM_P2P: ": peer-to-peer slots", ope.COMM_RCCL: ": ncclAllReduce"}.get(ctx.comm_transport(), "") if not use_torch_comm else "") + ")" if launched else ""),
                        "start": "identity" if guess is None else "FPFH + SAC-IA coarse pose",
                        "final_mse": out.last_mse, "n_corr": int(out.n_corr),
-                       "update_launch": args.update_launch, "overlapped_updates_so_far": overlapped_updates,
+                       "update_launch": update_launch_note, "overlapped_updates_so_far": overlapped_updates,
                        "skip_certificates": args.certificates, "certificates_in_timed_window": cert_timed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

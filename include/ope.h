@@ -277,6 +277,12 @@ enum { OPE_KERNEL_GRID = 0, OPE_KERNEL_TREE_LANE = 1, OPE_KERNEL_TREE_PACKET = 2
 int ope_icp_kernel_launches(const ope_ctx *ctx, int64_t counts[OPE_KERNEL_KINDS]);
 /* How many update steps of the current (or last) run were launched overlapped (ope_icp_params.update_launch). */
 int64_t ope_icp_overlapped_updates(const ope_ctx *ctx);
+/* How many runs of this context had an overlapped update launch give up its bounded wait (ope_ctx_set_wait_limit) and were
+ * resumed in line on the same pose (0 unless the GPU was held up by something else for that long).  Results are unaffected;
+ * TIMINGS are not: the launches enqueued behind the launch that gave up return at once and their iterations are enqueued
+ * again, in line, by the next ope_icp_poll / ope_icp_end — a benchmark that brackets ope_icp_iterate with stream
+ * synchronisation alone must check this counter (bench.py does, and measures again). */
+int ope_icp_update_fallbacks(const ope_ctx *ctx);
 /* Skip certificates of the run in progress (ope_icp_params.skip_certificates; synchronises the stream): out[0] = queries answered
  * from their certificate, summed over the run's launches; out[1] = accumulate launches that kept certificates; out[2] = 1 if the
  * run has reached the stage where it keeps them; out[3] = the last update's largest scene displacement in nanometres (what the

@@ -152,6 +152,7 @@ ABI = [
     ("ope_icp_overlapped_updates", C.c_int64, [_vp]),
     ("ope_icp_certificate_stats", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("ope_icp_set_fixed_correspondences", C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t]),
+    ("ope_icp_update_fallbacks", C.c_int, [_vp]),
     ("ope_icp_fixed_correspondences", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ope_icp_profile_launches", C.c_int, [_vp, _fp, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ope_cloud_select", C.c_int, [_vp, _vp, _ip, C.c_size_t, C.POINTER(_vp)]),
@@ -491,6 +492,10 @@ class Context:
     def icp_overlapped_updates(self) -> int:
         """Update steps of the current / last run that were launched overlapped (ope_icp_params.update_launch)."""
         return int(lib().ope_icp_overlapped_updates(self.h))
+
+    def icp_update_fallbacks(self) -> int:
+        """Runs of this context that resumed in line after an overlapped update launch gave up its bounded wait (ope.h)."""
+        return int(lib().ope_icp_update_fallbacks(self.h))
 
     def icp_certificate_stats(self) -> dict:
         """Skip certificates of the run in progress (ope_icp_params.skip_certificates): queries answered from their certificate

@@ -393,6 +393,8 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   return OPE_OK;
 }
 
+__global__ void prime_stream_kernel(uint32_t *word) { if (threadIdx.x == 0) *word = 1u; }
+
 }  // namespace ope
 
 using namespace ope;
@@ -447,6 +449,16 @@ int ope_ctx_create(ope_ctx **out, int device_ordinal) {
       hipHostMalloc((void **)&ctx->h_state, sizeof(IcpState)) != hipSuccess) {
     ope_ctx_destroy(ctx);
     return set_err(nullptr, OPE_ENOMEM, "context allocation failed");
+  }
+  // The runtime creates a stream's hardware queue at the stream's FIRST dispatch.  For the update stream that used to be update 0
+  // of the context's first overlapped run — with the blocks of accumulate launch 1 already waiting on the device for that update's
+  // word, under a bound (seen once in fifteen fresh processes, right after other processes had left the GPU: the queue took longer
+  // than the 2 s, the run fell back to in-line launches).  Both side streams get their queues here instead.
+  hipLaunchKernelGGL(prime_stream_kernel, dim3(1), dim3(64), 0, ctx->plan_stream, ctx->d_work_counter + 60);
+  hipLaunchKernelGGL(prime_stream_kernel, dim3(1), dim3(64), 0, ctx->upd_stream, ctx->d_work_counter + 61);
+  if (hipStreamSynchronize(ctx->plan_stream) != hipSuccess || hipStreamSynchronize(ctx->upd_stream) != hipSuccess) {
+    ope_ctx_destroy(ctx);
+    return set_err(nullptr, OPE_EHIP, "context set-up: the side streams' first dispatch failed");
   }
   *out = ctx;
   return OPE_OK;
@@ -920,6 +932,7 @@ void ope_icp_default_params(ope_icp_params *p) {
 }
 
 int64_t ope_icp_overlapped_updates(const ope_ctx *ctx) { return ctx ? (int64_t)ctx->chain_seq : 0; }
+int ope_icp_update_fallbacks(const ope_ctx *ctx) { return ctx ? ctx->chain_fallbacks : 0; }
 
 int ope_icp_certificate_stats(ope_ctx *ctx, int64_t out[4]) {
   if (!ctx || !out) return OPE_EINVAL;
@@ -1630,6 +1643,7 @@ int ope_icp_poll(ope_ctx *ctx, ope_icp_result *result) {
     // this context.
     ctx->chain_broken = true;
     ctx->chained = false;
+    ++ctx->chain_fallbacks;
     const int applied = ctx->h_state->iterations, lost = ctx->iters_enqueued - applied;
     if (lost <= 0 || lost > ctx->iters_enqueued || ctx->chain_recovering)
       return set_err(ctx, OPE_EHIP, "an overlapped update launch waited 2 s for its accumulate launch and the run could not be resumed in line (ope_icp_params.update_launch = OPE_UPDATE_IN_LINE avoids the overlapped launches from the start)");

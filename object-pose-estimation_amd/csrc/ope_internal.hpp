@@ -182,6 +182,7 @@ struct ope_ctx {
   bool chain_on = false;         // the batch being enqueued does overlap
   bool chain_open = false;       // the update stream holds launches the launch stream has not waited for yet
   bool chain_u_synced = false;   // the update stream has waited for the launch stream since the state was last written there
+  int chain_fallbacks = 0;       // runs of this context that resumed in line after a bounded wait ran out (ope_icp_update_fallbacks)
   bool chain_broken = false;     // a bounded wait ran out in an earlier run (or a counter-collecting profiler is attached): runs launch their updates in line
   bool chain_recovering = false; // ope_icp_poll is re-enqueueing, in line, the iterations an overlapped run lost to a bounded wait
   uint32_t chain_seq = 0;        // overlapped accumulate launches of this run so far (= updates published once they are done)

@@ -743,6 +743,7 @@ def test_overlapped_update_that_gives_up_resumes_in_line_on_the_same_pose():
             broken = c2.icp(cs, ix, ope.default_icp_params(update_launch=0, check_every=batch, **kw))
             if batch == 0:
                 assert c2.icp_overlapped_updates() == 30     # the run WAS launched overlapped ...
+                assert c2.icp_update_fallbacks() == 1        # ... and says that it fell back (what a benchmark has to check, ope.h)
             else:
                 assert c2.icp_overlapped_updates() == 0      # ... and the context launches in line ever after
             line = c2.icp(cs, ix, ope.default_icp_params(update_launch=1, check_every=batch, **kw))
@@ -757,7 +758,7 @@ def test_overlapped_update_that_gives_up_resumes_in_line_on_the_same_pose():
         cs = c3.upload(src)
         ix = c3.build_index(c3.upload(tgt), grid=0)
         again = c3.icp(cs, ix, ope.default_icp_params(update_launch=0, **kw))
-        assert c3.icp_overlapped_updates() == 30 and frob(again.T, ref.T) < 2e-5
+        assert c3.icp_overlapped_updates() == 30 and c3.icp_update_fallbacks() == 0 and frob(again.T, ref.T) < 2e-5
     finally:
         c3.close()
 
