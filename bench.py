@@ -311,7 +311,7 @@ def main() -> int:
         update_launch_note = "in-line (an overlapped update launch of the first attempt gave up its bounded wait: measured again, in line)"
         print("[bench] an overlapped update launch gave up its bounded wait; the timed window is measured again with in-line launches", file=sys.stderr, flush=True)
     cert_timed = ctx.icp_certificate_stats()
-    steady = None
+    steady, steady_invalid = None, None
     if S > 0:
         for _ in range(settle):
             step()
@@ -320,6 +320,9 @@ def main() -> int:
         c1 = ctx.icp_certificate_stats()
         steady = {"steps": S, "after_iterations": W + K + settle, "ms_per_step": s_elapsed / S * 1e3, "iterations_per_s": S / s_elapsed, "kernel_ms": s_kern_ms,
                   "queries_answered_from_certificates_per_launch": (c1["certified"] - c0["certified"]) / S}
+        ctx.icp_current_transform()   # (polls)
+        if ctx.icp_update_fallbacks() != fallbacks0:   # (as above; this phase is reported beside `value`, not measured again)
+            steady, steady_invalid = None, "an overlapped update launch gave up its bounded wait during this phase: its launches were re-enqueued outside the timed region"
     out = ctx.icp_end()
     assert out.iterations == W + K + settle + S, (out.iterations, W, K, settle, S)
     # ---- a whole run as the reference's flow has it: from the coarse pose, --full-run iterations, timed as one piece
@@ -463,7 +466,7 @@ def main() -> int:
                          "kernel_launches_so_far": kernels_timed,
                          "algorithmic_bytes_per_launch": algo_bytes},
             "phases": {"from_coarse_pose": {"steps": K, "after_warmup": W, "ms_per_step": elapsed / K * 1e3, "kernel_ms": kern_avg_ms},
-                       "steady_state": steady, "full_run": full},
+                       "steady_state": steady if steady is not None else ({"invalid": steady_invalid} if steady_invalid else None), "full_run": full},
             "pose_check": checks,
         }
         if ns_leg is not None:
