@@ -405,8 +405,7 @@ static int sor_core(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double std
   if (n == 0) return want_cloud ? select_cloud_device(ctx, cloud, nullptr, 0, out_cloud) : OPE_OK;
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   // the device-resident form keeps the distances on the device unless its threshold interval leaves a comparison open
-  static const bool host_thr_env = getenv("OPE_SOR_HOST_THRESHOLD") != nullptr;   // tests: force the sequential sums
-  const bool device_threshold = want_cloud && out_mean_dist == nullptr && cloud->n_valid > 1 && !host_thr_env;
+  const bool device_threshold = want_cloud && out_mean_dist == nullptr && cloud->n_valid > 1;
   std::vector<float> dist(n, 0.0f);
   float *d_dist = nullptr;
   OPE_HIP(ctx, tmp_malloc(ctx->stream, (void **)&d_dist, 4 * n));
