@@ -472,6 +472,7 @@ static int sor_core(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double std
       hipLaunchKernelGGL(sor_flags_band_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_dist, (uint32_t)n, thr, thr_lo, thr_hi, d_flags, d_band);
       e = hipMemcpyAsync(&band, d_band, 4, hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) rc = compact_cloud_device(ctx, cloud, d_flags, out_cloud, d_sel, &count);   // (synchronises: `band` has arrived)
+      if (e != hipSuccess || rc != OPE_OK) (void)hipStreamSynchronize(ctx->stream);   // (no copy into `band` may outlive this frame)
       if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_statistical_outlier_removal_cloud: ") + hipGetErrorString(e));
       if (rc != OPE_OK) return rc;
       settled = band == 0u;
