@@ -23,7 +23,7 @@
 namespace ope {
 
 __global__ __launch_bounds__(256) void voxel_key_kernel(CloudView c, float inv_leaf, int min_bx, int min_by, int min_bz,
-                                                         unsigned div_x, unsigned div_xy, unsigned long long *keys,
+                                                         unsigned div_x, unsigned div_xy, int idx_bits, unsigned long long *keys,
                                                          uint32_t *vals) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= c.n) return;
@@ -33,24 +33,25 @@ __global__ __launch_bounds__(256) void voxel_key_kernel(CloudView c, float inv_l
   const int ix = (int)floorf(p.x * inv_leaf) - min_bx, iy = (int)floorf(p.y * inv_leaf) - min_by,
             iz = (int)floorf(p.z * inv_leaf) - min_bz;
   const unsigned long long voxel = (unsigned long long)ix + (unsigned long long)iy * div_x + (unsigned long long)iz * div_xy;
-  keys[i] = (voxel << 32) | (unsigned long long)(uint32_t)__float_as_int(p.w);
+  // (voxel ‖ original index in as few bits as they need: the sort below runs over those bits only)
+  keys[i] = (voxel << idx_bits) | (unsigned long long)(uint32_t)__float_as_int(p.w);
 }
 
 __global__ __launch_bounds__(256) void voxel_winner_kernel(CloudView c, float inv_leaf, const unsigned long long *keys,
-                                                            const uint32_t *vals, uint32_t n_valid, int32_t *winner,
+                                                            const uint32_t *vals, uint32_t n_valid, int idx_bits, int32_t *winner,
                                                             unsigned char *flags) {
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= c.n) return;
   bool start = false;
   if (p < n_valid) {
-    const unsigned long long vox = keys[p] >> 32;
-    start = (p == 0) || ((keys[p - 1] >> 32) != vox);
+    const unsigned long long vox = keys[p] >> idx_bits;
+    start = (p == 0) || ((keys[p - 1] >> idx_bits) != vox);
     if (start) {
       // members arrive in ascending input index: the first one is PCL's initial leaf.idx
       float4 b = c.xyzw[vals[p]];
       const float ix = floorf(b.x * inv_leaf), iy = floorf(b.y * inv_leaf), iz = floorf(b.z * inv_leaf);
       int32_t best = __float_as_int(b.w);
-      for (uint32_t j = p + 1; j < n_valid && (keys[j] >> 32) == vox; ++j) {
+      for (uint32_t j = p + 1; j < n_valid && (keys[j] >> idx_bits) == vox; ++j) {
         const float4 q = c.xyzw[vals[j]];
         const float dc = (q.x - ix) * (q.x - ix) + (q.y - iy) * (q.y - iy) + (q.z - iz) * (q.z - iz) + 1.0f;
         const float dp = (b.x - ix) * (b.x - ix) + (b.y - iy) * (b.y - iy) + (b.z - iz) * (b.z - iz) + 1.0f;
@@ -699,8 +700,14 @@ static int uniform_sampling_dev(ope_ctx *ctx, const ope_cloud *cloud, float leaf
   unsigned int count = 0;
   if (e == hipSuccess) {
     const unsigned nb = (unsigned)((n + 255) / 256);
+    // key = voxel ‖ original index, packed: index bits so that no index is all ones (the keys of non-finite points, all ones, stay
+    // last), voxel bits for the table's size; the radix sort runs over idx_bits + vox_bits bits instead of 64 (C3's cluster: 39)
+    int idx_bits = 1, vox_bits = 1;
+    while (((size_t)1 << idx_bits) <= n) ++idx_bits;
+    while (((unsigned long long)1 << vox_bits) <= (unsigned long long)(div_b[0] * div_b[1] * div_b[2])) ++vox_bits;
+    const int key_bits = std::min(64, idx_bits + vox_bits);
     hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(256), 0, ctx->stream, cloud->view(), inv, (int)min_b[0], (int)min_b[1],
-                       (int)min_b[2], (unsigned)div_b[0], (unsigned)(div_b[0] * div_b[1]), d_keys, d_vals);
+                       (int)min_b[2], (unsigned)div_b[0], (unsigned)(div_b[0] * div_b[1]), idx_bits, d_keys, d_vals);
     size_t tmp_sort = 0, tmp_sel = 0;
     e = rocprim::radix_sort_pairs(nullptr, tmp_sort, d_keys, d_keys2, d_vals, d_vals2, n, 0, 64, ctx->stream);
     if (e == hipSuccess)
@@ -708,10 +715,10 @@ static int uniform_sampling_dev(ope_ctx *ctx, const ope_cloud *cloud, float leaf
     const size_t tmp_bytes = std::max(tmp_sort, tmp_sel);
     if (e == hipSuccess) e = tmp_malloc(ctx->stream, &d_tmp, tmp_bytes);
     size_t tb = tmp_bytes;
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 64, ctx->stream);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, key_bits, ctx->stream);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(voxel_winner_kernel, dim3(nb), dim3(256), 0, ctx->stream, cloud->view(), inv, d_keys2, d_vals2,
-                         (uint32_t)cloud->n_valid, d_win, d_flags);
+                         (uint32_t)cloud->n_valid, idx_bits, d_win, d_flags);
       tb = tmp_bytes;
       e = rocprim::select(d_tmp, tb, d_win, d_flags, d_out, d_count, n, ctx->stream);
     }
