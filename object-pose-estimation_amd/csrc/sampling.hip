@@ -37,30 +37,52 @@ __global__ __launch_bounds__(256) void voxel_key_kernel(CloudView c, float inv_l
   keys[i] = (voxel << idx_bits) | (unsigned long long)(uint32_t)__float_as_int(p.w);
 }
 
-__global__ __launch_bounds__(256) void voxel_winner_kernel(CloudView c, float inv_leaf, const unsigned long long *keys,
-                                                            const uint32_t *vals, uint32_t n_valid, int idx_bits, int32_t *winner,
-                                                            unsigned char *flags) {
+// The voxel's survivor (uniform_sampling.hpp).  (Until round 4 one lane per voxel walked its members in order; a voxel of the C3
+// cluster holds a thousand points: 0.8 ms of the 1.3 the call took.)  PCL's rule — the first member, replaced by every later one that is STRICTLY nearer to the voxel's
+// integer corner — is the minimum of (distance, position in the sorted order): a wave takes 64 consecutive positions, reduces
+// runs of equal voxels with shuffles, and each run's head adds its minimum to the voxel's slot, best[position of the voxel's first
+// member], with one 64-bit atomicMin (distances are >= 1: their float bits order like the floats).  A run that continues a
+// voxel begun in an earlier wave finds that voxel's first member by bisection in the sorted keys.
+__global__ __launch_bounds__(256) void voxel_min_kernel(CloudView c, float inv_leaf, const unsigned long long *__restrict__ keys,
+                                                         const uint32_t *__restrict__ vals, uint32_t n_valid, int idx_bits,
+                                                         unsigned long long *__restrict__ best) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const bool on = p < n_valid;
+  unsigned long long vox = ~0ull, m = ~0ull;
+  if (on) {
+    vox = keys[p] >> idx_bits;
+    const float4 q = c.xyzw[vals[p]];
+    const float ix = floorf(q.x * inv_leaf), iy = floorf(q.y * inv_leaf), iz = floorf(q.z * inv_leaf);
+    const float d = (q.x - ix) * (q.x - ix) + (q.y - iy) * (q.y - iy) + (q.z - iz) * (q.z - iz) + 1.0f;
+    m = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)p;
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long ov = __shfl_down(vox, off, 64), om = __shfl_down(m, off, 64);
+    if (lane + off < 64u && ov == vox && om < m) m = om;
+  }
+  const unsigned long long pv = __shfl_up(vox, 1, 64);
+  if (!on || (lane != 0u && pv == vox)) return;   // not the head of a run
+  uint32_t first = p;
+  if (lane == 0u && p > 0u && (keys[p - 1] >> idx_bits) == vox) {
+    uint32_t lo = 0u, hi = p - 1u;                 // first position whose voxel is not below this one
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) / 2u;
+      if ((keys[mid] >> idx_bits) < vox) lo = mid + 1u; else hi = mid;
+    }
+    first = lo;
+  }
+  atomicMin(best + first, m);
+}
+
+__global__ __launch_bounds__(256) void voxel_pick_kernel(CloudView c, const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                          uint32_t n_valid, int idx_bits, const unsigned long long *__restrict__ best,
+                                                          int32_t *__restrict__ winner, unsigned char *__restrict__ flags) {
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= c.n) return;
-  bool start = false;
-  if (p < n_valid) {
-    const unsigned long long vox = keys[p] >> idx_bits;
-    start = (p == 0) || ((keys[p - 1] >> idx_bits) != vox);
-    if (start) {
-      // members arrive in ascending input index: the first one is PCL's initial leaf.idx
-      float4 b = c.xyzw[vals[p]];
-      const float ix = floorf(b.x * inv_leaf), iy = floorf(b.y * inv_leaf), iz = floorf(b.z * inv_leaf);
-      int32_t best = __float_as_int(b.w);
-      for (uint32_t j = p + 1; j < n_valid && (keys[j] >> idx_bits) == vox; ++j) {
-        const float4 q = c.xyzw[vals[j]];
-        const float dc = (q.x - ix) * (q.x - ix) + (q.y - iy) * (q.y - iy) + (q.z - iz) * (q.z - iz) + 1.0f;
-        const float dp = (b.x - ix) * (b.x - ix) + (b.y - iy) * (b.y - iy) + (b.z - iz) * (b.z - iz) + 1.0f;
-        if (dc < dp) { b = q; best = __float_as_int(q.w); }
-      }
-      winner[p] = best;
-    }
-  }
-  if (!start) winner[p] = -1;
+  const bool start = p < n_valid && (p == 0u || (keys[p - 1] >> idx_bits) != (keys[p] >> idx_bits));
+  winner[p] = start ? __float_as_int(c.xyzw[vals[(uint32_t)(best[p] & 0xffffffffull)]].w) : -1;
   flags[p] = start ? 1 : 0;
 }
 
@@ -717,8 +739,11 @@ static int uniform_sampling_dev(ope_ctx *ctx, const ope_cloud *cloud, float leaf
     size_t tb = tmp_bytes;
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, key_bits, ctx->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(voxel_winner_kernel, dim3(nb), dim3(256), 0, ctx->stream, cloud->view(), inv, d_keys2, d_vals2,
-                         (uint32_t)cloud->n_valid, idx_bits, d_win, d_flags);
+      // (the unsorted keys are done with: their buffer holds the voxels' slots)
+      e = hipMemsetAsync(d_keys, 0xff, 8 * n, ctx->stream);
+      hipLaunchKernelGGL(voxel_min_kernel, dim3(nb), dim3(256), 0, ctx->stream, cloud->view(), inv, d_keys2, d_vals2, (uint32_t)cloud->n_valid, idx_bits, d_keys);
+      hipLaunchKernelGGL(voxel_pick_kernel, dim3(nb), dim3(256), 0, ctx->stream, cloud->view(), d_keys2, d_vals2, (uint32_t)cloud->n_valid, idx_bits, d_keys,
+                         d_win, d_flags);
       tb = tmp_bytes;
       e = rocprim::select(d_tmp, tb, d_win, d_flags, d_out, d_count, n, ctx->stream);
     }
