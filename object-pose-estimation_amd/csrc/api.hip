@@ -393,7 +393,17 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   return OPE_OK;
 }
 
-__global__ void prime_stream_kernel(uint32_t *word) { if (threadIdx.x == 0) *word = 1u; }
+// First dispatch of a stream at context creation (ope_ctx_create).  It asks for more private memory per lane than any kernel that
+// runs under a bounded device-side wait (icp_update_chained_kernel 48 bytes, the accumulate instantiations 16-44): the runtime
+// gives a hardware queue its scratch memory when a dispatch first needs it, with the queue stalled until its helper thread has
+// allocated it — milliseconds, or seconds when the driver is busy taking back what earlier processes held.
+__global__ __launch_bounds__(256) void prime_stream_kernel(uint32_t *word, int n) {
+  volatile uint32_t buf[64];
+  for (int i = 0; i < 64; ++i) buf[i] = (uint32_t)(i * n) + threadIdx.x;
+  uint32_t acc = 0u;
+  for (int i = 0; i < 64; ++i) acc += buf[(i * 7 + n) & 63];   // (run-time indices: the array stays in private memory)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *word = acc | 1u;
+}
 
 }  // namespace ope
 
@@ -450,13 +460,21 @@ int ope_ctx_create(ope_ctx **out, int device_ordinal) {
     ope_ctx_destroy(ctx);
     return set_err(nullptr, OPE_ENOMEM, "context allocation failed");
   }
-  // The runtime creates a stream's hardware queue at the stream's FIRST dispatch.  For the update stream that used to be update 0
-  // of the context's first overlapped run — with the blocks of accumulate launch 1 already waiting on the device for that update's
-  // word, under a bound (seen once in fifteen fresh processes, right after other processes had left the GPU: the queue took longer
-  // than the 2 s, the run fell back to in-line launches).  Both side streams get their queues here instead.
-  hipLaunchKernelGGL(prime_stream_kernel, dim3(1), dim3(64), 0, ctx->plan_stream, ctx->d_work_counter + 60);
-  hipLaunchKernelGGL(prime_stream_kernel, dim3(1), dim3(64), 0, ctx->upd_stream, ctx->d_work_counter + 61);
-  if (hipStreamSynchronize(ctx->plan_stream) != hipSuccess || hipStreamSynchronize(ctx->upd_stream) != hipSuccess) {
+  // The runtime creates a stream's hardware queue at the stream's FIRST dispatch and gives the queue its scratch memory when a
+  // dispatch first needs some.  For the update stream both used to happen at update 0 of the context's first overlapped run — with
+  // the blocks of accumulate launch 1 already waiting on the device for that update's word, under a bound (seen twice in some
+  // forty fresh processes, both right after other processes had left the GPU: the run fell back to in-line launches).  The
+  // streams get their queues, with scratch, here instead (prime_stream_kernel).
+  {
+    int n_cu = 0;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device_ordinal);
+    const dim3 grid((unsigned)std::max(n_cu, 1) * 8u);   // (a launch that could fill the device: the scratch is sized for that)
+    hipLaunchKernelGGL(prime_stream_kernel, grid, dim3(256), 0, ctx->plan_stream, ctx->d_work_counter + 60, 3);
+    hipLaunchKernelGGL(prime_stream_kernel, grid, dim3(256), 0, ctx->upd_stream, ctx->d_work_counter + 61, 5);
+    hipLaunchKernelGGL(prime_stream_kernel, grid, dim3(256), 0, ctx->own_stream, ctx->d_work_counter + 62, 7);
+  }
+  if (hipStreamSynchronize(ctx->plan_stream) != hipSuccess || hipStreamSynchronize(ctx->upd_stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->own_stream) != hipSuccess) {
     ope_ctx_destroy(ctx);
     return set_err(nullptr, OPE_EHIP, "context set-up: the side streams' first dispatch failed");
   }
