@@ -534,6 +534,12 @@ int ope_ctx_set_stream(ope_ctx *ctx, void *hip_stream) {
     // release them once the context has moved on); frees synchronise, so nothing in flight still uses them
     (void)hipSetDevice(ctx->device);
     tmp_release_stream(ctx->stream);
+    if (next != ctx->own_stream) {
+      // a caller's stream gets what ope_ctx_create gives the context's own: its queue and the queue's scratch memory, before any
+      // launch on it runs beside an update that waits for it under a bound (prime_stream_kernel)
+      hipLaunchKernelGGL(prime_stream_kernel, dim3((unsigned)std::max(ctx->n_cu, 1) * 8u), dim3(256), 0, next, ctx->d_work_counter + 62, 9);
+      OPE_HIP(ctx, hipStreamSynchronize(next));
+    }
   }
   ctx->stream = next;
   return OPE_OK;
