@@ -28,7 +28,7 @@ void fill_iota(hipStream_t, uint32_t *, uint32_t);
 hipError_t morton_order_device(hipStream_t, const float *, size_t, const float[3], const float[3], float4 *, int32_t *);
 hipError_t concat_device(hipStream_t, const CloudView &, const float *, const CloudView &, float *, float[3], float[3]);
 hipError_t build_bvh_device(hipStream_t, const float4 *, const float4 *, size_t, int, const float[3], const float[3], int *, float4 **,
-                            float4 **, float4 **, float4 **);
+                            float4 **, float4 **, float4 **, bool);
 void launch_icp_accumulate_grid(hipStream_t, int, bool, const CloudView &, const BvhView &, const GridView &, const IcpState *, double *, int32_t *,
                                 float *, uint32_t *, uint32_t *, const uint32_t *, unsigned char *, const uint32_t *, uint32_t *, const uint32_t *,
                                 double *, hipEvent_t, hipEvent_t, bool, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t, float4 *, uint32_t *, uint32_t *, float *);
@@ -753,6 +753,13 @@ void ope_index_default_params(ope_index_params *p) {
 }
 
 int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_params *params, ope_index **out) {
+  return ope::index_build_impl(ctx, target, params, false, out);
+}
+
+}  // extern "C"
+
+// temporary: an index that lives inside one entry point (index_build_tmp, ope_internal.hpp): buffers from the stream's cache
+int ope::index_build_impl(ope_ctx *ctx, const ope_cloud *target, const ope_index_params *params, bool temporary, ope_index **out) {
   if (!ctx || !target || !out) return set_err(ctx, OPE_EINVAL, "ope_index_build: bad argument");
   *out = nullptr;
   // Registration::setInputTarget: "Invalid or empty point cloud dataset given!" (registration_mod.hpp:60-64)
@@ -774,8 +781,10 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
     std::memcpy(ix->bb_lo, target->bb_lo, sizeof ix->bb_lo);
     std::memcpy(ix->bb_hi, target->bb_hi, sizeof ix->bb_hi);
     for (int d = 0; d < 3; ++d) ix->pivot[d] = 0.5 * ((double)target->bb_lo[d] + (double)target->bb_hi[d]);
+    ix->tmp_alloc = temporary;
+    ix->alloc_stream = ctx->stream;
     const hipError_t e = build_bvh_device(ctx->stream, target->d_xyzw, target->d_nrm, n, dp.leaf_size, target->bb_lo, target->bb_hi,
-                                          &ix->depth, &ix->d_nodes, &ix->d_pts, &ix->d_nrm, &ix->d_axis2);
+                                          &ix->depth, &ix->d_nodes, &ix->d_pts, &ix->d_nrm, &ix->d_axis2, temporary);
     if (e != hipSuccess) {
       ope_index_free(ix);
       return set_err(ctx, OPE_EHIP, std::string("ope_index_build: ") + hipGetErrorString(e));
@@ -838,14 +847,20 @@ int ope_index_build(ope_ctx *ctx, const ope_cloud *target, const ope_index_param
   return OPE_OK;
 }
 
+extern "C" {
+
 void ope_index_free(ope_index *index) {
   if (!index) return;
   if (index->ctx) (void)hipSetDevice(index->ctx->device);
   if (index->ctx && index->ctx->run_tgt == index) { index->ctx->run_tgt = nullptr; index->ctx->run_active = false; }
-  if (index->d_nodes) (void)hipFree(index->d_nodes);
-  if (index->d_pts) (void)hipFree(index->d_pts);
-  if (index->d_nrm) (void)hipFree(index->d_nrm);
-  if (index->d_axis2) (void)hipFree(index->d_axis2);
+  if (index->tmp_alloc) {   // (back to the cache of the stream the build and every use were enqueued on: reused behind them)
+    for (void *p : {(void *)index->d_nodes, (void *)index->d_pts, (void *)index->d_nrm, (void *)index->d_axis2}) tmp_free(index->alloc_stream, p);
+  } else {
+    if (index->d_nodes) (void)hipFree(index->d_nodes);
+    if (index->d_pts) (void)hipFree(index->d_pts);
+    if (index->d_nrm) (void)hipFree(index->d_nrm);
+    if (index->d_axis2) (void)hipFree(index->d_axis2);
+  }
   for (void *p : {(void *)index->d_gpts, (void *)index->d_gnrm, (void *)index->d_cell_start, (void *)index->d_gpos})
     if (p) (void)hipFree(p);
   delete index;

@@ -674,9 +674,13 @@ using LevelSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocp
 
 // d_src: n finite points (float4, w = original index bits) in any order, d_src_nrm optional (same order).
 // Allocates *d_nodes ((2 << D) * 48 B), *d_pts and (if normals) *d_nrm.
+// tmp_alloc: the index is a temporary of one entry point (the outlier filter's, a feature stage's): its buffers come from the
+// stream's cache of temporaries (tmp_malloc) instead of hipMalloc — three allocations and, later, three device-synchronising frees of
+// 2-15 MB each, 0.2-0.3 ms apiece (ope_index::tmp_alloc, ope_index_free).
 hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float4 *d_src_nrm, size_t n, int leaf_size,
                             const float bb_lo[3], const float bb_hi[3], int *out_depth, float4 **d_nodes, float4 **d_pts,
-                            float4 **d_nrm, float4 **d_axis2) {
+                            float4 **d_nrm, float4 **d_axis2, bool tmp_alloc) {
+  auto alloc = [&](void **p, size_t bytes) { return tmp_alloc ? tmp_malloc(stream, p, bytes) : hipMalloc(p, bytes); };
   if (leaf_size < 1) leaf_size = 16;
   int D = 0;
   while (((n + ((size_t)1 << D) - 1) >> D) > (size_t)leaf_size) ++D;
@@ -694,11 +698,11 @@ hipError_t build_bvh_device(hipStream_t stream, const float4 *d_src, const float
   const unsigned nb = (unsigned)((n + 255) / 256);
   const int bbox_rows = (int)std::max<size_t>(1, std::min<size_t>(kBboxMaxRows, n / (256 * 1024)));   // keep >= ~1024 blocks
   const unsigned nb_bbox = (unsigned)((n + 256 * (size_t)bbox_rows - 1) / (256 * (size_t)bbox_rows));
-  hipError_t e = hipMalloc((void **)d_nodes, n_nodes * kNodeFloats * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void **)d_axis2, n_nodes * sizeof(float4));
-  if (e == hipSuccess) e = hipMalloc((void **)d_pts, sizeof(float4) * (n + kPtsPad));
+  hipError_t e = alloc((void **)d_nodes, n_nodes * kNodeFloats * sizeof(float));
+  if (e == hipSuccess) e = alloc((void **)d_axis2, n_nodes * sizeof(float4));
+  if (e == hipSuccess) e = alloc((void **)d_pts, sizeof(float4) * (n + kPtsPad));
   if (e == hipSuccess) e = hipMemsetAsync(*d_pts + n, 0, sizeof(float4) * kPtsPad, stream);
-  if (e == hipSuccess && d_src_nrm) e = hipMalloc((void **)d_nrm, sizeof(float4) * n);
+  if (e == hipSuccess && d_src_nrm) e = alloc((void **)d_nrm, sizeof(float4) * n);
   if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_keys, 8 * n);
   if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_keys2, 8 * n);
   if (e == hipSuccess) e = tmp_malloc(stream, (void **)&d_order, 4 * n);

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void sacia_error_kernel(CloudView src, BvhView
 static int self_index(ope_ctx *ctx, const ope_cloud *cloud, ope_index **out) {
   ope_index_params p;
   ope_index_default_params(&p);
-  return ope_index_build(ctx, cloud, &p, out);
+  return index_build_tmp(ctx, cloud, &p, out);   // (freed by the entry point that asked for it: a temporary)
 }
 
 static void colmajor_to_rows12(const float *T, float rows[12]) {
@@ -578,9 +578,9 @@ int ope_radius_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *i
   int32_t *d_cnt = nullptr, *d_idx = nullptr;
   float *d_d2 = nullptr;
   const size_t m = std::max<size_t>((size_t)max_nn * n, 1);
-  hipError_t e = hipMalloc((void **)&d_cnt, sizeof(int32_t) * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_idx, sizeof(int32_t) * m);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_d2, sizeof(float) * m);
+  hipError_t e = tmp_malloc(ctx->stream, (void **)&d_cnt, sizeof(int32_t) * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_idx, sizeof(int32_t) * m);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_d2, sizeof(float) * m);
   std::vector<int32_t> hc(n), hi(m);
   std::vector<float> hd(m);
   if (e == hipSuccess) {
@@ -592,9 +592,9 @@ int ope_radius_search(ope_ctx *ctx, const ope_cloud *queries, const ope_index *i
   if (e == hipSuccess && max_nn) e = hipMemcpyAsync(hi.data(), d_idx, sizeof(int32_t) * m, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess && max_nn) e = hipMemcpyAsync(hd.data(), d_d2, sizeof(float) * m, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (d_cnt) (void)hipFree(d_cnt);
-  if (d_idx) (void)hipFree(d_idx);
-  if (d_d2) (void)hipFree(d_d2);
+  tmp_free(ctx->stream, d_cnt);
+  tmp_free(ctx->stream, d_idx);
+  tmp_free(ctx->stream, d_d2);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_radius_search: ") + hipGetErrorString(e));
   for (size_t i = 0; i < n; ++i) {
     const size_t o = (size_t)queries->perm[i];
@@ -697,11 +697,11 @@ int ope_fpfh(ope_ctx *ctx, const ope_cloud *cloud, float radius, float *out33) {
   float *d_spfh = nullptr, *d_out = nullptr;
   uint32_t *d_self = nullptr;
   unsigned long long *d_total = nullptr;
-  hipError_t e = hipMalloc((void **)&d_spfh, sizeof(float) * kSpfhStride * ix->n);
+  hipError_t e = tmp_malloc(ctx->stream, (void **)&d_spfh, sizeof(float) * kSpfhStride * ix->n);
   if (e == hipSuccess) e = hipMemsetAsync(d_spfh, 0, sizeof(float) * kSpfhStride * ix->n, ctx->stream);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_out, sizeof(float) * 33 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_self, sizeof(uint32_t) * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_total, sizeof(unsigned long long));
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_out, sizeof(float) * 33 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_self, sizeof(uint32_t) * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_total, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemsetAsync(d_total, 0, sizeof(unsigned long long), ctx->stream);
   if (e == hipSuccess) {
     const int nblocks = (int)std::min<size_t>((n + kFeatBlock - 1) / kFeatBlock, 4096);
@@ -732,10 +732,10 @@ int ope_fpfh(ope_ctx *ctx, const ope_cloud *cloud, float radius, float *out33) {
       ctx->last_fpfh_mean_neighbours = m;
     }
   }
-  if (d_spfh) (void)hipFree(d_spfh);
-  if (d_out) (void)hipFree(d_out);
-  if (d_self) (void)hipFree(d_self);
-  if (d_total) (void)hipFree(d_total);
+  tmp_free(ctx->stream, d_spfh);
+  tmp_free(ctx->stream, d_out);
+  tmp_free(ctx->stream, d_self);
+  tmp_free(ctx->stream, d_total);
   ope_index_free(ix);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_fpfh: ") + hipGetErrorString(e));
   return OPE_OK;
@@ -814,11 +814,11 @@ int ope_sacia(ope_ctx *ctx, const ope_cloud *src, const float *src_feat33, const
     float *d_tf = nullptr, *d_qf = nullptr;
     int32_t *d_nn = nullptr;
     std::vector<int32_t> nn(uniq.size() * K);
-    hipError_t e = hipMalloc((void **)&d_tf, sizeof(float) * 33 * (size_t)nt);
+    hipError_t e = tmp_malloc(ctx->stream, (void **)&d_tf, sizeof(float) * 33 * (size_t)nt);
     if (e == hipSuccess) e = h2d_copy(ctx->stream, d_tf, tgt_feat33, sizeof(float) * 33 * (size_t)nt);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_qf, sizeof(float) * qf.size());
+    if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_qf, sizeof(float) * qf.size());
     if (e == hipSuccess) e = h2d_copy(ctx->stream, d_qf, qf.data(), sizeof(float) * qf.size());
-    if (e == hipSuccess) e = hipMalloc((void **)&d_nn, sizeof(int32_t) * nn.size());
+    if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_nn, sizeof(int32_t) * nn.size());
     if (e == hipSuccess) {
       {
         // every query descriptor is compared with every target descriptor: 132 B of each, the target set once per query
@@ -828,9 +828,9 @@ int ope_sacia(ope_ctx *ctx, const ope_cloud *src, const float *src_feat33, const
       e = hipMemcpyAsync(nn.data(), d_nn, sizeof(int32_t) * nn.size(), hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
-    if (d_tf) (void)hipFree(d_tf);
-    if (d_qf) (void)hipFree(d_qf);
-    if (d_nn) (void)hipFree(d_nn);
+    tmp_free(ctx->stream, d_tf);
+    tmp_free(ctx->stream, d_qf);
+    tmp_free(ctx->stream, d_nn);
     if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_sacia(feature knn): ") + hipGetErrorString(e));
     for (size_t j = 0; j < samp.size(); ++j) {
       const int32_t *row = &nn[(size_t)slot[samp[j]] * K];
@@ -857,9 +857,9 @@ int ope_sacia(ope_ctx *ctx, const ope_cloud *src, const float *src_feat33, const
   float *d_rows = nullptr;
   double *d_part = nullptr;
   std::vector<double> part((size_t)H * bx);
-  hipError_t e = hipMalloc((void **)&d_rows, sizeof(float) * rows.size());
+  hipError_t e = tmp_malloc(ctx->stream, (void **)&d_rows, sizeof(float) * rows.size());
   if (e == hipSuccess) e = h2d_copy(ctx->stream, d_rows, rows.data(), sizeof(float) * rows.size());
-  if (e == hipSuccess) e = hipMalloc((void **)&d_part, sizeof(double) * part.size());
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_part, sizeof(double) * part.size());
   if (e == hipSuccess) {
     {
       // 24 N_s per hypothesis (read the source point, gather its nearest target point)
@@ -870,8 +870,8 @@ int ope_sacia(ope_ctx *ctx, const ope_cloud *src, const float *src_feat33, const
     e = hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
-  if (d_rows) (void)hipFree(d_rows);
-  if (d_part) (void)hipFree(d_part);
+  tmp_free(ctx->stream, d_rows);
+  tmp_free(ctx->stream, d_part);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_sacia(error metric): ") + hipGetErrorString(e));
   // non-finite source points score 1.0 each, as a failed search does in computeErrorMetric
   const double invalid = (double)(src->n - src->n_valid);

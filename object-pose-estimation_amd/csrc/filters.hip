@@ -416,7 +416,7 @@ static int sor_core(ope_ctx *ctx, const ope_cloud *cloud, int mean_k, double std
     ope_index_params ip;
     ope_index_default_params(&ip);
     ip.grid = 0;   // this index serves one k-NN pass
-    int rc = ope_index_build(ctx, cloud, &ip, &ix);
+    int rc = index_build_tmp(ctx, cloud, &ip, &ix);   // (a temporary of this call: no hipMalloc / hipFree)
     if (rc != OPE_OK) return rc;
     hipError_t e = hipSuccess;
     {

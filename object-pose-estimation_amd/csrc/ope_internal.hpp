@@ -300,6 +300,8 @@ struct ope_index {
   double pivot[3] = {0, 0, 0};
   float bb_lo[3] = {0, 0, 0}, bb_hi[3] = {0, 0, 0};
   float4 *d_axis2 = nullptr;
+  bool tmp_alloc = false;             // the four buffers above come from the stream's cache of temporaries (index_build_tmp)
+  hipStream_t alloc_stream = nullptr;
   // uniform grid over the same points (device-built indexes)
   float4 *d_gpts = nullptr, *d_gnrm = nullptr;
   uint32_t *d_cell_start = nullptr, *d_gpos = nullptr;
@@ -548,5 +550,11 @@ int select_cloud_device(ope_ctx *ctx, const ope_cloud *cloud, const int32_t *d_i
 int compact_cloud_device(ope_ctx *ctx, const ope_cloud *cloud, const unsigned char *d_keep, ope_cloud **out, int32_t *d_idx_out, size_t *n_out);
 
 void build_bvh_host(const float *xyz, const int32_t *ids, const float *nrm, size_t n, int leaf_size, HostBvh &out);
+// api.hip: ope_index_build's body; temporary = the index lives inside one entry point and its buffers come from (and go back to) the
+// stream's cache of temporaries instead of hipMalloc / hipFree
+int index_build_impl(ope_ctx *ctx, const ope_cloud *target, const ope_index_params *params, bool temporary, ope_index **out);
+inline int index_build_tmp(ope_ctx *ctx, const ope_cloud *target, const ope_index_params *params, ope_index **out) {
+  return index_build_impl(ctx, target, params, true, out);
+}
 
 }  // namespace ope
