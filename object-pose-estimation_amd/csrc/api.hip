@@ -232,7 +232,7 @@ static int enqueue_accumulate(ope_ctx *ctx, bool atomic_sums = false) {
   // order buys nothing there and its sorts queue up behind the launch — BuildModel's loop, 20 views of 500 k points: 1.50 s with plans,
   // 1.46-1.47 s without)
   const bool no_plan = no_plan_env || ctx->run_params.deterministic_sums != 0 ||
-                       (ctx->run_params.corr_mode == OPE_CORR_NORMAL_SHOOTING && nch > 8u * (uint32_t)ctx->n_cu * 4u * 4u);
+                       (ctx->run_params.corr_mode == OPE_CORR_NORMAL_SHOOTING && nch > 8u * (uint32_t)ctx->n_cu * 4u * 4u && !dev_env("OPE_NS_PLAN_ALWAYS"));
   // Chunk costs are double-buffered by launch parity: launch L writes half L & 1, and a plan made beside launch L (on the side
   // stream) reads the half launch L - 1 wrote — the measuring launch in front of every plan, in which every chunk reports.
   // Launch L + 1, which writes that half again, waits for the plan first (ev_plan_done).  (Round 3 copied the one buffer on the
@@ -781,6 +781,7 @@ int ope::index_build_impl(ope_ctx *ctx, const ope_cloud *target, const ope_index
     std::memcpy(ix->bb_lo, target->bb_lo, sizeof ix->bb_lo);
     std::memcpy(ix->bb_hi, target->bb_hi, sizeof ix->bb_hi);
     for (int d = 0; d < 3; ++d) ix->pivot[d] = 0.5 * ((double)target->bb_lo[d] + (double)target->bb_hi[d]);
+    if (dev_env("OPE_NO_TMP_INDEX")) temporary = false;   // developer A/B switch
     ix->tmp_alloc = temporary;
     ix->alloc_stream = ctx->stream;
     const hipError_t e = build_bvh_device(ctx->stream, target->d_xyzw, target->d_nrm, n, dp.leaf_size, target->bb_lo, target->bb_hi,

@@ -351,16 +351,16 @@ extern "C" int ope_voxel_grid_rgb(ope_ctx *ctx, const ope_cloud *cloud, const fl
   uint32_t *d_rgb = nullptr, *d_out_rgb = nullptr;
   void *d_tmp = nullptr;
   uint32_t count = 0;
-  hipError_t e = hipMalloc((void **)&d_keys, 8 * n);
-  if (e == hipSuccess && rgb) e = hipMalloc((void **)&d_rgb, 4 * n);
-  if (e == hipSuccess && rgb) e = hipMalloc((void **)&d_out_rgb, 4 * nv);
+  hipError_t e = tmp_malloc(ctx->stream, (void **)&d_keys, 8 * n);
+  if (e == hipSuccess && rgb) e = tmp_malloc(ctx->stream, (void **)&d_rgb, 4 * n);
+  if (e == hipSuccess && rgb) e = tmp_malloc(ctx->stream, (void **)&d_out_rgb, 4 * nv);
   if (e == hipSuccess && rgb) e = h2d_copy(ctx->stream, d_rgb, rgb, 4 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_keys2, 8 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_vals, 4 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_vals2, 4 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_flags, 4 * (n + 1));
-  if (e == hipSuccess) e = hipMalloc((void **)&d_slot, 4 * (n + 1));
-  if (e == hipSuccess) e = hipMalloc((void **)&d_out, 12 * nv);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_keys2, 8 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_vals, 4 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_vals2, 4 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_flags, 4 * (n + 1));
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_slot, 4 * (n + 1));
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_out, 12 * nv);
   if (e == hipSuccess) {
     const unsigned nb = (unsigned)((n + 256) / 256);
     hipLaunchKernelGGL(grid_key_kernel, dim3(nb), dim3(256), 0, ctx->stream, cloud->view(), inv[0], inv[1], inv[2], (int)min_b[0],
@@ -370,7 +370,7 @@ extern "C" int ope_voxel_grid_rgb(ope_ctx *ctx, const ope_cloud *cloud, const fl
     if (e == hipSuccess)
       e = rocprim::exclusive_scan(nullptr, tmp_scan, d_flags, d_slot, 0u, n + 1, rocprim::plus<uint32_t>(), ctx->stream);
     const size_t tmp_bytes = std::max(tmp_sort, tmp_scan);
-    if (e == hipSuccess) e = hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16));
+    if (e == hipSuccess) e = tmp_malloc(ctx->stream, &d_tmp, std::max<size_t>(tmp_bytes, 16));
     size_t tb = tmp_bytes;
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 64, ctx->stream);
     if (e == hipSuccess) {
@@ -389,7 +389,7 @@ extern "C" int ope_voxel_grid_rgb(ope_ctx *ctx, const ope_cloud *cloud, const fl
   }
   for (void *p : {(void *)d_keys, (void *)d_keys2, (void *)d_vals, (void *)d_vals2, (void *)d_flags, (void *)d_slot, (void *)d_out,
                   (void *)d_rgb, (void *)d_out_rgb, d_tmp})
-    if (p) (void)hipFree(p);
+    tmp_free(ctx->stream, p);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_voxel_grid: ") + hipGetErrorString(e));
   *n_out = count;
   return OPE_OK;
@@ -556,9 +556,9 @@ extern "C" int ope_reject_pairs(ope_ctx *ctx, int kind, const float *a, const fl
   OPE_HIP(ctx, hipSetDevice(ctx->device));
   float *d_a = nullptr, *d_b = nullptr;
   unsigned char *d_k = nullptr;
-  hipError_t e = hipMalloc((void **)&d_a, 12 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_b, 12 * n);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_k, n);
+  hipError_t e = tmp_malloc(ctx->stream, (void **)&d_a, 12 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_b, 12 * n);
+  if (e == hipSuccess) e = tmp_malloc(ctx->stream, (void **)&d_k, n);
   if (e == hipSuccess) e = h2d_copy(ctx->stream, d_a, a, 12 * n);
   if (e == hipSuccess) e = h2d_copy(ctx->stream, d_b, b, 12 * n);
   if (e == hipSuccess) {
@@ -567,7 +567,7 @@ extern "C" int ope_reject_pairs(ope_ctx *ctx, int kind, const float *a, const fl
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
   for (void *p : {(void *)d_a, (void *)d_b, (void *)d_k})
-    if (p) (void)hipFree(p);
+    tmp_free(ctx->stream, p);
   if (e != hipSuccess) return set_err(ctx, OPE_EHIP, std::string("ope_reject_pairs: ") + hipGetErrorString(e));
   return OPE_OK;
 }

@@ -188,11 +188,29 @@ def frame_views(n_frames: int, n_per_frame: int, noise_sigma: float = 0.0002, re
     args = [(i, n_per_frame, noise_sigma, n_azimuths) for i in range(n_frames)]
     out = None
     if workers > 1 and n_frames > 1:
-        import concurrent.futures as cf
-        import multiprocessing as mp
-        try:   # (spawn: the caller may hold a GPU context; an executor whose workers cannot start raises instead of respawning them)
-            with cf.ProcessPoolExecutor(min(workers, n_frames), mp_context=mp.get_context("spawn")) as pool:
-                out = list(pool.map(_frame_view, *zip(*args)))
+        # child INTERPRETERS, not multiprocessing: a spawned multiprocessing worker imports the caller's __main__ again, and a
+        # script without a __main__ guard then runs its whole body (its own frame_views call included) in every worker
+        import os, subprocess, sys, tempfile
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        code = ("import importlib, sys, numpy as np; sys.path.insert(0, sys.argv[1]); "
+                "s = importlib.import_module('object-pose-estimation_amd.synth'); "
+                "f, T = s._frame_view(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5])); "
+                "np.save(sys.argv[6] + '.f.npy', f); np.save(sys.argv[6] + '.T.npy', T)")
+        try:
+            with tempfile.TemporaryDirectory() as tmp:
+                out = [None] * n_frames
+                pending = list(range(n_frames))
+                running = []
+                while pending or running:
+                    while pending and len(running) < workers:
+                        i = pending.pop(0)
+                        base = os.path.join(tmp, f"frame{i}")
+                        running.append((i, base, subprocess.Popen([sys.executable, "-c", code, root, str(i), str(n_per_frame), repr(float(noise_sigma)),
+                                                                   str(n_azimuths), base], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+                    i, base, pr = running.pop(0)
+                    if pr.wait(timeout=1800) != 0:
+                        raise RuntimeError("frame worker failed")
+                    out[i] = (np.load(base + ".f.npy"), np.load(base + ".T.npy"))
         except Exception:
             out = None
     if out is None:
