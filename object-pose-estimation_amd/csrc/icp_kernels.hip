@@ -232,7 +232,12 @@ __device__ __forceinline__ bool cert_worth_building(float d2_prev, float cert_k,
 __device__ unsigned long long g_knn_stats[8];
 #endif
 template <int MODE, bool NRM, bool RECIP = false, bool PACKET = false, int KREG = 20, bool CERT = false>
-__global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !RECIP && !CERT) ? kAccWavesPerSimd : 4) void icp_accumulate_kernel(
+#ifndef OPE_KNN_WAVES
+#define OPE_KNN_WAVES 4   // waves per SIMD of the k-NN instantiations (developer A/B: make VARIANT=... EXTRA=-DOPE_KNN_WAVES=3).
+// k = 20 on C3, tools/ns_bench.py: 4 waves (128 VGPRs, 9 spilled) 0.545-0.554 ms per iteration; 3 waves (139 VGPRs, none spilled) 0.68;
+// 5 waves (96 VGPRs, 53 spilled) 0.90: the walks need the fourth wave more than their nine registers
+#endif
+__global__ __launch_bounds__(MODE == 0 ? kAccBlock : kKnnBlock, (MODE == 0 && !RECIP && !CERT) ? kAccWavesPerSimd : (MODE == 2 ? OPE_KNN_WAVES : 4)) void icp_accumulate_kernel(
     CloudView src, BvhView tgt, BvhView srcix, const IcpState *__restrict__ st, double *__restrict__ partials,
     int32_t *__restrict__ corr_match, float *__restrict__ corr_d2, uint32_t *__restrict__ work_counter,
     uint32_t *__restrict__ hint, const uint32_t *__restrict__ chunk_order, uint32_t *__restrict__ chunk_cost,
