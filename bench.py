@@ -234,7 +234,7 @@ def main() -> int:
                   "sacia_hypotheses_per_s": 400 / (sa_ms * 1e-3) if sa_ms > 0 else None,
                   "stages": stage, "kernels": kroof,
                   "note": "total_ms: the second pass over the same frame (device-resident hand-over between the stages; host wall-clock incl. "
-                          "the frame's upload, device index builds and the read-backs that are left: sizes, outlier-removal distances, 33 x "
+                          "the frame's upload, device index builds and the read-backs that are left: sizes, the outlier filter's two sums, 33 x "
                           "key points descriptors); first_frame_total_ms: the first pass, which also loads every kernel it touches; `kernels` "
                           "are HIP-event times of the launches with the algorithmic bytes of SURVEY 8d; none of it is part of value"}
 
