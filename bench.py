@@ -24,7 +24,8 @@ Rank 0 prints one JSON line with `roofline` (dominant kernel = the accumulate ke
 launch stream inside the timed region), `phases` (from the coarse pose = `value`; steady state, reported separately),
 `coarse_stage` (per-kernel HIP-event times with the algorithmic bytes of SURVEY 8d, FPFH points/s, SAC-IA hypotheses/s)
 and, at N = 1, `cpu_baseline` (the C oracle, a scalar single-thread port of the PCL path, on a bounded sample of the same
-workload).
+workload).  A timed window during which an overlapped update launch gave up its bounded wait (ope.h: ope_icp_update_fallbacks)
+has timed launches that did nothing: it is detected and measured again (`config.update_launch` says how).
 """
 from __future__ import annotations
 
